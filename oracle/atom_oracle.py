@@ -1,0 +1,367 @@
+"""CPU oracle for Atom's W4A4 mixed-precision GEMM hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (``atom_amd/``) may import
+this module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker.
+
+This is a numpy restatement of the reference algorithms (file:line relative to
+/root/reference):
+
+* simulated ("fake") quantisation -- ``model/quant.py:118-183`` (quantize_tensor),
+  ``:68-107`` (quantize_tensor_channel_group), ``:187-231``
+  (quantize_activation_wrapper), ``model/qLinearLayer.py:42-78`` (QLinearLayer.quant).
+  Restated in the *integer domain*: we return (codes, scales) such that
+  ``codes * scales`` reproduces the reference's FP16 fake-quant tensor bit for bit.
+  PINNED: ``tests/golden/gen_golden.py`` runs the unmodified reference modules and
+  stores their outputs; ``tests/test_oracle_golden.py`` checks this file against them.
+* kernel-flavoured quantisation (no clip, FP32 ``x*(1/s)``, round-half-away) --
+  ``kernels/include/Reorder/Reorder.cuh:64-190``, ``RMSNorm/RMSNorm.cuh:66-238``,
+  ``Activate/Activate.cuh:67-180`` and their CPU goldens
+  ``e2e/punica-atom/punica/ops/csrc/Reorder/test_Reorder.cu:41-112`` etc.
+  The reference holds no stored vectors for these (its self-check is tolerance
+  based, ints +-1 / scales 1e-3, on rand() data) -> "parity unpinned" beyond the
+  tolerance test we restate in tests/.
+* the GEMM -- ``kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:404-434`` (dequant),
+  ``:713-727`` (operand doc), A-scale layout ``Reorder.cuh:39-50``.
+  GEMM numerics are pinned by NO reference test ("parity unpinned"): the
+  golden for it is constructed from the reference's simulated path
+  (``F.linear`` on fake-quant operands, ``model/qLinearLayer.py:32-35``).
+
+All FP16 arithmetic follows torch's CPU/GPU "opmath" convention, which numpy's
+float16 also uses: operands widened to float32, one float32 op, result rounded to
+float16 (round-to-nearest-even).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GROUP = 128
+KEEPER = 128
+
+f16 = np.float16
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------- layout helpers
+def scale_index(row: int) -> int:
+    """Offset (in halves) of row's first scale replica. Reorder.cuh:39-44."""
+    bottom_upper = (row // 8) % 2
+    group_idx = row % 8
+    group_nums = row // 16
+    return group_nums * 64 + group_idx * 8 + bottom_upper
+
+
+def scale_size(rows: int) -> int:
+    """Leading dimension (halves) of the replicated A-scale layout.
+    SCALE_SIZE_A, Reorder.cuh:50 == punica/ops/__init__.py:137-138."""
+    x = rows
+    return x // 16 * 64 + 64 - (1 - (x % 16) // 8) * (8 - (x % 8)) * 8
+
+
+def scales_to_ref_layout(s: np.ndarray) -> np.ndarray:
+    """[G, M] plain -> [G, scale_size(M)] replicated layout (4 replicas at +0,+2,+4,+6).
+    Reorder.cuh:137-156.  Unwritten slots are zero."""
+    s = np.asarray(s, dtype=f16)
+    one_d = s.ndim == 1
+    if one_d:
+        s = s[None, :]
+    G, M = s.shape
+    out = np.zeros((G, scale_size(M)), dtype=f16)
+    for r in range(M):
+        b = scale_index(r)
+        for j in range(4):
+            out[:, b + 2 * j] = s[:, r]
+    return out[0] if one_d else out
+
+
+def scales_from_ref_layout(s: np.ndarray, M: int) -> np.ndarray:
+    s = np.asarray(s)
+    one_d = s.ndim == 1
+    if one_d:
+        s = s[None, :]
+    idx = np.array([scale_index(r) for r in range(M)], dtype=np.int64)
+    out = s[:, idx]
+    return out[0] if one_d else out
+
+
+def pack_int4(codes: np.ndarray) -> np.ndarray:
+    """int8 codes in [-8,7], last dim even -> uint8, element 2j in the LOW nibble,
+    2j+1 in the HIGH nibble (two's complement). PackInt4, Reorder.cuh:16-19,174-176."""
+    c = np.asarray(codes).astype(np.int16)
+    lo = c[..., 0::2] & 0xF
+    hi = c[..., 1::2] & 0xF
+    return (lo | (hi << 4)).astype(np.uint8)
+
+
+def unpack_int4(packed: np.ndarray) -> np.ndarray:
+    p = np.asarray(packed, dtype=np.uint8).astype(np.int16)
+    lo = p & 0xF
+    hi = (p >> 4) & 0xF
+    lo = np.where(lo >= 8, lo - 16, lo)
+    hi = np.where(hi >= 8, hi - 16, hi)
+    out = np.empty(p.shape[:-1] + (p.shape[-1] * 2,), dtype=np.int8)
+    out[..., 0::2] = lo
+    out[..., 1::2] = hi
+    return out
+
+
+# --------------------------------------------------------------------------- rounding helpers
+def _rne(x):
+    return np.rint(x)  # round half to even == torch.round
+
+
+def _round_half_away(x):
+    """C/CUDA round(): half away from zero (Reorder.cuh:171-172)."""
+    x = np.asarray(x, dtype=f32)
+    return np.sign(x) * np.floor(np.abs(x) + f32(0.5))
+
+
+# --------------------------------------------------------------------------- quantisation tails
+def quant_groups_sim(v16: np.ndarray, n_bits: int, clip: float):
+    """quantize_tensor(sym=True, group_size=0) on rows of ``v16`` -- quant.py:141-142,166-172,181.
+
+    v16: float16 [rows, group].  Returns (codes int8 [rows, group], scale float16 [rows]).
+    Every step is one float32 op rounded to float16, exactly as torch does for half tensors.
+    """
+    v16 = np.asarray(v16, dtype=f16)
+    qmax = 2 ** (n_bits - 1) - 1
+    qmin = -(2 ** (n_bits - 1))
+    amax = np.abs(v16).max(axis=-1)                        # exact in fp16
+    amax = np.maximum(amax, f16(1e-5))                     # .clamp(min=1e-5): scalar cast to half
+    if clip < 1.0:
+        amax = (amax.astype(f32) * f32(clip)).astype(f16)  # w_max * clip_ratio
+    scale = (amax.astype(f32) / f32(qmax)).astype(f16)     # scales = w_max / q_max
+    q = (v16.astype(f32) / scale.astype(f32)[..., None]).astype(f16)   # w / scales (half)
+    q = np.clip(_rne(q.astype(f32)), qmin, qmax)           # clamp(round(.))
+    return q.astype(np.int8), scale
+
+
+def dequant_sim(codes: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    """(clamp(round(w/s)) - 0) * s in half -- quant.py:181."""
+    with np.errstate(over="ignore"):
+        return (codes.astype(f32) * scale.astype(f32)[..., None]).astype(f16)
+
+
+def quant_groups_kernel(v32: np.ndarray, n_bits: int, clip: float = 1.0):
+    """The CUDA kernels' tail -- Reorder.cuh:137-178 (== RMSNorm.cuh:153-237, Activate.cuh:112-167).
+
+    v32: float32 [rows, group] (values already rounded to fp16 where the kernel does so).
+    scale_f = amax / qmax (fp32); stored scale = half(scale_f); r = 1/scale_f;
+    q = clamp(round_half_away(v * r)).
+    Divergence, documented: an all-zero group gives scale 0 and codes 0 here (the reference
+    computes 0 * inf = NaN -> undefined int cast).
+    """
+    v32 = np.asarray(v32, dtype=f32)
+    qmax = 2 ** (n_bits - 1) - 1
+    qmin = -(2 ** (n_bits - 1))
+    amax = np.abs(v32).max(axis=-1).astype(f32)
+    if clip < 1.0:
+        amax = (amax * f32(clip)).astype(f32)
+    scale_f = (amax / f32(qmax)).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (f32(1.0) / scale_f).astype(f32)
+        q = _round_half_away((v32 * r[..., None]).astype(f32))
+    q = np.where(scale_f[..., None] == 0, f32(0), q)
+    q = np.clip(q, qmin, qmax)
+    return q.astype(np.int8), scale_f.astype(f16)
+
+
+def _quant_row_tail(y, mode: str, clip: float):
+    """Shared tail of the three activation ops: split [M,K] into G INT4 groups + 1 INT8 keeper group.
+
+    y: float16 (sim) or float32 (kernel) [M, K], already in reordered channel order.
+    Returns dict(q4 int8 [M,K4], s4 f16 [M,G], q8 int8 [M,128], s8 f16 [M]).
+    """
+    M, K = y.shape
+    assert K % GROUP == 0 and K > KEEPER
+    K4 = K - KEEPER
+    G = K4 // GROUP
+    body = y[:, :K4].reshape(M * G, GROUP)
+    keep = y[:, K4:]
+    if mode == "sim":
+        q4, s4 = quant_groups_sim(body, 4, clip)           # quant.py:192-201,225
+        q8, s8 = quant_groups_sim(keep, 8, 1.0)            # quant.py:219-220 (no clip)
+    elif mode == "kernel":
+        q4, s4 = quant_groups_kernel(body, 4, clip)
+        q8, s8 = quant_groups_kernel(keep, 8, 1.0)
+    else:
+        raise ValueError(mode)
+    return dict(q4=q4.reshape(M, K4), s4=s4.reshape(M, G), q8=q8, s8=s8)
+
+
+def act_dequant_sim(t) -> np.ndarray:
+    """Rebuild the FP16 tensor quantize_activation_wrapper returns (quant.py:225-228)."""
+    M, K4 = t["q4"].shape
+    G = K4 // GROUP
+    body = dequant_sim(t["q4"].reshape(M * G, GROUP), t["s4"].reshape(M * G)).reshape(M, K4)
+    keep = dequant_sim(t["q8"], t["s8"])
+    return np.concatenate([body, keep], axis=1)
+
+
+# --------------------------------------------------------------------------- the three activation ops
+def reorder_quant(x16: np.ndarray, reorder_index, mode: str = "sim", clip: float = 0.9):
+    """index_select(x, -1, idx) then dynamic per-token quant.
+    sim: qLlamaLayer.py:300-304 + quant.py:187-231.  kernel: Reorder.cuh:64-190."""
+    x16 = np.asarray(x16, dtype=f16)
+    idx = np.asarray(reorder_index).astype(np.int64)
+    y = x16[:, idx]
+    if mode == "kernel":
+        y = y.astype(f32)
+    return _quant_row_tail(y, mode, clip)
+
+
+def rmsnorm_f16(x16, w16, eps: float, mode: str) -> np.ndarray:
+    """RMSNorm producing the FP16 tensor that is then quantised.
+
+    sim   : HF LlamaRMSNorm (transformers 4.39 modeling_llama.py, called at qLlamaLayer.py:143):
+            var = mean(float(x)^2); y = half(float(x) * rsqrt(var+eps)); out = half(w * y).
+    kernel: RMSNorm.cuh:112-151: out = half(float(x) * float(w) * r).
+    Sum of squares is accumulated in float64 and rounded to float32 once (fp16 squares are exact in
+    fp32, so this equals the exactly-rounded sum up to ~1e-16); r = 1/sqrt(var+eps) with correctly
+    rounded fp32 sqrt and divide -- a deterministic spec the HIP kernel follows to the bit.
+    """
+    x16 = np.asarray(x16, dtype=f16)
+    w16 = np.asarray(w16, dtype=f16)
+    H = x16.shape[-1]
+    ss = (x16.astype(np.float64) ** 2).sum(axis=-1)
+    var = (ss / np.float64(H)).astype(f32)
+    r = (f32(1.0) / np.sqrt((var + f32(eps)).astype(f32))).astype(f32)
+    xf = x16.astype(f32)
+    if mode == "sim":
+        y = (xf * r[:, None]).astype(f16)
+        return (w16.astype(f32)[None, :] * y.astype(f32)).astype(f16)
+    t = (xf * w16.astype(f32)[None, :]).astype(f32)
+    return (t * r[:, None]).astype(f16)
+
+
+def rmsnorm_reorder_quant(x16, w16, eps, reorder_index, mode: str = "sim", clip: float = 0.9):
+    """sim: qLlamaLayer.py:141-151.  kernel: RMSNorm.cuh:66-238."""
+    y = rmsnorm_f16(x16, w16, eps, mode)
+    idx = np.asarray(reorder_index).astype(np.int64)
+    y = y[:, idx]
+    if mode == "kernel":
+        y = y.astype(f32)
+    return _quant_row_tail(y, mode, clip)
+
+
+def silu_mul(a16, b16, mode: str):
+    """sim: act_fn(gate)*up in half (qLlamaLayer.py:346-348): half(half(silu(a)) * b).
+    kernel: silu(float(a))*float(b) kept in FP32 (Activate.cuh:28,103-106)."""
+    a = np.asarray(a16, dtype=f16).astype(f32)
+    b = np.asarray(b16, dtype=f16).astype(f32)
+    s = (a / (f32(1.0) + np.exp(-a).astype(f32))).astype(f32)
+    if mode == "sim":
+        s = s.astype(f16).astype(f32)
+        return (s * b).astype(f16)
+    return (s * b).astype(f32)
+
+
+def silu_mul_quant(a16, b16, mode: str = "sim", clip: float = 0.9):
+    """sim: qLlamaLayer.py:345-351.  kernel: Activate.cuh:67-180. No reorder (weights pre-permuted)."""
+    return _quant_row_tail(silu_mul(a16, b16, mode), mode, clip)
+
+
+# --------------------------------------------------------------------------- weights
+def quant_weight_sim(W16: np.ndarray, w_clip: float = 0.85, channel_group: int = 2):
+    """QLinearLayer.quant (qLinearLayer.py:42-78) in the integer domain.
+
+    W16 [N,K] float16 (already column-reordered).  Keeper = last 128 columns -> INT8 per output row,
+    no clip (:58).  Remaining columns: for each 128-column slice, ``channel_group`` adjacent rows share
+    one scale (quant.py:86-87), clip w_clip, 4 bit.
+    Returns dict(q4 int8 [N,K4], s4 f16 [G,N], q8 int8 [N,128], s8 f16 [N], wq f16 [N,K]).
+    """
+    W16 = np.asarray(W16, dtype=f16)
+    N, K = W16.shape
+    K4 = K - KEEPER
+    G = K4 // GROUP
+    cg = channel_group
+    assert N % cg == 0
+    q8, s8 = quant_groups_sim(W16[:, K4:], 8, 1.0)
+    q4 = np.empty((N, K4), dtype=np.int8)
+    s4 = np.empty((G, N), dtype=f16)
+    for g in range(G):
+        blk = W16[:, g * GROUP:(g + 1) * GROUP].reshape(N // cg, cg * GROUP)
+        q, s = quant_groups_sim(blk, 4, w_clip)
+        q4[:, g * GROUP:(g + 1) * GROUP] = q.reshape(N, GROUP)
+        s4[g] = np.repeat(s, cg)
+    wq = np.empty((N, K), dtype=f16)
+    for g in range(G):
+        wq[:, g * GROUP:(g + 1) * GROUP] = dequant_sim(q4[:, g * GROUP:(g + 1) * GROUP], s4[g])
+    wq[:, K4:] = dequant_sim(q8, s8)
+    return dict(q4=q4, s4=s4, q8=q8, s8=s8, wq=wq)
+
+
+# --------------------------------------------------------------------------- GEMM
+def _group_int_dots(qa4, qb4, g):
+    a = qa4[:, g * GROUP:(g + 1) * GROUP].astype(f32)
+    b = qb4[:, g * GROUP:(g + 1) * GROUP].astype(f32)
+    return a @ b.T  # exact: |sum| <= 128*64 < 2^24
+
+
+def gemm_w4a4_exact(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
+    """D = sum_g (A4_g . B4_g^T) sA[m,g] sB[g,n] + (A8 . B8^T) sA8[m] sB8[n] in float64.
+
+    qa4 int8 [M,K4], qb4 int8 [N,K4], sA f16 [M,G], sB f16 [G,N], qa8 int8 [M,128], qb8 int8 [N,128],
+    sA8 f16 [M], sB8 f16 [N].  Mathematical value of the reference GEMM
+    (Dense_layer_gemm_i4_o16.cuh:404-434, :590-691) with no intermediate rounding."""
+    M, K4 = qa4.shape
+    G = K4 // GROUP
+    D = np.zeros((M, qb4.shape[0]), dtype=np.float64)
+    for g in range(G):
+        I = _group_int_dots(qa4, qb4, g).astype(np.float64)
+        D += I * sA[:, g].astype(np.float64)[:, None] * sB[g].astype(np.float64)[None, :]
+    I8 = (qa8.astype(f32) @ qb8.astype(f32).T).astype(np.float64)  # |sum| <= 2^21, exact
+    D += I8 * sA8.astype(np.float64)[:, None] * sB8.astype(np.float64)[None, :]
+    return D
+
+
+def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
+    """The reference kernel's rounding order: scale product in FP16 (__hmul2, :417), widened to
+    FP32, c_fp32 += float(int_acc) * s per group in group order then keeper (:404-434, :680-691),
+    D = half(c) (:240-243).  Returns float16 [M,N]."""
+    M, K4 = qa4.shape
+    G = K4 // GROUP
+    c = np.zeros((M, qb4.shape[0]), dtype=f32)
+    for g in range(G):
+        I = _group_int_dots(qa4, qb4, g)
+        s = (sA[:, g].astype(f32)[:, None] * sB[g].astype(f32)[None, :]).astype(f16).astype(f32)
+        c = (c + (I * s).astype(f32)).astype(f32)
+    I8 = qa8.astype(f32) @ qb8.astype(f32).T
+    s = (sA8.astype(f32)[:, None] * sB8.astype(f32)[None, :]).astype(f16).astype(f32)
+    c = (c + (I8 * s).astype(f32)).astype(f32)
+    return c.astype(f16)
+
+
+def quant_o4(D32: np.ndarray):
+    """The _o4 epilogue (e2e/.../GEMM/DenseLayerGEMM_i4_o4.cu:704-788): asymmetric u4 per 128-col
+    output group.  scale = (max-min)/15, zero = -min, q = round((x+zero)/scale) & 0xF  (fp32).
+    We restate the *intended* min/max (the reference's local_max_min takes abs() of both, :73-80 of
+    that file, which is only equivalent when min<=0<=max).
+    Returns (u8 packed [M,N/2], half2 (scale,zero) [M, N/128, 2])."""
+    D32 = np.asarray(D32, dtype=f32)
+    M, N = D32.shape
+    g = D32.reshape(M, N // GROUP, GROUP)
+    mx = g.max(axis=-1)
+    mn = g.min(axis=-1)
+    scale = ((mx - mn) / f32(15)).astype(f32)
+    zero = (-mn).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = _round_half_away(((g + zero[..., None]) / scale[..., None]).astype(f32))
+    q = np.where(scale[..., None] == 0, f32(0), q)
+    q = np.clip(q, 0, 15).astype(np.int16).reshape(M, N)
+    packed = ((q[:, 0::2] & 0xF) | ((q[:, 1::2] & 0xF) << 4)).astype(np.uint8)
+    sz = np.stack([scale.astype(f16), zero.astype(f16)], axis=-1)
+    return packed, sz
+
+
+# --------------------------------------------------------------------------- simulated path (the north-star oracle)
+def sim_linear(xq16: np.ndarray, wq16: np.ndarray) -> np.ndarray:
+    """QLinearLayer.forward (qLinearLayer.py:32-35): F.linear on fake-quant FP16 operands,
+    FP32 accumulate, FP16 out."""
+    return (xq16.astype(f32) @ wq16.astype(f32).T).astype(f16)
+
+
+def sim_linear_torch(xq, wq):
+    """The literal reference call, torch CPU kernels: used as bench.py's cpu_baseline ("port")."""
+    import torch
+    return torch.nn.functional.linear(xq, wq, None)
