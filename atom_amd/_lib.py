@@ -1,0 +1,87 @@
+"""ctypes binding of libatom_hip.so (the C ABI declared in include/atom_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  (The CPU oracle lives in /oracle and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatom_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK = 0
+SCALE_LAYOUT_REF = 0
+SCALE_LAYOUT_PLAIN = 1
+QUANT_KERNEL = 0
+QUANT_SIM = 1
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/atom_hip.h
+SIGNATURES = {
+    "atom_version": (ctypes.c_char_p, []),
+    "atom_strerror": (ctypes.c_char_p, [_int]),
+    "atom_scale_size": (ctypes.c_size_t, [_i64, _int]),
+    "atom_gemm_w4a4_f16": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
+    "atom_gemm_w4a4_o4": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
+    "atom_reorder_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "atom_rmsnorm_reorder_quant_f16": (_int, [_vp, _vp, _f32, _vp, _i64, _int, _int, _f32, _int,
+                                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    "atom_silu_mul_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "atom_quant_weight_w4": (_int, [_vp, _i64, _i64, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class AtomHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into atom_amd/libatom_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "all"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode != 0:
+        raise AtomHipError("building libatom_hip.so failed:\n" + r.stderr)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AtomHipError(
+                f"{LIB_PATH} not found: build it with `make -C atom_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the Atom W4A4 path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        msg = lib().atom_strerror(status).decode()
+        raise AtomHipError(f"{what} failed: {msg} (status {status})")
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

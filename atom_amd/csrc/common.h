@@ -1,0 +1,44 @@
+// Shared device/host helpers for libatom_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atom_hip.h"
+
+namespace atom {
+
+constexpr int kGroup = 128;
+constexpr int kKeeper = 128;
+
+typedef _Float16 half_t;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+// Make a float opaque to the optimiser so that fptrunc(fdiv(fpext a, fpext b)) is NOT narrowed to a
+// half-precision divide: the spec is "one correctly rounded FP32 op, then round to FP16".
+__device__ __forceinline__ float opaque(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // RNE
+__device__ __forceinline__ float round_h(float f) { return (float)(half_t)f; }
+
+// Offset (halves) of row r's first replica in the reference A-scale layout (Reorder.cuh:39-44).
+__host__ __device__ __forceinline__ int ref_scale_index(int r) {
+  return (r >> 4) * 64 + (r & 7) * 8 + ((r >> 3) & 1);
+}
+
+__host__ __device__ __forceinline__ int64_t ref_scale_size(int64_t x) {
+  return x / 16 * 64 + 64 - (1 - (x % 16) / 8) * (8 - (x % 8)) * 8;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? ATOM_OK : ATOM_ERR_LAUNCH; }
+
+}  // namespace atom

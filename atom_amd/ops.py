@@ -1,0 +1,170 @@
+"""Native op wrappers with the call surface of the reference's ``punica.ops``
+(/root/reference/e2e/punica-atom/punica/ops/__init__.py:137-219): same names, same positional arguments,
+same return tuples and output shapes/dtypes.  Each call allocates its outputs with ``torch.empty`` and
+enqueues one HIP kernel of libatom_hip.so on the current stream.
+
+Keyword-only extras (defaults reproduce the reference CUDA kernels exactly):
+  quant_mode   "kernel" (Reorder.cuh:137-178 arithmetic) | "sim" (model/quant.py arithmetic)
+  clip         clip ratio applied to the INT4 groups' absmax (1.0 = none, the kernels' behaviour)
+  scale_layout "ref" (ldmatrix-replicated layout, scale_size(M) halves per group) | "plain" ([G, M])
+  return_dequant  also return the de-quantised FP16 tensor (what quantize_activation_wrapper returns)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+GROUP_SIZE = 128
+
+_MODES = {"kernel": L.QUANT_KERNEL, "sim": L.QUANT_SIM}
+_LAYOUTS = {"ref": L.SCALE_LAYOUT_REF, "plain": L.SCALE_LAYOUT_PLAIN}
+
+
+def scale_size(x: int) -> int:
+    """punica/ops/__init__.py:137-138 (SCALE_SIZE_A, Reorder.cuh:50)."""
+    return ((x) // 16 * 64 + 64 - (1 - (x % 16) // 8) * (8 - (x % 8)) * 8)
+
+
+def _ld(rows: int, layout: str) -> int:
+    return scale_size(rows) if layout == "ref" else rows
+
+
+def _require_cuda_half(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise L.AtomHipError(f"{name} must live on the GPU: the Atom W4A4 path has no CPU fallback")
+    if t.dtype != torch.float16:
+        raise TypeError(f"{name} must be float16, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _alloc_act_outputs(bs, hidden_dim, device, layout, return_dequant):
+    # zeros, not empty, for the replicated layout: it has slots no row ever writes
+    alloc = torch.zeros if layout == "ref" else torch.empty
+    o_outlier = torch.empty((bs, GROUP_SIZE), dtype=torch.int8, device=device)
+    o_norms = torch.empty((bs, (hidden_dim - GROUP_SIZE) // 2), dtype=torch.int8, device=device)
+    outlier_scales = alloc((_ld(bs, layout),), dtype=torch.float16, device=device)
+    norm_scales = alloc((hidden_dim // GROUP_SIZE - 1, _ld(bs, layout)), dtype=torch.float16, device=device)
+    xq = torch.empty((bs, hidden_dim), dtype=torch.float16, device=device) if return_dequant else None
+    return o_outlier, o_norms, outlier_scales, norm_scales, xq
+
+
+def _ret(o_outlier, o_norms, outlier_scales, norm_scales, xq):
+    if xq is None:
+        return o_outlier, o_norms, outlier_scales, norm_scales
+    return o_outlier, o_norms, outlier_scales, norm_scales, xq
+
+
+def activate_fp16_i4(a: torch.Tensor, b: torch.Tensor, *, quant_mode="kernel", clip=1.0, scale_layout="ref",
+                     return_dequant=False):
+    """quant(silu(a) * b) -> (o_outlier i8[bs,128], o_norms i8[bs,(H-128)/2], outlier_scales, norm_scales).
+    Reference: punica/ops/__init__.py:141-156 -> run_activate_fp16_i4 (Activate.cuh:194-217).  Any H % 128 == 0
+    (the reference is hard-instantiated for 11008, punica_ops.cc:76)."""
+    _require_cuda_half(a, "a")
+    _require_cuda_half(b, "b")
+    bs, hidden_dim = a.shape
+    assert b.shape == a.shape
+    outs = _alloc_act_outputs(bs, hidden_dim, a.device, scale_layout, return_dequant)
+    st = L.lib().atom_silu_mul_quant_f16(a.data_ptr(), b.data_ptr(), bs, hidden_dim, _MODES[quant_mode], clip,
+                                          _LAYOUTS[scale_layout], outs[0].data_ptr(), outs[1].data_ptr(),
+                                          outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
+                                          L.current_stream(a.device))
+    L.check(st, "atom_silu_mul_quant_f16")
+    return _ret(*outs)
+
+
+def rmsnorm_fp16_i4(hidden_states: torch.Tensor, weight: torch.Tensor, reorder_index: torch.Tensor, eps: float, *,
+                    quant_mode="kernel", clip=1.0, scale_layout="ref", return_dequant=False):
+    """quant(index_select(RMSNorm(x)*w, reorder_index)).  Reference: punica/ops/__init__.py:183-200 ->
+    run_rmsnorm_fp16_i4 (RMSNorm.cuh:255-285).  reorder_index is int16 [H] as in the reference."""
+    _require_cuda_half(hidden_states, "hidden_states")
+    _require_cuda_half(weight, "weight")
+    assert reorder_index.dtype == torch.int16 and reorder_index.is_cuda
+    bs, hidden_dim = hidden_states.shape
+    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant)
+    st = L.lib().atom_rmsnorm_reorder_quant_f16(hidden_states.data_ptr(), weight.data_ptr(), float(eps),
+                                                 reorder_index.data_ptr(), bs, hidden_dim, _MODES[quant_mode], clip,
+                                                 _LAYOUTS[scale_layout], outs[0].data_ptr(), outs[1].data_ptr(),
+                                                 outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
+                                                 L.current_stream(hidden_states.device))
+    L.check(st, "atom_rmsnorm_reorder_quant_f16")
+    return _ret(*outs)
+
+
+def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="kernel", clip=1.0,
+                    scale_layout="ref", return_dequant=False):
+    """quant(index_select(x, reorder_index)).  Reference: punica/ops/__init__.py:203-219 ->
+    run_reorder_fp16_i4 (Reorder.cuh:205-228).  ``reorder_index=None`` quantises x in its given channel order
+    (the tail of quantize_activation_wrapper, model/quant.py:187-231)."""
+    _require_cuda_half(hidden_states, "hidden_states")
+    if reorder_index is not None:
+        assert reorder_index.dtype == torch.int16 and reorder_index.is_cuda
+    bs, hidden_dim = hidden_states.shape
+    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant)
+    st = L.lib().atom_reorder_quant_f16(hidden_states.data_ptr(), L.ptr(reorder_index), bs, hidden_dim,
+                                         _MODES[quant_mode], clip, _LAYOUTS[scale_layout], outs[0].data_ptr(),
+                                         outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
+                                         L.current_stream(hidden_states.device))
+    L.check(st, "atom_reorder_quant_f16")
+    return _ret(*outs)
+
+
+def _gemm_dims(a, b, a_keeper):
+    m = a.size(0)
+    n = b.size(0)
+    k = a.size(1) * 2 + a_keeper.size(1)       # punica_ops.cc:228-241
+    return m, n, k
+
+
+def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
+                             scale_layout="ref"):
+    """d[M,N] fp16 = W4A4 group-128 GEMM + INT8 keeper.  Reference: punica/ops/__init__.py:159-167 ->
+    DenseLayerGEMM_i4<nv_half> (DenseLayerGEMM_i4.cu:722-791).  b_scale is read flat as [G][N] and b_keeper_scale
+    as [N], exactly like the reference kernel (Dense_layer_gemm_i4_o16.cuh:497), whatever the tensor's shape."""
+    for t in (a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale):
+        if not t.is_cuda:
+            raise L.AtomHipError("all GEMM operands must live on the GPU: no CPU fallback")
+    m, n, k = _gemm_dims(a, b, a_keeper)
+    d = torch.empty((m, n), dtype=torch.float16, device=a.device)
+    st = L.lib().atom_gemm_w4a4_f16(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
+                                     a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
+                                     b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
+                                     _LAYOUTS[scale_layout], L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_f16")
+    return d
+
+
+def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
+                           scale_layout="ref"):
+    """Same GEMM, output asymmetric-quantised to u4 per 128-column group: (d u8[M,N/2], d_scale f16[M,N/128*2]).
+    Reference: punica/ops/__init__.py:170-180 -> DenseLayerGEMM_i4_o4 (DenseLayerGEMM_i4_o4.cu:808-856)."""
+    m, n, k = _gemm_dims(a, b, a_keeper)
+    assert n % 128 == 0
+    d = torch.empty((m, n // 2), dtype=torch.uint8, device=a.device)
+    d_scale = torch.empty((m, n // 128 * 2), dtype=torch.float16, device=a.device)
+    st = L.lib().atom_gemm_w4a4_o4(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
+                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
+                                    b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
+                                    GROUP_SIZE, _LAYOUTS[scale_layout], L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_o4")
+    return d, d_scale
+
+
+def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: int = 2, return_fake_quant=False):
+    """NEW (no reference counterpart): quantise + pack a (column-reordered) FP16 weight [N,K] the
+    way QLinearLayer.quant does (qLinearLayer.py:42-78).  Returns (B4 u8[N,K4/2], B8 i8[N,128], sB f16[G,N],
+    sB8 f16[N][, Wq f16[N,K]])."""
+    _require_cuda_half(weight, "weight")
+    n, k = weight.shape
+    dev = weight.device
+    b4 = torch.empty((n, (k - GROUP_SIZE) // 2), dtype=torch.uint8, device=dev)
+    b8 = torch.empty((n, GROUP_SIZE), dtype=torch.int8, device=dev)
+    sb = torch.empty(((k - GROUP_SIZE) // GROUP_SIZE, n), dtype=torch.float16, device=dev)
+    sb8 = torch.empty((n,), dtype=torch.float16, device=dev)
+    wq = torch.empty_like(weight) if return_fake_quant else None
+    st = L.lib().atom_quant_weight_w4(weight.data_ptr(), n, k, float(w_clip), int(channel_group), b4.data_ptr(),
+                                       b8.data_ptr(), sb.data_ptr(), sb8.data_ptr(), L.ptr(wq),
+                                       L.current_stream(dev))
+    L.check(st, "atom_quant_weight_w4")
+    return (b4, b8, sb, sb8, wq) if return_fake_quant else (b4, b8, sb, sb8)

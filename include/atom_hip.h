@@ -1,0 +1,138 @@
+/*
+ * atom_hip.h -- C ABI of libatom_hip.so: MI355X (gfx950) implementation of Atom's W4A4
+ * mixed-precision GEMM hot path.
+ *
+ * Every entry point replaces one host launcher of the reference (file:line relative to
+ * /root/reference).  Conventions, all entry points:
+ *   - plain device pointers + sizes, no framework types; caller owns every buffer; nothing is
+ *     allocated, nothing is synchronised; the launch is enqueued on `stream` (a hipStream_t passed
+ *     as void*; NULL = the null stream).  Re-entrant and thread-safe (no global state).
+ *   - returns ATOM_OK (0) or a negative ATOM_ERR_* code; shapes/alignment are validated BEFORE any
+ *     launch (the reference validates nothing: e2e/punica-atom/punica/ops/csrc/punica_ops.cc:73-80,
+ *     211-262).  atom_strerror() names a code.
+ *   - group size 128 and keeper (INT8 outlier columns) 128 are the only supported values, as in the
+ *     reference (GROUP_SIZE/KEEPER macros, kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:35,54).
+ *
+ * Data formats (identical to the reference unless noted):
+ *   A4 / B4   uint8 [rows, K4/2]   two's-complement int4, element 2j in the LOW nibble, 2j+1 in the
+ *                                   HIGH nibble (PackInt4, kernels/include/Reorder/Reorder.cuh:16-19)
+ *   A8 / B8   int8  [rows, 128]    keeper columns (the LAST 128 reordered channels)
+ *   sB        fp16  [G, N]         weight scales, G = K4/128 (Dense_layer_gemm_i4_o16.cuh:497)
+ *   sB8       fp16  [N]
+ *   sA, sA8   fp16  activation scales, one of two layouts selected by `scale_layout`:
+ *       ATOM_SCALE_LAYOUT_REF   (0): the reference's ldmatrix-replicated layout -- row r of group g
+ *                                    at g*atom_scale_size(M,0) + scale_index(r) + 2j, j=0..3
+ *                                    (Reorder.cuh:39-50,137-156)
+ *       ATOM_SCALE_LAYOUT_PLAIN (1): [G, M] row-major (sA8: [M]); the native layout.
+ *   K_total = K4 + 128 (the e2e convention, e2e/.../GEMM/DenseLayerGEMM_i4.cu:764).
+ */
+#ifndef ATOM_HIP_H_
+#define ATOM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATOM_OK 0
+#define ATOM_ERR_INVALID_ARG (-22)  /* null pointer, bad enum */
+#define ATOM_ERR_SHAPE (-33)        /* unsupported M/N/K/hidden/group/keeper */
+#define ATOM_ERR_ALIGN (-14)        /* pointer not 16-byte aligned */
+#define ATOM_ERR_LAUNCH (-5)        /* hipGetLastError() != hipSuccess after the launch */
+
+#define ATOM_SCALE_LAYOUT_REF 0
+#define ATOM_SCALE_LAYOUT_PLAIN 1
+
+/* Quantisation arithmetic of the three activation ops */
+#define ATOM_QUANT_KERNEL 0 /* the reference CUDA kernels: FP32, q = round_half_away(x*(1/s)), s = amax*clip/qmax
+                               (Reorder.cuh:137-178).  clip = 1.0 reproduces them exactly. */
+#define ATOM_QUANT_SIM 1    /* the reference simulated path: FP16 opmath, amax.clamp(1e-5)*clip, q = rint(x/s)
+                               (model/quant.py:141-142,166-172,181).  clip = args.a_clip_ratio. */
+
+const char *atom_version(void);
+const char *atom_strerror(int code);
+
+/* == python scale_size() for layout 0 (punica/ops/__init__.py:137-138, SCALE_SIZE_A Reorder.cuh:50);
+ * == rows for layout 1.  Unit: halves. */
+size_t atom_scale_size(int64_t rows, int scale_layout);
+
+/*
+ * D[M,N] (fp16) = sum_g (A4_g . B4_g^T) * sA[m,g] * sB[g,n]  +  (A8 . B8^T) * sA8[m] * sB8[n]
+ * Replaces: DenseLayerGEMM_i4_o16 (kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:728-769) and
+ *           DenseLayerGEMM_i4<nv_half> (e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4.cu:722-791).
+ * Integer dot products are exact (INT8 MFMA); per group c += round_f32(idot*sA)*sB in FP32, group order
+ * then keeper; D = half(c).  Constraints: (K_total-128) % 128 == 0, K_total >= 256, N % 64 == 0, M >= 1,
+ * all pointers 16-byte aligned.
+ */
+int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const void *sB,
+                       const void *A8, const void *B8, const void *sA8, const void *sB8,
+                       void *D, int64_t M, int64_t N, int64_t K_total,
+                       int group, int keeper, int scale_layout, void *stream);
+
+/*
+ * Same GEMM; epilogue asymmetric-quantises every 128-wide output group to u4:
+ *   scale = (max-min)/15, zero = -min, q = round((x+zero)/scale) & 0xF
+ * D_u4 uint8 [M, N/2] (same nibble order), D_scale_zero fp16 [M, N/128, 2] = (scale, zero).
+ * Replaces: DenseLayerGEMM_i4_o4 (e2e/.../GEMM/DenseLayerGEMM_i4_o4.cu:808-856, epilogue :704-788).
+ * Constraint in addition: N % 128 == 0.
+ */
+int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void *sB,
+                      const void *A8, const void *B8, const void *sA8, const void *sB8,
+                      void *D_u4, void *D_scale_zero, int64_t M, int64_t N, int64_t K_total,
+                      int group, int keeper, int scale_layout, void *stream);
+
+/*
+ * The three fused activation-quantisation ops.  Common outputs (row r, hidden = H, K4 = H-128):
+ *   o_outliers     int8  [M, 128]        INT8 codes of the last 128 (reordered) channels
+ *   o_norms        uint8 [M, K4/2]       packed INT4 codes of the first K4 channels
+ *   outlier_scales fp16  atom_scale_size(M, layout) halves
+ *   norm_scales    fp16  [K4/128, atom_scale_size(M, layout)]
+ *   xq_f16         fp16  [M, H] or NULL  optional de-quantised tensor (codes*scale in half) == what the
+ *                                         reference's quantize_activation_wrapper returns (sim mode)
+ * Constraints: H % 128 == 0, 256 <= H <= 16384, reorder_index int16 [H] with values in [0,H); a NULL
+ * reorder_index means the identity (input already in reordered channel order).
+ */
+
+/* y = index_select(x, -1, reorder_index); quantise.
+ * Replaces: run_reorder_fp16_i4<128,4096> (kernels/include/Reorder/Reorder.cuh:205-228);
+ * sim mode == index_select + quantize_activation_wrapper (model/qLlamaLayer.py:300-304). */
+int atom_reorder_quant_f16(const void *x, const int16_t *reorder_index, int64_t M, int hidden,
+                           int quant_mode, float clip, int scale_layout,
+                           void *o_outliers, void *o_norms, void *outlier_scales, void *norm_scales,
+                           void *xq_f16, void *stream);
+
+/* y = RMSNorm(x)*w; index_select; quantise.
+ * Replaces: run_rmsnorm_fp16_i4<128,4096> (kernels/include/RMSNorm/RMSNorm.cuh:255-285);
+ * sim mode == QLlamaRMSNorm.forward (model/qLlamaLayer.py:141-151) with HF LlamaRMSNorm numerics. */
+int atom_rmsnorm_reorder_quant_f16(const void *x, const void *weight, float eps,
+                                   const int16_t *reorder_index, int64_t M, int hidden,
+                                   int quant_mode, float clip, int scale_layout,
+                                   void *o_outliers, void *o_norms, void *outlier_scales,
+                                   void *norm_scales, void *xq_f16, void *stream);
+
+/* y = silu(a)*b; quantise (no reorder: the weights are pre-permuted, modelutils_llama.py:33-40).
+ * Replaces: run_activate_fp16_i4<128,11008> (kernels/include/Activate/Activate.cuh:194-217);
+ * sim mode == act_fn(gate)*up -> act_quant (model/qLlamaLayer.py:345-351). */
+int atom_silu_mul_quant_f16(const void *a, const void *b, int64_t M, int hidden,
+                            int quant_mode, float clip, int scale_layout,
+                            void *o_outliers, void *o_norms, void *outlier_scales, void *norm_scales,
+                            void *xq_f16, void *stream);
+
+/*
+ * NEW (the bridge the reference lacks): quantise + pack an FP16 weight [N,K] (columns
+ * already reordered, keeper = last 128 columns) exactly as QLinearLayer.quant does
+ * (model/qLinearLayer.py:42-78, model/quant.py:68-107): INT8 per output row for the keeper columns,
+ * INT4 with `channel_group` (1 or 2) adjacent rows sharing a scale per 128-column slice, clip w_clip.
+ * Outputs: B4 uint8 [N,K4/2], B8 int8 [N,128], sB fp16 [G,N], sB8 fp16 [N], Wq_f16 fp16 [N,K] or NULL
+ * (the fake-quant weight the reference would hold).
+ */
+int atom_quant_weight_w4(const void *W_f16, int64_t N, int64_t K_total, float w_clip,
+                         int channel_group, void *B4, void *B8, void *sB, void *sB8, void *Wq_f16,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATOM_HIP_H_ */

@@ -113,7 +113,8 @@ def _rne(x):
 def _round_half_away(x):
     """C/CUDA round(): half away from zero (Reorder.cuh:171-172)."""
     x = np.asarray(x, dtype=f32)
-    return np.sign(x) * np.floor(np.abs(x) + f32(0.5))
+    t = np.trunc(x)
+    return (t + np.sign(x) * (np.abs(x - t) >= f32(0.5))).astype(f32)
 
 
 # --------------------------------------------------------------------------- quantisation tails

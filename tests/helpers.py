@@ -1,0 +1,93 @@
+"""Shared helpers for the GPU parity tests (checker side only)."""
+import numpy as np
+import torch
+
+from oracle import atom_oracle as O
+
+
+def bits16(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float16)).view(np.uint16)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def scales_plain(t, M, layout):
+    """Device scale tensor ([G, ld] or [ld]) -> plain numpy [G, M] / [M]."""
+    a = t2n(t)
+    if layout == "ref":
+        return O.scales_from_ref_layout(a, M)
+    return a[..., :M]
+
+
+def rand_act(M, H, seed, outliers=True):
+    g = np.random.default_rng(seed)
+    x = g.standard_normal((M, H)).astype(np.float32)
+    if outliers:
+        cols = g.permutation(H)[:128]
+        x[:, cols] *= 20.0
+    return x.astype(np.float16)
+
+
+def rand_gemm_operands(M, N, K, seed, device="cuda"):
+    """Synthetic operands per SURVEY 8(d): uniform int4/int8 codes, scales ~U(0.005,0.05), weight scales equal
+    for channel pairs.  Returns dict of numpy arrays (codes unpacked) -- pack/move with to_device()."""
+    g = np.random.default_rng(seed)
+    K4 = K - 128
+    G = K4 // 128
+    d = dict(
+        qa4=g.integers(-8, 8, size=(M, K4), dtype=np.int8),
+        qb4=g.integers(-8, 8, size=(N, K4), dtype=np.int8),
+        qa8=g.integers(-128, 128, size=(M, 128), dtype=np.int16).astype(np.int8),
+        qb8=g.integers(-128, 128, size=(N, 128), dtype=np.int16).astype(np.int8),
+        sA=g.uniform(0.005, 0.05, size=(M, G)).astype(np.float16),
+        sA8=g.uniform(0.005, 0.05, size=(M,)).astype(np.float16),
+        sB8=g.uniform(0.005, 0.05, size=(N,)).astype(np.float16),
+    )
+    sb = g.uniform(0.005, 0.05, size=(G, N // 2)).astype(np.float16)
+    d["sB"] = np.repeat(sb, 2, axis=1)
+    return d
+
+
+def to_device(d, layout, device="cuda"):
+    """numpy operand dict -> the 8 device tensors dense_layer_gemm_i4_fp16 takes."""
+    M = d["qa4"].shape[0]
+    sA = np.ascontiguousarray(d["sA"].T)              # [G, M]
+    if layout == "ref":
+        sA = O.scales_to_ref_layout(sA)
+        sA8 = O.scales_to_ref_layout(d["sA8"])
+    else:
+        sA8 = d["sA8"]
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return (f(O.pack_int4(d["qa4"])), f(O.pack_int4(d["qb4"])), f(sA), f(d["sB"]), f(d["qa8"]), f(d["qb8"]),
+            f(sA8), f(d["sB8"]))
+
+
+def gemm_ref_torch_f64(d, device="cuda"):
+    """Independent torch FP64 evaluation of the GEMM definition on the GPU (checker for sizes the numpy oracle
+    would take minutes on)."""
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    qa4, qb4 = f(d["qa4"]).double(), f(d["qb4"]).double()
+    sA, sB = f(d["sA"]).double(), f(d["sB"]).double()
+    M, K4 = qa4.shape
+    G = K4 // 128
+    out = torch.zeros((M, qb4.shape[0]), dtype=torch.float64, device=device)
+    for g in range(G):
+        sl = slice(g * 128, (g + 1) * 128)
+        out += (qa4[:, sl] @ qb4[:, sl].T) * sA[:, g:g + 1] * sB[g:g + 1, :]
+    out += (f(d["qa8"]).double() @ f(d["qb8"]).double().T) * f(d["sA8"]).double()[:, None] * f(d["sB8"]).double()[None, :]
+    return out
+
+
+def assert_gemm_close(d_hip, d_exact, what=""):
+    """fp16 output rounding is 2^-11 relative; FP32 accumulation noise is far below that."""
+    d_hip = np.asarray(d_hip, dtype=np.float64)
+    d_exact = np.asarray(d_exact, dtype=np.float64)
+    rms = np.sqrt((d_exact ** 2).mean())
+    err = np.abs(d_hip - d_exact)
+    tol = 1e-3 * np.abs(d_exact) + 1e-3 * rms
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.4g}, rms {rms:.4g}"
+    rel = np.linalg.norm(d_hip - d_exact) / max(np.linalg.norm(d_exact), 1e-30)
+    assert rel < 5e-4, f"{what}: relative Frobenius error {rel:.3g}"

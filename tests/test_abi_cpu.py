@@ -1,0 +1,57 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads and exports every symbol include/atom_hip.h
+declares (no compute calls without a GPU), and the host-side helpers agree with the oracle."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "atom_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(atom_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from atom_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.lib()
+    decl = _declared_symbols()
+    assert len(decl) >= 9
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/atom_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(decl)
+    assert b"gfx950" in L.atom_version()
+    assert L.atom_strerror(0) == b"ok"
+
+
+def test_scale_size_matches_reference_formula():
+    from atom_amd import _lib, ops
+    from oracle import atom_oracle as O
+    L = _lib.lib()
+    for m in list(range(0, 70)) + [100, 127, 128, 4095, 4096, 65536]:
+        assert L.atom_scale_size(m, 0) == ops.scale_size(m) == O.scale_size(m)
+        assert L.atom_scale_size(m, 1) == m
+
+
+def test_no_cpu_fallback():
+    """Product ops refuse CPU tensors instead of silently computing on the host."""
+    import torch
+    from atom_amd import ops
+    from atom_amd._lib import AtomHipError
+    with pytest.raises(AtomHipError):
+        ops.reorder_fp16_i4(torch.zeros((2, 256), dtype=torch.float16), None)
+    with pytest.raises(AtomHipError):
+        ops.quant_weight_w4(torch.zeros((4, 256), dtype=torch.float16))
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "atom_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", txt, flags=re.S).replace("# ", ""), f

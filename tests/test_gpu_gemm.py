@@ -1,0 +1,132 @@
+"""GPU parity tests of the W4A4 GEMM through the C ABI (atom_amd.ops.dense_layer_gemm_i4_fp16).
+
+Checkers: the numpy oracle (oracle/atom_oracle.py) at sizes it finishes in seconds, the reference-generated golden
+(config 1) and, at BASELINE.json's full sizes, an independent FP64 torch evaluation on the GPU plus exact algebraic
+properties (scale linearity, M-tail independence, layout equivalence)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import atom_oracle as O
+from tests.helpers import (assert_gemm_close, gemm_ref_torch_f64, rand_gemm_operands, t2n, to_device, bits16)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from atom_amd import ops
+    return ops
+
+
+def _exact(d):
+    return O.gemm_w4a4_exact(d["qa4"], d["qb4"], d["sA"], d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+
+
+# (M, N, K): K includes the 128 keeper columns.  Ragged M (tails), minimum K (one int4 group), N not a multiple
+# of the 256-wide block tile, M = 1 (config 2 shape is covered at full size below).
+SMALL = [(16, 512, 512), (1, 256, 256), (7, 256, 640), (129, 320, 384), (257, 1024, 1152), (128, 256, 4096),
+         (300, 64, 1280), (5, 4096, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", SMALL)
+@pytest.mark.parametrize("layout", ["ref", "plain"])
+def test_gemm_vs_oracle(M, N, K, layout):
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M + N + K)
+    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, layout), scale_layout=layout)
+    assert out.shape == (M, N) and out.dtype == torch.float16
+    assert_gemm_close(t2n(out), _exact(d), f"{M}x{N}x{K} {layout}")
+    # and within the north-star 1e-2 of the reference kernel's own rounding order (fp16 scale product)
+    ref = O.gemm_w4a4_ref(d["qa4"], d["qb4"], d["sA"], d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"]).astype(np.float64)
+    rms = np.sqrt((ref ** 2).mean())
+    assert np.abs(t2n(out).astype(np.float64) - ref).max() <= 1e-2 * rms
+
+
+def test_gemm_extreme_codes():
+    """All-(-8) x all-(-8) int4 and all-(-128) int8: the largest integer dot products (2^13 / 2^21); checks the
+    magic-number accumulator trick at its range limit, and +7/-8 sign handling of the nibble widening."""
+    ops = _ops()
+    M, N, K = 64, 128, 512
+    d = rand_gemm_operands(M, N, K, seed=1)
+    d["qa4"][:] = -8; d["qb4"][:] = -8; d["qa8"][:] = -128; d["qb8"][:] = -128
+    d["qa4"][1::2] = 7; d["qa8"][1::2] = 127
+    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
+    assert_gemm_close(t2n(out), _exact(d), "extreme codes")
+    # asymmetric pattern: catches transposed / permuted operands
+    d2 = rand_gemm_operands(M, N, K, seed=2)
+    d2["qa4"][:] = 0; d2["qa8"][:] = 0
+    d2["qa4"][3, 5] = 7        # single non-zero activation
+    out2 = t2n(ops.dense_layer_gemm_i4_fp16(*to_device(d2, "plain"), scale_layout="plain")).astype(np.float64)
+    ex = _exact(d2)
+    assert_gemm_close(out2, ex, "single nonzero")
+    assert np.count_nonzero(out2[np.arange(M) != 3]) == 0
+
+
+def test_config1_golden_end_to_end(golden_dir):
+    """BASELINE config 1 (M=16 N=512 K=512): HIP weight packer + HIP act quant (sim) + HIP GEMM against the
+    reference's own QLinearLayer.forward output, tolerance 1e-2 relative (north star)."""
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "c1_qlinear_16x512x512.npz"))
+    b4, b8, sb, sb8 = ops.quant_weight_w4(torch.from_numpy(z["W"]).cuda(), 0.85, 2)
+    o8, o4, s8, s4, xq = ops.reorder_fp16_i4(torch.from_numpy(z["x"]).cuda(), None, quant_mode="sim", clip=0.9,
+                                             scale_layout="plain", return_dequant=True)
+    assert np.array_equal(bits16(t2n(xq)), bits16(z["xq"]))             # fake-quant activation bit-exact
+    y = t2n(ops.dense_layer_gemm_i4_fp16(o4, b4, s4, sb, o8, b8, s8, sb8, scale_layout="plain")).astype(np.float64)
+    want = z["y"].astype(np.float64)
+    rms = np.sqrt((want ** 2).mean())
+    assert np.abs(y - want).max() <= 1e-2 * rms
+    assert np.linalg.norm(y - want) / np.linalg.norm(want) < 1e-3
+
+
+FULL = [(1, 4096, 4096),            # config 2
+        (4096, 4096, 4096),         # config 3 (headline)
+        (16, 5120, 5120), (64, 13824, 5120), (256, 5120, 13824), (2048, 5120, 5120), (1, 13824, 5120),  # config 5
+        (2048, 11008, 4096), (1000, 4096, 11008)]                                                         # config 4 shapes
+
+
+@pytest.mark.parametrize("M,N,K", FULL)
+def test_gemm_full_size_vs_fp64(M, N, K):
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M ^ N ^ K)
+    dev = to_device(d, "plain")
+    out = ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")
+    ref = gemm_ref_torch_f64(d)
+    assert_gemm_close(t2n(out), t2n(ref), f"full {M}x{N}x{K}")
+
+
+def test_gemm_properties_full_size():
+    """Size-independent exact properties at the headline shape (no oracle needed):
+       * doubling every activation scale doubles D exactly (powers of two commute with every rounding);
+       * rows are independent: computing only the first 1000 tokens reproduces those rows bit-for-bit;
+       * the replicated and the plain A-scale layouts give identical bits."""
+    ops = _ops()
+    M, N, K = 4096, 4096, 4096
+    d = rand_gemm_operands(M, N, K, seed=11)
+    a = to_device(d, "plain")
+    base = ops.dense_layer_gemm_i4_fp16(*a, scale_layout="plain")
+    a2 = list(a); a2[2] = a[2] * 2; a2[6] = a[6] * 2
+    dbl = ops.dense_layer_gemm_i4_fp16(*a2, scale_layout="plain")
+    assert torch.equal(dbl, base * 2)
+    Mh = 1000
+    sub = ops.dense_layer_gemm_i4_fp16(a[0][:Mh].contiguous(), a[1], a[2][:, :Mh].contiguous(), a[3],
+                                       a[4][:Mh].contiguous(), a[5], a[6][:Mh].contiguous(), a[7],
+                                       scale_layout="plain")
+    assert torch.equal(sub, base[:Mh])
+    r = to_device(d, "ref")
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*r, scale_layout="ref"), base)
+
+
+def test_gemm_error_behaviour():
+    ops = _ops()
+    from atom_amd._lib import AtomHipError
+    d = rand_gemm_operands(4, 64, 256, seed=0)
+    a = to_device(d, "plain")
+    ops.dense_layer_gemm_i4_fp16(*a, scale_layout="plain")                       # smallest legal problem
+    bad = list(a); bad[1] = a[1][:60].contiguous()                                # N = 60: not a multiple of 64
+    with pytest.raises(AtomHipError):
+        ops.dense_layer_gemm_i4_fp16(*bad, scale_layout="plain")
+    cpu = [t.cpu() for t in a]
+    with pytest.raises(AtomHipError):
+        ops.dense_layer_gemm_i4_fp16(*cpu, scale_layout="plain")

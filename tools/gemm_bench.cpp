@@ -1,0 +1,102 @@
+// Native tuning harness for libatom_hip.so (no Python): correctness against a naive GPU kernel + hipEvent timing.
+//   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -o build/gemm_bench -Latom_amd -latom_hip -Wl,-rpath,$PWD/atom_amd
+//   build/gemm_bench M N K iters [check_rows]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../include/atom_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef _Float16 half_t;
+
+__device__ inline int nib(const uint8_t *p, int k) {
+  int v = (p[k >> 1] >> ((k & 1) * 4)) & 0xF;
+  return v >= 8 ? v - 16 : v;
+}
+
+// one thread per output element, straight from the definition, FP64 accumulate
+__global__ void naive_ref(const uint8_t *A4, const uint8_t *B4, const half_t *sA, const half_t *sB, const int8_t *A8,
+                          const int8_t *B8, const half_t *sA8, const half_t *sB8, double *D, int M, int N, int K4, int ldA) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N || m >= M) return;
+  int G = K4 / 128;
+  double acc = 0;
+  for (int g = 0; g < G; ++g) {
+    int s = 0;
+    for (int k = 0; k < 128; ++k) s += nib(A4 + (size_t)m * (K4 / 2), g * 128 + k) * nib(B4 + (size_t)n * (K4 / 2), g * 128 + k);
+    acc += (double)s * (double)(float)sA[(size_t)g * ldA + m] * (double)(float)sB[(size_t)g * N + n];
+  }
+  int s = 0;
+  for (int k = 0; k < 128; ++k) s += (int)A8[(size_t)m * 128 + k] * (int)B8[(size_t)n * 128 + k];
+  acc += (double)s * (double)(float)sA8[m] * (double)(float)sB8[n];
+  D[(size_t)m * N + n] = acc;
+}
+
+int main(int argc, char **argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
+  int iters = argc > 4 ? atoi(argv[4]) : 50;
+  int check_rows = argc > 5 ? atoi(argv[5]) : 256;
+  int K4 = K - 128, G = K4 / 128;
+  std::mt19937_64 rng(123);
+  auto fill_u8 = [&](std::vector<uint8_t> &v) { for (auto &x : v) x = (uint8_t)(rng() & 0xFF); };
+  auto fill_sc = [&](std::vector<half_t> &v) { for (auto &x : v) x = (half_t)(0.005f + 0.045f * (float)((rng() >> 11) * (1.0 / 9007199254740992.0))); };
+  std::vector<uint8_t> hA4((size_t)M * K4 / 2), hB4((size_t)N * K4 / 2), hA8((size_t)M * 128), hB8((size_t)N * 128);
+  std::vector<half_t> hsA((size_t)G * M), hsB((size_t)G * N), hsA8(M), hsB8(N);
+  fill_u8(hA4); fill_u8(hB4); fill_u8(hA8); fill_u8(hB8);
+  fill_sc(hsA); fill_sc(hsB); fill_sc(hsA8); fill_sc(hsB8);
+  for (int g = 0; g < G; ++g) for (int n = 0; n < N; n += 2) hsB[(size_t)g * N + n + 1] = hsB[(size_t)g * N + n];
+  void *A4, *B4, *A8, *B8, *sA, *sB, *sA8, *sB8, *D;
+  auto up = [&](void **d, const void *h, size_t bytes) { CK(hipMalloc(d, bytes)); CK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice)); };
+  up(&A4, hA4.data(), hA4.size()); up(&B4, hB4.data(), hB4.size()); up(&A8, hA8.data(), hA8.size()); up(&B8, hB8.data(), hB8.size());
+  up(&sA, hsA.data(), hsA.size() * 2); up(&sB, hsB.data(), hsB.size() * 2); up(&sA8, hsA8.data(), hsA8.size() * 2); up(&sB8, hsB8.data(), hsB8.size() * 2);
+  CK(hipMalloc(&D, (size_t)M * N * 2));
+  CK(hipMemset(D, 0xFF, (size_t)M * N * 2));
+
+  int st = atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, ATOM_SCALE_LAYOUT_PLAIN, nullptr);
+  if (st) { printf("atom_gemm_w4a4_f16: %s\n", atom_strerror(st)); return 1; }
+  CK(hipDeviceSynchronize());
+
+  // correctness on the first and last check_rows rows
+  int cr = check_rows < M ? check_rows : M;
+  if (cr > 0) {
+    double *Dref; CK(hipMalloc(&Dref, (size_t)M * N * 8));
+    hipLaunchKernelGGL(naive_ref, dim3((N + 255) / 256, M), dim3(256), 0, 0, (const uint8_t *)A4, (const uint8_t *)B4,
+                       (const half_t *)sA, (const half_t *)sB, (const int8_t *)A8, (const int8_t *)B8, (const half_t *)sA8,
+                       (const half_t *)sB8, Dref, (cr == M ? M : M), N, K4, M);
+    CK(hipDeviceSynchronize());
+    std::vector<double> href((size_t)M * N); std::vector<half_t> hD((size_t)M * N);
+    CK(hipMemcpy(href.data(), Dref, href.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hD.data(), D, hD.size() * 2, hipMemcpyDeviceToHost));
+    double ss = 0; for (double v : href) ss += v * v; double rms = sqrt(ss / href.size());
+    double maxerr = 0; size_t bad = 0;
+    for (size_t i = 0; i < href.size(); ++i) {
+      double e = fabs((double)(float)hD[i] - href[i]);
+      if (e > maxerr) maxerr = e;
+      if (e > 1e-3 * fabs(href[i]) + 1e-3 * rms) ++bad;
+    }
+    printf("check %dx%dx%d: rms %.4g max_abs_err %.4g bad %zu / %zu -> %s\n", M, N, K, rms, maxerr, bad, href.size(), bad ? "FAIL" : "ok");
+    CK(hipFree(Dref));
+  }
+
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1, nullptr);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, tot = 0;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1, nullptr);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters; tot += ms; if (ms < best) best = ms;
+  }
+  double ops = 2.0 * M * N * K;
+  const char *var = getenv("ATOM_GEMM_VARIANT");
+  printf("RESULT variant=%s M=%d N=%d K=%d  avg %.2f us  best %.2f us  %.1f TOPS (avg)  %.1f TOPS (best)  frac_of_5033=%.3f\n",
+         var ? var : "default", M, N, K, tot / 5 * 1e3, best * 1e3, ops / (tot / 5 * 1e-3) / 1e12, ops / (best * 1e-3) / 1e12,
+         ops / (tot / 5 * 1e-3) / 1e12 / 5033.0);
+  return 0;
+}
