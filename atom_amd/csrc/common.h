@@ -25,8 +25,12 @@ __device__ __forceinline__ float opaque(float x) {
 }
 
 __device__ __forceinline__ float h2f(half_t h) { return (float)h; }
-__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // RNE
-__device__ __forceinline__ float round_h(float f) { return (float)(half_t)f; }
+// FP32 -> FP16 (RNE) of a value that has ALREADY been rounded to FP32.  The opaque() matters: without it LLVM
+// fuses fptrunc(fmul/fma) into v_fma_mixlo_f16, which rounds the exact product ONCE to half, while the
+// specification (torch/numpy "opmath") is one FP32 op followed by a second rounding to FP16 (measured on gfx950:
+// 3.740234375h * 0.9f -> 0x42BB fused vs 0x42BC double-rounded).
+__device__ __forceinline__ half_t f2h(float f) { return (half_t)opaque(f); }
+__device__ __forceinline__ float round_h(float f) { return (float)(half_t)opaque(f); }
 
 // Offset (halves) of row r's first replica in the reference A-scale layout (Reorder.cuh:39-44).
 __host__ __device__ __forceinline__ int ref_scale_index(int r) {

@@ -69,7 +69,7 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
       float t = rintf(round_h(v[i] / so));                  // :181 torch.round(w / scales), half
       t = fminf(fmaxf(t, qmin), qmax);
       q[i] = (int)t;
-      dq[i] = t * s;
+      dq[i] = (float)q[i] * s;                             // (q + 0) * s: a code of -0.0 de-quantises to +0.0
     }
     scale_store = s;
   } else {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
       t = fminf(fmaxf(t, qmin), qmax);
       if (sf == 0.f) t = 0.f;
       q[i] = (int)t;
-      dq[i] = t * sh;
+      dq[i] = (float)q[i] * sh;
     }
     scale_store = sf;
   }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(WeightQuantParams p) 
       float t = rintf(round_h(v[k] / so));
       t = fminf(fmaxf(t, qmin), qmax);
       q[k] = (int)t;
-      ov[k] = f2h(t * s);
+      ov[k] = f2h((float)q[k] * s);
     }
     if (keeper) {
       const unsigned w = (q[0] & 0xFF) | ((q[1] & 0xFF) << 8) | ((q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);

@@ -108,7 +108,9 @@ def test_gemm_properties_full_size():
     base = ops.dense_layer_gemm_i4_fp16(*a, scale_layout="plain")
     a2 = list(a); a2[2] = a[2] * 2; a2[6] = a[6] * 2
     dbl = ops.dense_layer_gemm_i4_fp16(*a2, scale_layout="plain")
-    assert torch.equal(dbl, base * 2)
+    normal = base.abs() >= 2.0 ** -13           # fp16 subnormal results carry fewer bits: 2*round(c) != round(2c)
+    assert torch.equal(dbl[normal], (base * 2)[normal])
+    assert (dbl.float() - 2 * base.float()).abs().max() <= 2.0 ** -23
     Mh = 1000
     sub = ops.dense_layer_gemm_i4_fp16(a[0][:Mh].contiguous(), a[1], a[2][:, :Mh].contiguous(), a[3],
                                        a[4][:Mh].contiguous(), a[5], a[6][:Mh].contiguous(), a[7],
