@@ -41,6 +41,21 @@ __host__ __device__ __forceinline__ int64_t ref_scale_size(int64_t x) {
   return x / 16 * 64 + 64 - (1 - (x % 16) / 8) * (8 - (x % 8)) * 8;
 }
 
+struct GemmParams {
+  const uint8_t *A4, *B4;
+  const half_t *sA, *sB;
+  const uint8_t *A8, *B8;
+  const half_t *sA8, *sB8;
+  half_t *D;
+  int M, N;
+  int K4h;          // packed bytes per row of A4/B4 = K4/2
+  int G;            // int4 groups
+  int ref_layout;
+  int64_t ldA;      // halves between groups of sA
+};
+
+int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? ATOM_OK : ATOM_ERR_LAUNCH; }

@@ -27,24 +27,12 @@
 //    the current one (T14 "issue early / write late").
 //  * The 128 INT8 keeper columns run as two extra 64-wide steps through the same pipeline.
 #include "common.h"
+#include <cstdlib>
 
 namespace atom {
 
 constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23
 constexpr int kMagicBits = 0x4B400000;
-
-struct GemmParams {
-  const uint8_t *A4, *B4;
-  const half_t *sA, *sB;
-  const uint8_t *A8, *B8;
-  const half_t *sA8, *sB8;
-  half_t *D;
-  int M, N;
-  int K4h;          // packed bytes per row of A4/B4 = K4/2
-  int G;            // int4 groups
-  int ref_layout;
-  int64_t ldA;      // halves between groups of sA
-};
 
 template <int BM_, int BN_, int WGM_, int WGN_>
 struct GemmCfg {
@@ -133,7 +121,8 @@ __device__ __forceinline__ void stage_store(const GemmParams &p, int step, char 
 }
 
 // ---- one K step out of LDS: fragment reads, MFMAs, fused dequant ----------------------------------
-template <class C, int KSTEPS, bool INIT, bool DEQ>
+// ABL (tuning only, never the default): 1 = no dequant VALU, 2 = no LDS stage stores, 4 = no MFMA, 8 = no global loads
+template <class C, int KSTEPS, bool INIT, bool DEQ, int ABL = 0>
 __device__ __forceinline__ void compute_step(const char *stage, int wm, int wn, int lane, v16i (&acc)[C::TN][C::TM],
                                              float (&c)[C::TN][C::TM][16]) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -182,12 +171,17 @@ __device__ __forceinline__ void compute_step(const char *stage, int wm, int wn, 
     for (int tm = 0; tm < C::TM; ++tm) {
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
-        if (INIT && s == 0)
+        if constexpr (ABL & 4) {
+          asm volatile("" ::"v"(af[tn][s]), "v"(bf[tm][s]));
+          if (INIT && s == 0) acc[tn][tm] = magic;
+        } else if (INIT && s == 0)
           acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[tm][s], magic, 0, 0, 0);
         else
           acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[tm][s], acc[tn][tm], 0, 0, 0);
       }
-      if constexpr (DEQ) {
+      if constexpr (DEQ && (ABL & 1)) {
+        asm volatile("" ::"v"(acc[tn][tm]));
+      } else if constexpr (DEQ) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float t = __builtin_fmaf(__int_as_float(acc[tn][tm][r]), sa[tm], nms[tm]);
@@ -198,7 +192,7 @@ __device__ __forceinline__ void compute_step(const char *stage, int wm, int wn, 
   }
 }
 
-template <class C>
+template <class C, int ABL = 0>
 __global__ __launch_bounds__(C::NT) void gemm_w4a4_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
@@ -231,14 +225,14 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_kernel(GemmParams p) {
     char *cur = lds + (step & 1) * C::STAGE_BYTES;
     char *nxt = lds + ((step + 1) & 1) * C::STAGE_BYTES;
     const bool more = step + 1 < nsteps;
-    if (more) stage_load<C>(p, step + 1, m0, n0, tid, st);
+    if (more && !(ABL & 8)) stage_load<C>(p, step + 1, m0, n0, tid, st);
     if (step < p.G)
-      compute_step<C, 4, true, true>(cur, wm, wn, lane, acc, c);
+      compute_step<C, 4, true, true, ABL>(cur, wm, wn, lane, acc, c);
     else if (step == p.G)
-      compute_step<C, 2, true, false>(cur, wm, wn, lane, acc, c);
+      compute_step<C, 2, true, false, ABL>(cur, wm, wn, lane, acc, c);
     else
-      compute_step<C, 2, false, true>(cur, wm, wn, lane, acc, c);
-    if (more) stage_store<C>(p, step + 1, nxt, tid, st);
+      compute_step<C, 2, false, true, ABL>(cur, wm, wn, lane, acc, c);
+    if (more && !(ABL & 2)) stage_store<C>(p, step + 1, nxt, tid, st);
     __syncthreads();
   }
 
@@ -264,17 +258,17 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_kernel(GemmParams p) {
   }
 }
 
-template <class C>
+template <class C, int ABL = 0>
 static int launch_gemm(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;     // benign race: idempotent
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_kernel<C>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_kernel<C, ABL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_kernel<C, ABL>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
   return check_launch();
 }
 
@@ -317,7 +311,24 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
   p.G = (int)((K_total - kKeeper) / kGroup);
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
   p.ldA = (int64_t)atom_scale_size(M, scale_layout);
-  return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, reinterpret_cast<hipStream_t>(stream));
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  static const int variant = [] { const char *e = getenv("ATOM_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  switch (variant) {   // tuning / ablation variants; 0 is the product path
+    case 101: return launch_gemm<GemmCfg<128, 256, 2, 4>, 1>(p, hs);
+    case 102: return launch_gemm<GemmCfg<128, 256, 2, 4>, 2>(p, hs);
+    case 103: return launch_gemm<GemmCfg<128, 256, 2, 4>, 3>(p, hs);
+    case 104: return launch_gemm<GemmCfg<128, 256, 2, 4>, 4>(p, hs);
+    case 108: return launch_gemm<GemmCfg<128, 256, 2, 4>, 8>(p, hs);
+    case 110: return launch_gemm<GemmCfg<128, 256, 2, 4>, 10>(p, hs);
+    case 111: return launch_gemm<GemmCfg<128, 256, 2, 4>, 11>(p, hs);
+    case 115: return launch_gemm<GemmCfg<128, 256, 2, 4>, 15>(p, hs);
+    case 203: return launch_gemm_v2(p, 3, hs);
+    case 204: return launch_gemm_v2(p, 4, hs);
+    case 1001: case 1002: case 1003: case 1004: case 1008: case 1016: case 1019: case 1023: case 1031:
+      return launch_gemm_v2(p, variant, hs);
+    case 1: return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, hs);    // v1: register-staged, int8-expanded LDS tiles
+    default: return launch_gemm_v2(p, 4, hs);                       // product path: v2 (LDS-DMA, 256x256 tile)
+  }
 }
 
 int atom_gemm_w4a4_o4(const void *, const void *, const void *, const void *, const void *, const void *,

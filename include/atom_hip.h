@@ -62,8 +62,8 @@ size_t atom_scale_size(int64_t rows, int scale_layout);
  * D[M,N] (fp16) = sum_g (A4_g . B4_g^T) * sA[m,g] * sB[g,n]  +  (A8 . B8^T) * sA8[m] * sB8[n]
  * Replaces: DenseLayerGEMM_i4_o16 (kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:728-769) and
  *           DenseLayerGEMM_i4<nv_half> (e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4.cu:722-791).
- * Integer dot products are exact (INT8 MFMA); per group c += round_f32(idot*sA)*sB in FP32, group order
- * then keeper; D = half(c).  Constraints: (K_total-128) % 128 == 0, K_total >= 256, N % 64 == 0, M >= 1,
+ * Integer dot products are exact (INT8 MFMA); per group c = fma(round_f32(idot*sA), sB, c) in FP32, groups in
+ * order, then the keeper as two 64-column halves (each dequantised the same way); D = half(c).  Constraints: (K_total-128) % 128 == 0, K_total >= 256, N % 64 == 0, M >= 1,
  * all pointers 16-byte aligned.
  */
 int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const void *sB,

@@ -132,3 +132,15 @@ def test_gemm_error_behaviour():
     cpu = [t.cpu() for t in a]
     with pytest.raises(AtomHipError):
         ops.dense_layer_gemm_i4_fp16(*cpu, scale_layout="plain")
+
+
+def test_gemm_bit_exact_vs_c_contract():
+    """The arithmetic contract of include/atom_hip.h restated in plain C (oracle/atom_oracle.c): exact integer dots,
+    t = round_f32(idot*sA), c = fmaf(t, sB, c), groups in order, keeper as two halves, D = half(c).  Bit-for-bit."""
+    from tests import c_oracle as C
+    ops = _ops()
+    for (M, N, K) in [(40, 128, 640), (257, 64, 384), (3, 320, 1152)]:
+        d = rand_gemm_operands(M, N, K, seed=M * 7 + N)
+        out = t2n(ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain"))
+        want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+        assert np.array_equal(bits16(out), bits16(want)), f"{M}x{N}x{K}: {(bits16(out) != bits16(want)).sum()} elements differ"
