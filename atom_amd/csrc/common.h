@@ -55,6 +55,7 @@ struct GemmParams {
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
+int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -145,16 +145,33 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) load_frag<INT4, ABL>(slot, wn * 64 + tn * 32 + l31, h, af[tn]);
 
+  // software pipeline over the 4 m-tiles: the two packed 16-byte chunks (8 VGPRs) and the scale of tile tm+1 are
+  // requested from LDS before tile tm's MFMAs/dequant, so their latency is covered by work instead of a stall.
+  v4u pk0, pk1;
+  half_t sah;
+  auto request = [&](int tm) {
+    const int row = 256 + wm * 128 + tm * 32 + l31;
+    const int sw = (row >> 2) & 3;
+    const char *rb = slot + row * 64;
+    pk0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
+    pk1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
+    sah = *reinterpret_cast<const half_t *>(slot + SA_OFF + (wm * 128 + tm * 32 + l31) * 4);
+  };
+  request(0);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    // keep the scheduler from hoisting the next m-tile's fragment loads / widening above this tile's dequant:
-    // the register file is full (128 running sums + 32 weight fragments + ...); the co-resident wave hides latency
     __builtin_amdgcn_sched_barrier(0);
-    const int ml = wm * 128 + tm * 32 + l31;
     v4i bf[4];
-    load_frag<INT4, ABL>(slot, 256 + ml, h, bf);
+    if constexpr (INT4 && !(ABL & 2)) {
+      widen(pk0, bf[0], bf[1]);
+      widen(pk1, bf[2], bf[3]);
+    } else {
+      bf[0] = __builtin_bit_cast(v4i, pk0); bf[1] = __builtin_bit_cast(v4i, pk1); bf[2] = bf[0]; bf[3] = bf[1];
+    }
     // int4 operands are widened to 16*value on both sides: fold 1/256 into the activation scale (exact)
-    const float sa = (float)*reinterpret_cast<const half_t *>(slot + SA_OFF + ml * 4) * (INT4 ? (1.0f / 256.0f) : 1.0f);
+    const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
+    if (tm + 1 < TM) request(tm + 1);
+    __builtin_amdgcn_sched_barrier(0);
     const float nms = -kMagic * sa;             // exact: 3*2^22 times an 11-bit significand
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -203,8 +220,20 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const int nbn = (p.N + BN - 1) / BN;
-  const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+  // Block -> tile.  Workgroup b runs on XCD b % 8 (observed; speed only, never correctness): give every XCD a
+  // contiguous chunk of the tile sequence (bijective for any grid size), and walk the tiles in bands of 4 m-tiles so
+  // that the blocks resident on one XCD at a time share A/B panels in that XCD's private L2.
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
   const int m0 = bm * BM, n0 = bn * BN;
 
   float c[TN][TM][16];
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   {                                                                                                                \
     /* my own DMA parts of stage `step` have landed once at most NS-2 younger stages are outstanding */            \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 8) ? 0 : GLDS_PER_STAGE * (NS - 2)) : "memory");               \
-    __builtin_amdgcn_s_barrier(); /* everyone's parts landed; everyone finished step-1 */                          \
+    if (!(ABL & 32)) __builtin_amdgcn_s_barrier(); /* everyone's parts landed; everyone finished step-1 */         \
     /* refill the slot consumed in step-1 */                                                                       \
     if (!(ABL & 8))                                                                                                \
       issue_stage(p, min(step + NS - 1, nsteps - 1), lds + ((step + NS - 1) % NS) * STAGE_BYTES, wave, sa_);       \
@@ -309,6 +338,9 @@ int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s) {
     case 1019: return launch_v2<4, 19>(p, s);
     case 1023: return launch_v2<4, 23>(p, s);
     case 1031: return launch_v2<4, 31>(p, s);
+    case 1032: return launch_v2<4, 32>(p, s);
+    case 1033: return launch_v2<4, 33>(p, s);
+    case 1035: return launch_v2<4, 35>(p, s);
     default: return launch_v2<4>(p, s);
   }
 }

@@ -1,0 +1,142 @@
+// W4A4 GEMM, decode path (M <= 16) for gfx950: weight streaming, HBM-bound.
+//
+// BASELINE config 2 (M=1, N=K=4096): 8.9 MB of packed weights + scales must cross HBM once; the 256x256 MFMA tile
+// kernel would launch 16 workgroups on a 256-CU chip (55 us measured).  Here instead:
+//   * one wave owns one output feature n at a time and streams that weight row with fully coalesced 16-byte loads
+//     (lane l reads chunk l, l+64, ...: 1 KiB per wave instruction, straight to VGPRs -- a row is read exactly once,
+//     so an LDS round trip would be pure overhead);
+//   * int4 x int4 dot products run on v_dot8_i32_i4 directly on the PACKED dwords (no widening at all), the INT8
+//     keeper on v_dot4_i32_i8;
+//   * the (at most 16) activation rows live in LDS (34 KB at K=4096), read with conflict-free ds_read_b128;
+//   * a quantisation group is 4 consecutive chunks = 4 consecutive lanes: integer partials are combined exactly with
+//     two DPP xor-adds, the quad leader applies  t = round_f32(idot*sA[m,g]); c = fma(t, sB[g,n], c);  per-lane sums
+//     are then reduced with a 6-step butterfly, keeper added last (FP32 summation ORDER therefore differs from the
+//     prefill kernel; both are within 1 fp16 ulp of the exact value).
+//   * grid: up to 1024 waves (4 per workgroup) round-robin over the N rows.
+// Replaces the M<=16 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
+// which runs the same 128x128 tensor-core tile kernel for every M.
+#include "common.h"
+
+namespace atom {
+
+// xor-1 / xor-2 lane exchange inside a quad as a DPP modifier (no LDS-pipe ds_bpermute)
+__device__ __forceinline__ int quad_sum(int d) {
+  d += __builtin_amdgcn_mov_dpp(d, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  d += __builtin_amdgcn_mov_dpp(d, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  return d;
+}
+
+template <int MB>   // rows of activations handled per pass (compile-time: 1, 2, 4, 8, 16)
+__global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, G = p.G;
+  const int rowb = K4h + kKeeper;                       // bytes of one activation row in LDS: packed int4 | int8 keeper
+  float *sAl = reinterpret_cast<float *>(lds + ((MB * rowb + 15) & ~15));   // [MB][G+1] activation scales (keeper last)
+
+  // stage activations (tiny) into LDS
+  for (int m = 0; m < MB; ++m) {
+    const int ms = min(m, p.M - 1);
+    for (int i = tid * 16; i < K4h; i += 256 * 16)
+      *reinterpret_cast<v4u *>(lds + m * rowb + i) = *reinterpret_cast<const v4u *>(p.A4 + (int64_t)ms * K4h + i);
+    if (tid < 8)
+      *reinterpret_cast<v4u *>(lds + m * rowb + K4h + tid * 16) =
+          *reinterpret_cast<const v4u *>(p.A8 + (int64_t)ms * kKeeper + tid * 16);
+    const int off = p.ref_layout ? ref_scale_index(ms) : ms;
+    for (int g = tid; g <= G; g += 256)
+      sAl[m * (G + 1) + g] = g < G ? (float)p.sA[(int64_t)g * p.ldA + off] : (float)p.sA8[off];
+  }
+  __syncthreads();
+
+  const int nchunks = K4h >> 4;                         // 16-byte chunks per weight row (multiple of 4)
+  const int nwaves = gridDim.x * 4;
+  for (int n = blockIdx.x * 4 + wave; n < p.N; n += nwaves) {
+    const uint8_t *brow = p.B4 + (int64_t)n * K4h;
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+      const int c = c0 + lane;
+      const bool ok = c < nchunks;
+      v4i w = {0, 0, 0, 0};
+      float sb = 0.f;
+      const int g = c >> 2;
+      if (ok) {
+        w = *reinterpret_cast<const v4i *>(brow + c * 16);
+        if ((lane & 3) == 0) sb = (float)p.sB[(int64_t)g * p.N + n];
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        int d = 0;
+        if (ok) {
+          const v4i a = *reinterpret_cast<const v4i *>(lds + m * rowb + c * 16);
+          d = __builtin_amdgcn_sdot8(a[0], w[0], d, false);
+          d = __builtin_amdgcn_sdot8(a[1], w[1], d, false);
+          d = __builtin_amdgcn_sdot8(a[2], w[2], d, false);
+          d = __builtin_amdgcn_sdot8(a[3], w[3], d, false);
+        }
+        d = quad_sum(d);                                // exact: the group's 128-element integer dot
+        if (ok && (lane & 3) == 0) {
+          const float t = (float)d * sAl[m * (G + 1) + g];
+          acc[m] = __builtin_fmaf(t, sb, acc[m]);
+        }
+      }
+    }
+    // INT8 keeper: 8 chunks of 16 bytes on lanes 0..7
+    {
+      v4i w = {0, 0, 0, 0};
+      if (lane < 8) w = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + lane * 16);
+      const float sb8 = (float)p.sB8[n];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        int d = 0;
+        if (lane < 8) {
+          const v4i a = *reinterpret_cast<const v4i *>(lds + m * rowb + K4h + lane * 16);
+          d = __builtin_amdgcn_sdot4(a[0], w[0], d, false);
+          d = __builtin_amdgcn_sdot4(a[1], w[1], d, false);
+          d = __builtin_amdgcn_sdot4(a[2], w[2], d, false);
+          d = __builtin_amdgcn_sdot4(a[3], w[3], d, false);
+        }
+        d = quad_sum(d);
+        d += __shfl_xor(d, 4);
+        float s = acc[m];
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k);
+        if (lane == 0 && m < p.M) {
+          const float t = (float)d * sAl[m * (G + 1) + G];
+          p.D[(int64_t)m * p.N + n] = f2h(__builtin_fmaf(t, sb8, s));
+        }
+      }
+    }
+  }
+}
+
+template <int MB>
+static int launch_gemv_mb(const GemmParams &p, hipStream_t s) {
+  const size_t lds = (size_t)((MB * (p.K4h + kKeeper) + 15) & ~15) + (size_t)MB * (p.G + 1) * 4;
+  if (lds > 160 * 1024) return ATOM_ERR_SHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_w4a4_kernel<MB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ATOM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  int blocks = (p.N + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL((gemv_w4a4_kernel<MB>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  return check_launch();
+}
+
+// M <= 16.  Returns ATOM_ERR_SHAPE when the activations do not fit LDS (caller falls back to the tile kernel).
+int launch_gemv(const GemmParams &p, hipStream_t s) {
+  if (p.M <= 1) return launch_gemv_mb<1>(p, s);
+  if (p.M <= 2) return launch_gemv_mb<2>(p, s);
+  if (p.M <= 4) return launch_gemv_mb<4>(p, s);
+  if (p.M <= 8) return launch_gemv_mb<8>(p, s);
+  return launch_gemv_mb<16>(p, s);
+}
+
+}  // namespace atom
