@@ -47,6 +47,8 @@ struct GemmParams {
   const uint8_t *A8, *B8;
   const half_t *sA8, *sB8;
   half_t *D;
+  uint8_t *D4;      // o4 epilogue: packed u4 [M, N/2]
+  half_t *Dsz;      // o4 epilogue: (scale, zero) [M, N/128, 2]
   int M, N;
   int K4h;          // packed bytes per row of A4/B4 = K4/2
   int G;            // int4 groups
@@ -55,6 +57,7 @@ struct GemmParams {
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
+int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s);         // gemm_w4a4_v2.hip, u4 epilogue
 int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -276,6 +276,10 @@ static int launch_gemm(const GemmParams &p, hipStream_t s) {
 
 using namespace atom;
 
+static int fill_params(GemmParams &p, const void *A4, const void *B4, const void *sA, const void *sB, const void *A8,
+                       const void *B8, const void *sA8, const void *sB8, int64_t M, int64_t N, int64_t K_total, int group,
+                       int keeper, int scale_layout);
+
 extern "C" {
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }
@@ -294,23 +298,12 @@ const char *atom_strerror(int code) {
 int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8,
                        const void *B8, const void *sA8, const void *sB8, void *D, int64_t M, int64_t N,
                        int64_t K_total, int group, int keeper, int scale_layout, void *stream) {
-  if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8 || !D) return ATOM_ERR_INVALID_ARG;
-  if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
-  if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
-  if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return ATOM_ERR_SHAPE;
-  if (M > (1 << 24) || N > (1 << 24) || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
-  if (!aligned16(A4) || !aligned16(B4) || !aligned16(A8) || !aligned16(B8) || !aligned16(D)) return ATOM_ERR_ALIGN;
+  if (!D) return ATOM_ERR_INVALID_ARG;
   GemmParams p;
-  p.A4 = (const uint8_t *)A4; p.B4 = (const uint8_t *)B4;
-  p.sA = (const half_t *)sA;  p.sB = (const half_t *)sB;
-  p.A8 = (const uint8_t *)A8; p.B8 = (const uint8_t *)B8;
-  p.sA8 = (const half_t *)sA8; p.sB8 = (const half_t *)sB8;
+  const int fst = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+  if (fst != ATOM_OK) return fst;
+  if (!aligned16(D)) return ATOM_ERR_ALIGN;
   p.D = (half_t *)D;
-  p.M = (int)M; p.N = (int)N;
-  p.K4h = (int)((K_total - kKeeper) / 2);
-  p.G = (int)((K_total - kKeeper) / kGroup);
-  p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
-  p.ldA = (int64_t)atom_scale_size(M, scale_layout);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int variant = [] { const char *e = getenv("ATOM_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
   switch (variant) {   // tuning / ablation variants; 0 is the product path
@@ -337,10 +330,42 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
   }
 }
 
-int atom_gemm_w4a4_o4(const void *, const void *, const void *, const void *, const void *, const void *,
-                      const void *, const void *, void *, void *, int64_t, int64_t, int64_t, int, int, int,
-                      void *) {
-  return ATOM_ERR_SHAPE;   // implemented in gemm_w4a4_o4.hip once the f16 path is parity-green
+static int fill_params(GemmParams &p, const void *A4, const void *B4, const void *sA, const void *sB, const void *A8,
+                       const void *B8, const void *sA8, const void *sB8, int64_t M, int64_t N, int64_t K_total, int group,
+                       int keeper, int scale_layout) {
+  if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8) return ATOM_ERR_INVALID_ARG;
+  if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
+  if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
+  if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return ATOM_ERR_SHAPE;
+  if (M > (1 << 24) || N > (1 << 24) || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if ((M > N ? M : N) * ((K_total - kKeeper) / 2) >= (int64_t(1) << 32)) return ATOM_ERR_SHAPE;   // 32-bit DMA offsets
+  if (!aligned16(A4) || !aligned16(B4) || !aligned16(A8) || !aligned16(B8)) return ATOM_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(sB) & 3u) || (reinterpret_cast<uintptr_t>(sB8) & 3u)) return ATOM_ERR_ALIGN;
+  p.A4 = (const uint8_t *)A4; p.B4 = (const uint8_t *)B4;
+  p.sA = (const half_t *)sA;  p.sB = (const half_t *)sB;
+  p.A8 = (const uint8_t *)A8; p.B8 = (const uint8_t *)B8;
+  p.sA8 = (const half_t *)sA8; p.sB8 = (const half_t *)sB8;
+  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr;
+  p.M = (int)M; p.N = (int)N;
+  p.K4h = (int)((K_total - kKeeper) / 2);
+  p.G = (int)((K_total - kKeeper) / kGroup);
+  p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
+  p.ldA = (int64_t)atom_scale_size(M, scale_layout);
+  return ATOM_OK;
+}
+
+int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                      const void *sA8, const void *sB8, void *D_u4, void *D_scale_zero, int64_t M, int64_t N,
+                      int64_t K_total, int group, int keeper, int scale_layout, void *stream) {
+  if (!D_u4 || !D_scale_zero) return ATOM_ERR_INVALID_ARG;
+  GemmParams p;
+  const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+  if (st != ATOM_OK) return st;
+  if ((N % 128) != 0) return ATOM_ERR_SHAPE;
+  if (!aligned16(D_u4)) return ATOM_ERR_ALIGN;
+  p.D4 = (uint8_t *)D_u4;
+  p.Dsz = (half_t *)D_scale_zero;
+  return launch_gemm_v2_o4(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -212,7 +212,7 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   }
 }
 
-template <int NS, int ABL = 0>
+template <int NS, int ABL = 0, bool O4 = false>
 __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
@@ -272,6 +272,82 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail DMAs: they still target the LDS ring
   __builtin_amdgcn_s_barrier();                       // nobody reads stage data any more
 
+  if constexpr (O4) {
+    // u4 epilogue (reference: e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4_o4.cu:704-788): every 128-wide
+    // output group of a row is asymmetrically quantised from the FP32 accumulators:
+    //   scale = (max-min)/15, zero = -min, q = clamp(round_half_away((x+zero)*(1/scale)), 0, 15)
+    // (the reference's local_max_min takes abs() of BOTH extrema, :73-80 -- a bug that only cancels for non-negative
+    // tiles; we implement the intended min/max, which is what its consumer de-quantises: q*scale - zero,
+    // kernels/include/flashinfer/quantization.cuh:59-84).
+    const int l31 = lane & 31, h = lane >> 5;
+    float *mm = reinterpret_cast<float *>(lds);                 // [wave][128 rows][2] = 8 KB
+    char *ep = lds + 8192 + wave * (128 * 48);                  // per-wave [128 rows][32 B], stride 48
+    float mn[TM], mx[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      float lo = c[0][tm][0], hi = lo;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          lo = fminf(lo, c[tn][tm][r]);
+          hi = fmaxf(hi, c[tn][tm][r]);
+        }
+      lo = fminf(lo, __shfl_xor(lo, 32));                       // the other half-wave holds the other 32 features
+      hi = fmaxf(hi, __shfl_xor(hi, 32));
+      mn[tm] = lo; mx[tm] = hi;
+      if (h == 0) {
+        mm[(wave * 128 + tm * 32 + l31) * 2 + 0] = lo;
+        mm[(wave * 128 + tm * 32 + l31) * 2 + 1] = hi;
+      }
+    }
+    __syncthreads();
+    const int partner = wave ^ 1;                               // the wave holding the other 64 columns of the group
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float lo = fminf(mn[tm], mm[(partner * 128 + tm * 32 + l31) * 2 + 0]);
+      const float hi = fmaxf(mx[tm], mm[(partner * 128 + tm * 32 + l31) * 2 + 1]);
+      const float scale = (hi - lo) / 15.f;
+      const float zero = -lo;
+      const float rs = 1.0f / scale;
+      const int m = m0 + wm * 128 + tm * 32 + l31;
+      if (h == 0 && (wn & 1) == 0 && m < p.M) {
+        const int grp = (n0 + wn * 64) >> 7;
+        if (grp * 128 < p.N) {
+          half_t *dst = p.Dsz + ((int64_t)m * (p.N >> 7) + grp) * 2;
+          dst[0] = f2h(scale);
+          dst[1] = f2h(zero);
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned w = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = (c[tn][tm][4 * q + k] + zero) * rs;
+            float tr = truncf(t);
+            if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);
+            tr = fminf(fmaxf(tr, 0.f), 15.f);
+            if (scale == 0.f) tr = 0.f;
+            w |= (unsigned)(int)tr << (4 * k);
+          }
+          *reinterpret_cast<unsigned short *>(ep + (tm * 32 + l31) * 48 + (tn * 32 + 8 * q + 4 * h) / 2) = (unsigned short)w;
+        }
+    }
+    // wave-private transpose region: two 16-byte chunks per row -> 16-byte global stores, 32 rows per instruction
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = i * 32 + (lane >> 1), ch = lane & 1;
+      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * 48 + ch * 16);
+      const int m = m0 + wm * 128 + rl;
+      const int n = n0 + wn * 64 + ch * 32;
+      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D4 + ((int64_t)m * p.N + n) / 2) = v;
+    }
+    return;
+  }
+
   // Epilogue.  A lane owns token m and 4 consecutive features per (tile, q): written straight to HBM that is an
   // 8-byte store per lane at a row stride -- 64 different cache lines per instruction (measured: 32 us of a 109 us
   // kernel).  Instead each wave transposes its 128x64 fp16 tile through its own LDS region (row stride 144 B: 16-byte
@@ -311,20 +387,22 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
 
 }  // namespace v2
 
-template <int NS, int ABL = 0>
+template <int NS, int ABL = 0, bool O4 = false>
 static int launch_v2(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
   constexpr int lds_bytes = NS * v2::STAGE_BYTES > 8 * 64 * 144 ? NS * v2::STAGE_BYTES : 8 * 64 * 144;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v2::gemm_w4a4_v2_kernel<NS, ABL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v2::gemm_w4a4_v2_kernel<NS, ABL, O4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
   const int nbm = (p.M + v2::BM - 1) / v2::BM, nbn = (p.N + v2::BN - 1) / v2::BN;
-  hipLaunchKernelGGL((v2::gemm_w4a4_v2_kernel<NS, ABL>), dim3((unsigned)(nbm * nbn)), dim3(v2::NT), lds_bytes, s, p);
+  hipLaunchKernelGGL((v2::gemm_w4a4_v2_kernel<NS, ABL, O4>), dim3((unsigned)(nbm * nbn)), dim3(v2::NT), lds_bytes, s, p);
   return check_launch();
 }
+
+int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s) { return launch_v2<4, 0, true>(p, s); }
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s) {
   switch (ns) {

@@ -335,9 +335,11 @@ def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
 
 def quant_o4(D32: np.ndarray):
     """The _o4 epilogue (e2e/.../GEMM/DenseLayerGEMM_i4_o4.cu:704-788): asymmetric u4 per 128-col
-    output group.  scale = (max-min)/15, zero = -min, q = round((x+zero)/scale) & 0xF  (fp32).
-    We restate the *intended* min/max (the reference's local_max_min takes abs() of both, :73-80 of
-    that file, which is only equivalent when min<=0<=max).
+    output group of the FP32 accumulators.  scale = (max-min)/15, zero = -min, r = 1/scale,
+    q = clamp(round_half_away((x+zero)*r), 0, 15)  (fp32; the reference masks with & 0xF instead of clamping).
+    We restate the *intended* min/max: the reference's local_max_min takes abs() of BOTH extrema (:73-80 of
+    that file), which is wrong for any tile with negative values; its consumer de-quantises q*scale - zero
+    (kernels/include/flashinfer/quantization.cuh:59-84), i.e. expects the true minimum.  See DESIGN.md.
     Returns (u8 packed [M,N/2], half2 (scale,zero) [M, N/128, 2])."""
     D32 = np.asarray(D32, dtype=f32)
     M, N = D32.shape
@@ -347,7 +349,8 @@ def quant_o4(D32: np.ndarray):
     scale = ((mx - mn) / f32(15)).astype(f32)
     zero = (-mn).astype(f32)
     with np.errstate(divide="ignore", invalid="ignore"):
-        q = _round_half_away(((g + zero[..., None]) / scale[..., None]).astype(f32))
+        r = (f32(1.0) / scale).astype(f32)
+        q = _round_half_away(((g + zero[..., None]).astype(f32) * r[..., None]).astype(f32))
     q = np.where(scale[..., None] == 0, f32(0), q)
     q = np.clip(q, 0, 15).astype(np.int16).reshape(M, N)
     packed = ((q[:, 0::2] & 0xF) | ((q[:, 1::2] & 0xF) << 4)).astype(np.uint8)

@@ -29,6 +29,8 @@ def lib():
                                        ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.oracle_gemm_w4a4_f16.restype = None
         L.oracle_gemm_w4a4_f16.argtypes = [vp] * 9 + [ctypes.c_long] * 3
+        L.oracle_gemm_w4a4_f32.restype = None
+        L.oracle_gemm_w4a4_f32.argtypes = [vp] * 9 + [ctypes.c_long] * 3
         _lib = L
     return _lib
 
@@ -49,14 +51,19 @@ def act_quant(op, x, b, idx, sim, clip, eps=0.0):
     return dict(q4=q4, s4=s4, q8=q8, s8=s8)
 
 
-def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8):
-    """Packed operands, sA_GM plain [G, M].  Returns float16 [M, N] under the C-ABI arithmetic contract."""
+def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False):
+    """Packed operands, sA_GM plain [G, M].  Returns float16 [M, N] under the C-ABI arithmetic contract
+    (fp32=True: the FP32 accumulators before the final rounding)."""
     A4 = np.ascontiguousarray(A4, np.uint8); B4 = np.ascontiguousarray(B4, np.uint8)
     M, N = A4.shape[0], B4.shape[0]
     K = A4.shape[1] * 2 + 128
     arrs = [A4, B4, np.ascontiguousarray(sA_GM, np.float16), np.ascontiguousarray(sB, np.float16),
             np.ascontiguousarray(A8, np.int8), np.ascontiguousarray(B8, np.int8),
             np.ascontiguousarray(sA8, np.float16), np.ascontiguousarray(sB8, np.float16)]
+    if fp32:
+        D = np.empty((M, N), np.float32)
+        lib().oracle_gemm_w4a4_f32(*[_p(a) for a in arrs], _p(D), M, N, K)
+        return D
     D = np.empty((M, N), np.float16)
     lib().oracle_gemm_w4a4_f16(*[_p(a) for a in arrs], _p(D), M, N, K)
     return D

@@ -144,3 +144,27 @@ def test_gemm_bit_exact_vs_c_contract():
         out = t2n(ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain"))
         want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
         assert np.array_equal(bits16(out), bits16(want)), f"{M}x{N}x{K}: {(bits16(out) != bits16(want)).sum()} elements differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 128, 640), (300, 384, 384), (64, 4096, 1152)])
+def test_gemm_o4_epilogue(M, N, K):
+    """dense_layer_gemm_i4_o4: u4 codes + (scale, zero) per 128-column output group, bit-exact against the oracle's
+    restatement of the epilogue applied to the C-contract FP32 accumulators; and the de-quantised tensor
+    q*scale - zero (flashinfer/quantization.cuh:59-84) is within half a quantisation step of the fp16 GEMM."""
+    from tests import c_oracle as C
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M + 3 * N)
+    dev = to_device(d, "plain")
+    q, sz = ops.dense_layer_gemm_i4_o4(*dev, scale_layout="plain")
+    assert q.shape == (M, N // 2) and q.dtype == torch.uint8 and sz.shape == (M, N // 128 * 2)
+    c32 = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"],
+                 d["sB8"], fp32=True)
+    want_q, want_sz = O.quant_o4(c32)
+    assert np.array_equal(bits16(t2n(sz).reshape(M, N // 128, 2)), bits16(want_sz))
+    assert np.array_equal(t2n(q), want_q)
+    # round trip
+    codes = np.stack([t2n(q) & 0xF, t2n(q) >> 4], axis=-1).reshape(M, N).astype(np.float32)
+    s = t2n(sz).reshape(M, N // 128, 2).astype(np.float32)
+    deq = codes.reshape(M, N // 128, 128) * s[..., 0:1] - s[..., 1:2]
+    ref = t2n(ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")).astype(np.float32).reshape(M, N // 128, 128)
+    assert np.abs(deq - ref).max() <= 0.51 * s[..., 0].max() + 0.1
