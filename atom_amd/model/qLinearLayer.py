@@ -1,0 +1,133 @@
+"""HIP-backed mirror of the reference's ``model/qLinearLayer.py`` (same class / function names and signatures).
+
+``QLinearLayer`` keeps the reference contract -- a mutable fp16 ``weight`` buffer [N, K] that ``reorder()`` permutes,
+``quant()`` fake-quantises in place and GPTQ may overwrite (``layer.weight.data = Q``, gptq.py:331) -- and ADDS the
+packed INT4/INT8 form the W4A4 GEMM consumes (the bridge the reference lacks):
+
+    quant()    ->  atom_quant_weight_w4: one HIP kernel writes B4 / B8 / sB / sB8 and the fake-quant fp16 weight
+    forward(x) ->  atom_gemm_w4a4_f16 when x carries activation codes (quant.ActCodes) and the packed weight is
+                   current; ``F.linear`` (the reference's own forward, qLinearLayer.py:32-35) otherwise, e.g. for
+                   16-bit configurations or a weight rewritten after packing.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops as _ops
+from .quant import (fake_quantize_quarter_E4M3, fake_quantize_quarter_E5M2, get_codes,  # noqa: F401
+                    quantize_tensor, quantize_tensor_channel_group)
+
+GROUP = 128
+
+
+def find_qlinear_layers(module, name=''):
+    """reference qLinearLayer.py:5-14 (exact-type match, only layers with enable_quant)."""
+    if type(module) == QLinearLayer:
+        return {name: module} if module.enable_quant else {}
+    found = {}
+    for child_name, child in module.named_children():
+        found.update(find_qlinear_layers(child, name=f"{name}.{child_name}" if name else child_name))
+    return found
+
+
+def _is_hot_weight_config(args, n, k) -> bool:
+    return (args.wbits == 4 and bool(args.w_sym) and args.weight_group_size == GROUP and args.keeper == GROUP
+            and getattr(args, "keeper_precision", 0) == 3 and args.weight_channel_group in (1, 2)
+            and getattr(args, "quant_type", "int") == "int" and not getattr(args, "exponential", False)
+            and k % GROUP == 0 and k >= 2 * GROUP and n % 64 == 0)
+
+
+class QLinearLayer(nn.Module):
+    def __init__(self, originalLayer: nn.Linear, args, enable_quant: bool = True):
+        super().__init__()
+        self.args = args
+        self.register_buffer('weight', originalLayer.weight)
+        self.enable_quant = enable_quant
+        if originalLayer.bias is not None:
+            self.register_buffer('bias', originalLayer.bias)
+        else:
+            self.bias = None
+        self._packed = None          # (B4, B8, sB, sB8)
+        self._packed_key = None      # identity of the fp16 weight the packed form was made from
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _weight_key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, tuple(w.shape), w.device)
+
+    def packed_weight(self):
+        """Packed operands if they are current for ``self.weight``, else None."""
+        if self._packed is not None and self._packed_key == self._weight_key():
+            return self._packed
+        return None
+
+    @torch.no_grad()
+    def forward(self, x):
+        codes = get_codes(x)
+        packed = self.packed_weight() if codes is not None else None
+        if packed is not None and codes.hidden == self.weight.shape[1] and x.is_cuda:
+            b4, b8, sb, sb8 = packed
+            y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
+                                              scale_layout=codes.layout)
+            y = y.view(*x.shape[:-1], self.weight.shape[0])
+            if self.bias is not None:
+                y = y + self.bias
+            return y
+        return torch.functional.F.linear(x, self.weight, self.bias)
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.weight = self.weight.to(*args, **kwargs)
+        if self._packed is not None:
+            dev = self.weight.device
+            if dev.type == "cuda":
+                self._packed = tuple(t.to(dev) for t in self._packed)
+                self._packed_key = self._weight_key()
+            else:
+                self._packed_key = None      # packed form stays on its GPU; re-keyed when the weight comes back
+        return self
+
+    # ------------------------------------------------------------------------------------------------ quant
+    @torch.no_grad()
+    def quant(self):
+        """reference qLinearLayer.py:42-78.  Hot configuration: one HIP kernel; otherwise the reference steps in torch."""
+        a = self.args
+        if a.wbits >= 16:
+            return
+        n, k = self.weight.shape
+        if self.weight.is_cuda and self.weight.dtype == torch.float16 and _is_hot_weight_config(a, n, k):
+            w = self.weight.contiguous()
+            b4, b8, sb, sb8, wq = _ops.quant_weight_w4(w, float(a.w_clip_ratio), int(a.weight_channel_group),
+                                                        return_fake_quant=True)
+            self.weight = wq
+            self._packed = (b4, b8, sb, sb8)
+            self._packed_key = self._weight_key()
+            return
+        saved = None
+        if a.keeper > 0:
+            saved = self.weight[:, -a.keeper:].clone().contiguous()
+            kp = getattr(a, "keeper_precision", 0)
+            if kp == 1:
+                saved = fake_quantize_quarter_E5M2(saved)
+            elif kp == 2:
+                saved = fake_quantize_quarter_E4M3(saved)
+            elif kp == 3:
+                saved = quantize_tensor(saved, n_bits=8, group_size=0, tiling=0, sym=True)
+            self.weight[:, -a.keeper:] = 0
+        self.weight = quantize_tensor_channel_group(self.weight.clone(), n_bits=a.wbits, exponential=a.exponential,
+                                                    sym=a.w_sym, group_size=a.weight_group_size,
+                                                    channel_group=a.weight_channel_group, clip_ratio=a.w_clip_ratio,
+                                                    tiling=a.tiling, quant_type=a.quant_type)
+        if saved is not None:
+            self.weight[:, -a.keeper:] = saved
+        self._packed = None
+
+    def reorder(self, in_reorder_index, out_reorder_index=None):
+        """reference qLinearLayer.py:80-86."""
+        if self.args.reorder is True:
+            self.weight = torch.index_select(self.weight, 1, in_reorder_index.to(self.weight.device))
+            if out_reorder_index is not None:
+                self.weight = torch.index_select(self.weight, 0, out_reorder_index.to(self.weight.device))
+            self._packed = None
+        return
