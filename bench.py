@@ -69,6 +69,24 @@ def cpu_baseline(M, N, K, budget_s=15.0):
                       f"median of {max(len(times), 1)} runs, {t * 1e3:.1f} ms each"}
 
 
+def max_over_ranks(values, dist, device):
+    """Element-wise MAX of a list of per-rank floats over all ranks (identity when not distributed)."""
+    if dist is None:
+        return list(values)
+    tt = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return tt.tolist()
+
+
+def aggregate(world, steps, wall_s, kern_ms, M, N, K):
+    """Whole-job numbers from the slowest rank's times: every rank ran `steps` independent replicas of the GEMM."""
+    ops_per_step = 2.0 * M * N * K
+    return {"value": world * ops_per_step * steps / wall_s / 1e12,
+            "gbps": world * algorithmic_bytes(M, N, K) * steps / wall_s / 1e9,
+            "ms_per_step": wall_s / steps * 1e3,
+            "achieved": ops_per_step / (kern_ms * 1e-3) / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,23 +140,20 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps                  # HIP events on the launch stream
-    if dist is not None:
-        tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, kern_ms = tt[0].item(), tt[1].item()
+    wall, kern_ms = max_over_ranks([wall, kern_ms], dist, dev)
 
     if rank == 0:
+        agg = aggregate(world, args.steps, wall, kern_ms, M, N, K)
         ops_per_step = 2.0 * M * N * K
-        tops = world * ops_per_step * args.steps / wall / 1e12
-        ach = ops_per_step / (kern_ms * 1e-3) / 1e12
+        tops, ach = agg["value"], agg["achieved"]
         out = {
             "metric": "effective TOPS, W4A4 group-128 GEMM + 128 INT8 outlier cols, fp16 out",
             "value": round(tops, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(agg["ms_per_step"], 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int4xint4->int32 (i8 MFMA), fp32 dequant, fp16 out", "data": "synthetic",
             "config": {"workload": f"W4A4 GEMM M={M} N={N} K={K} group=128 keeper=128 (BASELINE configs[2])",
                        "M": M, "N": N, "K": K, "parallelism": f"replicas x{world}"},
-            "gbps": round(world * algorithmic_bytes(M, N, K) * args.steps / wall / 1e9, 1),
+            "gbps": round(agg["gbps"], 1),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_I8_TOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": None,
                          "kernel_us": round(kern_ms * 1e3, 2),
