@@ -317,16 +317,22 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
     case 115: return launch_gemm<GemmCfg<128, 256, 2, 4>, 15>(p, hs);
     case 203: return launch_gemm_v2(p, 3, hs);
     case 204: return launch_gemm_v2(p, 4, hs);
-    case 1001: case 1002: case 1003: case 1004: case 1008: case 1016: case 1019: case 1023: case 1031: case 1032: case 1033: case 1035:
+    case 1001: case 1002: case 1003: case 1004: case 1008: case 1016: case 1019: case 1023: case 1031: case 1032: case 1033: case 1035: case 1064: case 1128: case 1256:
       return launch_gemm_v2(p, variant, hs);
     case 1: return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, hs);    // v1: register-staged, int8-expanded LDS tiles
     case 2: return launch_gemm_v2(p, 4, hs);
+    case 300: case 301: case 302: case 303: return launch_gemm_v3(p, variant - 300, hs);
     default:                                                        // product path
       if (M <= 16) {                                                // decode: weight-streaming dot-product kernel
         const int st = launch_gemv(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
       }
-      return launch_gemm_v2(p, 4, hs);                              // prefill: LDS-DMA 256x256 MFMA tile kernel
+      {                                                             // prefill: LDS-DMA MFMA tile kernel (v3 = v2 design)
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        // >= 4 full waves of 256x256 tiles: one 8-wave workgroup per CU; otherwise 256x128 tiles, two 4-wave
+        // workgroups per CU (finer tile quantisation; measured +10 % at 2048x11008x4096, equal at 4096^3)
+        return launch_gemm_v3(p, tiles256 >= 1024 ? 0 : 1, hs);
+      }
   }
 }
 

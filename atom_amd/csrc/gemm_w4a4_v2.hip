@@ -212,6 +212,62 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   }
 }
 
+// Ping-pong variant (ABL bit 64, experimental): the MFMA chain of tile i+1 is issued BEFORE the dequant of tile i, so
+// the 12 wait states after a chain and the dequant's dependency latency are covered by matrix work of the same wave.
+template <bool INT4>
+__device__ __forceinline__ void compute_step_pp(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+  constexpr int KS = INT4 ? 4 : 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  v16i magic;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
+  v4i af[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) load_frag<INT4, 0>(slot, wn * 64 + tn * 32 + l31, h, af[tn]);
+
+  auto chain = [&](const v4i (&bf)[4], int tn) {
+    v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], bf[0], magic, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < KS; ++s) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[s], a, 0, 0, 0);
+    return a;
+  };
+  auto dequant = [&](const v16i &a, int tn, int tm, float sa, float nms) {
+    v2u sbp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      sbp[q] = *reinterpret_cast<const v2u *>(slot + SB_OFF + (wn * 64 + tn * 32 + 8 * q + 4 * h) * 2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+      const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
+      c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+      asm volatile("" : "+v"(c[tn][tm][r]));
+    }
+  };
+
+  v16i a_prev;
+  float sa_prev = 0.f, nms_prev = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int ml = wm * 128 + tm * 32 + l31;
+    v4i bf[4];
+    load_frag<INT4, 0>(slot, 256 + ml, h, bf);
+    const float sa = (float)*reinterpret_cast<const half_t *>(slot + SA_OFF + ml * 4) * (INT4 ? (1.0f / 256.0f) : 1.0f);
+    const float nms = -kMagic * sa;
+    __builtin_amdgcn_sched_barrier(0);
+    v16i a0 = chain(bf, 0);                       // tile (tm, 0) in flight ...
+    __builtin_amdgcn_sched_barrier(0);
+    if (tm > 0) dequant(a_prev, 1, tm - 1, sa_prev, nms_prev);     // ... while tile (tm-1, 1) is dequantised
+    __builtin_amdgcn_sched_barrier(0);
+    v16i a1 = chain(bf, 1);                       // tile (tm, 1) in flight ...
+    __builtin_amdgcn_sched_barrier(0);
+    dequant(a0, 0, tm, sa, nms);                  // ... while tile (tm, 0) is dequantised
+    __builtin_amdgcn_sched_barrier(0);
+    a_prev = a1; sa_prev = sa; nms_prev = nms;
+  }
+  dequant(a_prev, 1, TM - 1, sa_prev, nms_prev);
+}
+
 template <int NS, int ABL = 0, bool O4 = false>
 __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -263,7 +319,16 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
     if (!(ABL & 8))                                                                                                \
       issue_stage(p, min(step + NS - 1, nsteps - 1), lds + ((step + NS - 1) % NS) * STAGE_BYTES, wave, sa_);       \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
-    compute_step<INT4, ABL>(lds + (step % NS) * STAGE_BYTES, wm, wn, lane, c);                                     \
+    if constexpr (ABL & 64)                                                                                        \
+      compute_step_pp<INT4>(lds + (step % NS) * STAGE_BYTES, wm, wn, lane, c);                                     \
+    else                                                                                                           \
+      compute_step<INT4, ABL>(lds + (step % NS) * STAGE_BYTES, wm, wn, lane, c);                                   \
+  }
+  if constexpr (ABL & 128) {   // experiment: static priority for the younger half of the workgroup
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
+  if constexpr (ABL & 256) {   // experiment: start the two waves of a SIMD half a tile apart
+    if (wave >= 4) __builtin_amdgcn_s_sleep(4);
   }
   int step = 0;
   for (; step < p.G; ++step) ATOM_V2_STEP(true)
@@ -419,6 +484,9 @@ int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s) {
     case 1032: return launch_v2<4, 32>(p, s);
     case 1033: return launch_v2<4, 33>(p, s);
     case 1035: return launch_v2<4, 35>(p, s);
+    case 1064: return launch_v2<4, 64>(p, s);
+    case 1128: return launch_v2<4, 128>(p, s);
+    case 1256: return launch_v2<4, 256>(p, s);
     default: return launch_v2<4>(p, s);
   }
 }

@@ -1,0 +1,282 @@
+// W4A4 GEMM, prefill kernel v3 = gemm_w4a4_v2.hip with the block geometry as a template parameter (see that file's
+// header for the design).  The second instantiation runs TWO independent 4-wave workgroups per CU (256x128 tile, 76 KiB
+// LDS each) instead of one 8-wave workgroup: the two workgroups drift out of phase, so one's prologue / barrier /
+// epilogue stalls are covered by the other's main loop.
+#include "common.h"
+
+namespace atom {
+namespace v3 {
+
+constexpr float kMagic = 12582912.0f;
+constexpr int kMagicBits = 0x4B400000;
+constexpr int TM = 4, TN = 2;                  // wave tile 128(m) x 64(n)
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int BM_, int BN_, int NS_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, NS = NS_;
+  static constexpr int WGM = BM / 128, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
+  static constexpr int ROWS = BM + BN;                       // weights rows [0,BN), activation rows [BN, BN+BM)
+  static constexpr int DATA_BYTES = ROWS * 64;
+  static constexpr int SB_OFF = DATA_BYTES;                  // BN fp16, dense
+  static constexpr int SA_OFF = DATA_BYTES + BN * 2;         // BM dwords (fp16 in the low half)
+  static constexpr int STAGE_BYTES = DATA_BYTES + BN * 2 + BM * 4;
+  static constexpr int IPW = ROWS / 16 / NW;                 // data DMA instructions per wave per stage
+  static constexpr int NSA = BM / 64, NSB = BN / 128;        // scale DMA instructions per stage (ushort / dword)
+  static constexpr int SPW = (NSA + NSB + NW - 1) / NW;      // scale DMA slots per wave (padded with duplicates)
+  static constexpr int GLDS = IPW + SPW;
+  static constexpr int EP_BYTES = NW * 64 * 144;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
+  static_assert(ROWS % (16 * NW) == 0 && BN % 128 == 0 && BM % 128 == 0, "geometry");
+  static_assert(STAGE_BYTES % 16 == 0, "stage alignment");
+};
+
+template <class C>
+struct StageAddr {
+  unsigned data[C::IPW];
+  unsigned data8[C::IPW];
+  unsigned scale[C::SPW];
+};
+
+template <class C>
+__device__ __forceinline__ void make_stage_addr(const GemmParams &p, int wave, int lane, int m0, int n0, StageAddr<C> &a) {
+#pragma unroll
+  for (int i = 0; i < C::IPW; ++i) {
+    const int row = (wave * C::IPW + i) * 16 + (lane >> 2);   // row inside the stage
+    const bool isW = row < C::BN;                             // wave-uniform (16-row granules, BN % 16 == 0)
+    const int j = (lane & 3) ^ ((row >> 2) & 3);              // logical chunk that must land in slot lane&3
+    const int idx = isW ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1);
+    a.data[i] = (unsigned)idx * (unsigned)p.K4h + j * 16;
+    a.data8[i] = (unsigned)idx * kKeeper + j * 16;
+  }
+#pragma unroll
+  for (int s = 0; s < C::SPW; ++s) {
+    const int slot = wave * C::SPW + s;
+    if (slot < C::NSA) {
+      const int idx = min(m0 + slot * 64 + lane, p.M - 1);
+      a.scale[s] = p.ref_layout ? ref_scale_index(idx) : idx;
+    } else {
+      const int part = slot - C::NSA < C::NSB ? slot - C::NSA : 0;
+      a.scale[s] = min(n0 + part * 128 + 2 * lane, p.N - 2);
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char *slot, int wave, const StageAddr<C> &a) {
+  const bool int4 = step < p.G;
+  const int koff = (int4 ? step : step - p.G) * 64;
+  const uint8_t *wb = (int4 ? p.B4 : p.B8) + koff;
+  const uint8_t *ab = (int4 ? p.A4 : p.A8) + koff;
+#pragma unroll
+  for (int i = 0; i < C::IPW; ++i) {
+    const int row0 = (wave * C::IPW + i) * 16;
+    const uint8_t *base = row0 < C::BN ? wb : ab;
+    const unsigned off = int4 ? a.data[i] : a.data8[i];
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(slot + row0 * 64), 16, 0, 0);
+  }
+  const bool keeper = step >= p.G;
+  const int g = min(step, p.G - 1);
+  const half_t *sAb = keeper ? p.sA8 : p.sA + (int64_t)g * p.ldA;
+  const half_t *sBb = keeper ? p.sB8 : p.sB + (int64_t)g * p.N;
+#pragma unroll
+  for (int s = 0; s < C::SPW; ++s) {
+    const int sl = wave * C::SPW + s;
+    if (sl < C::NSA) {   // one fp16 per lane; lands as one zero-extended dword per lane (tools/probes/glds_probe.cpp)
+      __builtin_amdgcn_global_load_lds((gptr_t)(sAb + a.scale[s]), (lptr_t)(slot + C::SA_OFF + sl * 256), 2, 0, 0);
+    } else {             // a dword = two adjacent channels per lane, dense fp16 image (padding slots repeat part 0)
+      const int part = sl - C::NSA < C::NSB ? sl - C::NSA : 0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(sBb + a.scale[s]), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void widen(const v4u p, v4i &lo, v4i &hi) {
+  const v4u l = (p << 4) & 0xF0F0F0F0u;
+  const v4u h = p & 0xF0F0F0F0u;
+  lo = __builtin_bit_cast(v4i, l);
+  hi = __builtin_bit_cast(v4i, h);
+}
+
+template <bool INT4>
+__device__ __forceinline__ void load_frag(const char *slot, int row, int h, v4i (&f)[4]) {
+  const int sw = (row >> 2) & 3;
+  const char *rb = slot + row * 64;
+  const v4u c0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
+  const v4u c1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
+  if constexpr (INT4) {
+    widen(c0, f[0], f[1]);
+    widen(c1, f[2], f[3]);
+  } else {
+    f[0] = __builtin_bit_cast(v4i, c0);
+    f[1] = __builtin_bit_cast(v4i, c1);
+  }
+}
+
+template <class C, bool INT4>
+__device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+  constexpr int KS = INT4 ? 4 : 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  v16i magic;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
+  v4i af[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) load_frag<INT4>(slot, wn * 64 + tn * 32 + l31, h, af[tn]);
+
+  v4u pk0, pk1;
+  half_t sah;
+  auto request = [&](int tm) {
+    const int row = C::BN + wm * 128 + tm * 32 + l31;
+    const int sw = (row >> 2) & 3;
+    const char *rb = slot + row * 64;
+    pk0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
+    pk1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
+    sah = *reinterpret_cast<const half_t *>(slot + C::SA_OFF + (wm * 128 + tm * 32 + l31) * 4);
+  };
+  request(0);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_sched_barrier(0);
+    v4i bf[4];
+    if constexpr (INT4) {
+      widen(pk0, bf[0], bf[1]);
+      widen(pk1, bf[2], bf[3]);
+    } else {
+      bf[0] = __builtin_bit_cast(v4i, pk0); bf[1] = __builtin_bit_cast(v4i, pk1); bf[2] = bf[0]; bf[3] = bf[1];
+    }
+    const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
+    if (tm + 1 < TM) request(tm + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float nms = -kMagic * sa;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      __builtin_amdgcn_sched_barrier(0);
+      v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], bf[0], magic, 0, 0, 0);
+#pragma unroll
+      for (int s = 1; s < KS; ++s) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[s], a, 0, 0, 0);
+      v2u sbp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        sbp[q] = *reinterpret_cast<const v2u *>(slot + C::SB_OFF + (wn * 64 + tn * 32 + 8 * q + 4 * h) * 2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
+        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        asm volatile("" : "+v"(c[tn][tm][r]));
+      }
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[TN][TM][16];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
+
+  const int nsteps = p.G + 2;
+  StageAddr<C> sa_;
+  make_stage_addr<C>(p, wave, lane, m0, n0, sa_);
+#pragma unroll
+  for (int s = 0; s < C::NS - 1; ++s) issue_stage<C>(p, min(s, nsteps - 1), lds + s * C::STAGE_BYTES, wave, sa_);
+
+#define ATOM_V3_STEP(INT4)                                                                                           \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (C::NS - 2)) : "memory");                                     \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    issue_stage<C>(p, min(step + C::NS - 1, nsteps - 1), lds + ((step + C::NS - 1) % C::NS) * C::STAGE_BYTES, wave,  \
+                   sa_);                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    compute_step<C, INT4>(lds + (step % C::NS) * C::STAGE_BYTES, wm, wn, lane, c);                                   \
+  }
+  int step = 0;
+  for (; step < p.G; ++step) ATOM_V3_STEP(true)
+  for (; step < nsteps; ++step) ATOM_V3_STEP(false)
+#undef ATOM_V3_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int EP_STRIDE = 144;
+  char *ep = lds + wave * (64 * EP_STRIDE);
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int tm = half * 2 + t2;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v2u o;
+          half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ov[k] = f2h(c[tn][tm][4 * q + k]);
+          *reinterpret_cast<v2u *>(ep + (t2 * 32 + l31) * EP_STRIDE + (tn * 32 + 8 * q + 4 * h) * 2) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = i * 8 + (lane >> 3);
+      const int ch = lane & 7;
+      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
+      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int n = n0 + wn * 64 + ch * 8;
+      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+    }
+  }
+}
+
+}  // namespace v3
+
+template <class C>
+static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return ATOM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  return check_launch();
+}
+
+int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 1: return launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
+    case 2: return launch_v3_cfg<v3::Cfg<128, 256, 3>>(p, s);   // 4 waves (1 x 4), two workgroups per CU
+    case 3: return launch_v3_cfg<v3::Cfg<256, 128, 2>>(p, s);
+    default: return launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
+  }
+}
+
+}  // namespace atom
