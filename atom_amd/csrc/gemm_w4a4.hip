@@ -322,6 +322,12 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
     case 1: return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, hs);    // v1: register-staged, int8-expanded LDS tiles
     case 2: return launch_gemm_v2(p, 4, hs);
     case 300: case 301: case 302: case 303: return launch_gemm_v3(p, variant - 300, hs);
+    case 310: case 311: {   // traced run: the trace buffer pointer arrives in ATOM_TRACE_PTR (tools/trace_gemm.cpp)
+      const char *e = getenv("ATOM_TRACE_PTR");
+      if (!e) return ATOM_ERR_INVALID_ARG;
+      p.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+      return launch_gemm_v3(p, variant - 300, hs);
+    }
     default:                                                        // product path
       if (M <= 16) {                                                // decode: weight-streaming dot-product kernel
         const int st = launch_gemv(p, hs);

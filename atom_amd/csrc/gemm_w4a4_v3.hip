@@ -172,7 +172,7 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   }
 }
 
-template <class C>
+template <class C, bool TRACE = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
@@ -207,19 +207,27 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < C::NS - 1; ++s) issue_stage<C>(p, min(s, nsteps - 1), lds + s * C::STAGE_BYTES, wave, sa_);
 
+  // TRACE (tuning only): s_memtime stamps of block 0 into p.Dsz as u64[wave][step][4]
+  unsigned long long *trace = reinterpret_cast<unsigned long long *>(p.Dsz);
+  const bool tr = TRACE && blockIdx.x == 0 && lane == 0;
 #define ATOM_V3_STEP(INT4)                                                                                           \
   {                                                                                                                  \
+    if (tr) trace[(wave * 64 + step) * 4 + 0] = __builtin_amdgcn_s_memtime();                                        \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (C::NS - 2)) : "memory");                                     \
+    if (tr) trace[(wave * 64 + step) * 4 + 1] = __builtin_amdgcn_s_memtime();                                        \
     __builtin_amdgcn_s_barrier();                                                                                    \
+    if (tr) trace[(wave * 64 + step) * 4 + 2] = __builtin_amdgcn_s_memtime();                                        \
     issue_stage<C>(p, min(step + C::NS - 1, nsteps - 1), lds + ((step + C::NS - 1) % C::NS) * C::STAGE_BYTES, wave,  \
                    sa_);                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (tr) trace[(wave * 64 + step) * 4 + 3] = __builtin_amdgcn_s_memtime();                                        \
     compute_step<C, INT4>(lds + (step % C::NS) * C::STAGE_BYTES, wm, wn, lane, c);                                   \
   }
   int step = 0;
   for (; step < p.G; ++step) ATOM_V3_STEP(true)
   for (; step < nsteps; ++step) ATOM_V3_STEP(false)
 #undef ATOM_V3_STEP
+  if (tr) trace[(wave * 64 + step) * 4 + 0] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -256,17 +264,17 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
 
 }  // namespace v3
 
-template <class C>
+template <class C, bool TRACE = false>
 static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, TRACE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C, TRACE>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
   return check_launch();
 }
 
@@ -275,6 +283,8 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     case 1: return launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
     case 2: return launch_v3_cfg<v3::Cfg<128, 256, 3>>(p, s);   // 4 waves (1 x 4), two workgroups per CU
     case 3: return launch_v3_cfg<v3::Cfg<256, 128, 2>>(p, s);
+    case 10: return launch_v3_cfg<v3::Cfg<256, 256, 4>, true>(p, s);   // traced (p.Dsz = u64 trace buffer)
+    case 11: return launch_v3_cfg<v3::Cfg<256, 128, 3>, true>(p, s);
     default: return launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
   }
 }

@@ -87,6 +87,20 @@ def aggregate(world, steps, wall_s, kern_ms, M, N, K):
             "achieved": ops_per_step / (kern_ms * 1e-3) / 1e12}
 
 
+def measured_traffic(M, N, K):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/bench_hbm_traffic.json), or None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for d in sorted(os.listdir(pdir)):
+            f = os.path.join(pdir, d, "bench_hbm_traffic.json")
+            if os.path.isfile(f):
+                t = json.load(open(f))
+                if t.get("algorithmic_bytes_per_launch") == algorithmic_bytes(M, N, K):
+                    best = int(t["traffic_bytes_per_launch"])
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +169,7 @@ def main():
                        "M": M, "N": N, "K": K, "parallelism": f"replicas x{world}"},
             "gbps": round(agg["gbps"], 1),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_I8_TOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": measured_traffic(M, N, K),
                          "kernel_us": round(kern_ms * 1e3, 2),
                          "algorithmic_bytes": algorithmic_bytes(M, N, K), "algorithmic_ops": int(ops_per_step)},
         }
