@@ -321,7 +321,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       return launch_gemm_v2(p, variant, hs);
     case 1: return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, hs);    // v1: register-staged, int8-expanded LDS tiles
     case 2: return launch_gemm_v2(p, 4, hs);
-    case 300: case 301: case 302: case 303: return launch_gemm_v3(p, variant - 300, hs);
+    case 300: case 301: case 302: case 303: case 304: case 305: case 306: return launch_gemm_v3(p, variant - 300, hs);
     case 310: case 311: {   // traced run: the trace buffer pointer arrives in ATOM_TRACE_PTR (tools/trace_gemm.cpp)
       const char *e = getenv("ATOM_TRACE_PTR");
       if (!e) return ATOM_ERR_INVALID_ARG;
@@ -333,11 +333,17 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
         const int st = launch_gemv(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
       }
-      {                                                             // prefill: LDS-DMA MFMA tile kernel (v3 = v2 design)
-        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-        // >= 4 full waves of 256x256 tiles: one 8-wave workgroup per CU; otherwise 256x128 tiles, two 4-wave
-        // workgroups per CU (finer tile quantisation; measured +10 % at 2048x11008x4096, equal at 4096^3)
-        return launch_gemm_v3(p, tiles256 >= 1024 ? 0 : 1, hs);
+      {   // prefill: LDS-DMA MFMA tile kernel (gemm_w4a4_v3.hip); tile geometry by how many workgroups the shape yields
+          // (measured on MI355X, profiles/r01_tile_selection.txt): big tiles only once they fill the chip.
+        const int64_t cm256 = (M + 255) / 256, cm64 = (M + 63) / 64, cn256 = (N + 255) / 256, cn128 = (N + 127) / 128;
+        int cfg;
+        if (cm256 * cn256 >= 1024) cfg = 0;               // 256x256, 8 waves, 1 WG/CU
+        else if (cm256 * cn128 >= 512) cfg = 1;           // 256x128, 4 waves, 2 WGs/CU
+        else {
+          const int64_t t5 = cm64 * cn128;                // 64x128, 2 waves
+          cfg = (t5 > 256 && t5 < 1024) ? 4 : 5;          // in between: 64x64, 1 wave, twice the workgroups
+        }
+        return launch_gemm_v3(p, cfg, hs);
       }
   }
 }

@@ -9,27 +9,29 @@ namespace v3 {
 
 constexpr float kMagic = 12582912.0f;
 constexpr int kMagicBits = 0x4B400000;
-constexpr int TM = 4, TN = 2;                  // wave tile 128(m) x 64(n)
+constexpr int TN = 2;                          // wave tile (32*TM)(m) x 64(n); TM is a Cfg parameter (4, or 2 for skinny M)
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int BM_, int BN_, int NS_>
+template <int BM_, int BN_, int NS_, int TM_ = 4>
 struct Cfg {
-  static constexpr int BM = BM_, BN = BN_, NS = NS_;
-  static constexpr int WGM = BM / 128, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
+  static constexpr int BM = BM_, BN = BN_, NS = NS_, TM = TM_;
+  static constexpr int WM = 32 * TM;                         // rows of activations per wave
+  static constexpr int WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
   static constexpr int ROWS = BM + BN;                       // weights rows [0,BN), activation rows [BN, BN+BM)
   static constexpr int DATA_BYTES = ROWS * 64;
-  static constexpr int SB_OFF = DATA_BYTES;                  // BN fp16, dense
-  static constexpr int SA_OFF = DATA_BYTES + BN * 2;         // BM dwords (fp16 in the low half)
-  static constexpr int STAGE_BYTES = DATA_BYTES + BN * 2 + BM * 4;
+  static constexpr int SB_BYTES = (BN < 128 ? 128 : BN) * 2; // BN fp16, dense (one dword DMA always moves 128 of them)
+  static constexpr int SB_OFF = DATA_BYTES;
+  static constexpr int SA_OFF = DATA_BYTES + SB_BYTES;       // BM dwords (fp16 in the low half)
+  static constexpr int STAGE_BYTES = DATA_BYTES + SB_BYTES + BM * 4;
   static constexpr int IPW = ROWS / 16 / NW;                 // data DMA instructions per wave per stage
-  static constexpr int NSA = BM / 64, NSB = BN / 128;        // scale DMA instructions per stage (ushort / dword)
+  static constexpr int NSA = BM / 64, NSB = (BN + 127) / 128; // scale DMA instructions per stage (ushort / dword)
   static constexpr int SPW = (NSA + NSB + NW - 1) / NW;      // scale DMA slots per wave (padded with duplicates)
   static constexpr int GLDS = IPW + SPW;
   static constexpr int EP_BYTES = NW * 64 * 144;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
-  static_assert(ROWS % (16 * NW) == 0 && BN % 128 == 0 && BM % 128 == 0, "geometry");
+  static_assert(ROWS % (16 * NW) == 0 && BN % 64 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4), "geometry");
   static_assert(STAGE_BYTES % 16 == 0, "stage alignment");
 };
 
@@ -116,7 +118,8 @@ __device__ __forceinline__ void load_frag(const char *slot, int row, int h, v4i 
 }
 
 template <class C, bool INT4>
-__device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+__device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+  constexpr int TM = C::TM;
   constexpr int KS = INT4 ? 4 : 2;
   const int l31 = lane & 31, h = lane >> 5;
   v16i magic;
@@ -129,12 +132,12 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   v4u pk0, pk1;
   half_t sah;
   auto request = [&](int tm) {
-    const int row = C::BN + wm * 128 + tm * 32 + l31;
+    const int row = C::BN + wm * C::WM + tm * 32 + l31;
     const int sw = (row >> 2) & 3;
     const char *rb = slot + row * 64;
     pk0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
     pk1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
-    sah = *reinterpret_cast<const half_t *>(slot + C::SA_OFF + (wm * 128 + tm * 32 + l31) * 4);
+    sah = *reinterpret_cast<const half_t *>(slot + C::SA_OFF + (wm * C::WM + tm * 32 + l31) * 4);
   };
   request(0);
 #pragma unroll
@@ -173,7 +176,7 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
 }
 
 template <class C, bool TRACE = false>
-__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
+__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {   // <= 256 VGPRs: two waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
   const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
   const int m0 = bm * C::BM, n0 = bn * C::BN;
 
+  constexpr int TM = C::TM;
   float c[TN][TM][16];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
   char *ep = lds + wave * (64 * EP_STRIDE);
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       const int tm = half * 2 + t2;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {
       const int rl = i * 8 + (lane >> 3);
       const int ch = lane & 7;
       const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
-      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int m = m0 + wm * C::WM + half * 64 + rl;
       const int n = n0 + wn * 64 + ch * 8;
       if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
     }
@@ -283,6 +287,9 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     case 1: return launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
     case 2: return launch_v3_cfg<v3::Cfg<128, 256, 3>>(p, s);   // 4 waves (1 x 4), two workgroups per CU
     case 3: return launch_v3_cfg<v3::Cfg<256, 128, 2>>(p, s);
+    case 4: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2>>(p, s);     // skinny M: one wave per workgroup, 64x64 tile
+    case 5: return launch_v3_cfg<v3::Cfg<64, 128, 3, 2>>(p, s);    // skinny M: two waves, 64x128 tile
+    case 6: return launch_v3_cfg<v3::Cfg<128, 64, 3, 4>>(p, s);    // one wave, 128x64 tile
     case 10: return launch_v3_cfg<v3::Cfg<256, 256, 4>, true>(p, s);   // traced (p.Dsz = u64 trace buffer)
     case 11: return launch_v3_cfg<v3::Cfg<256, 128, 3>, true>(p, s);
     default: return launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
