@@ -64,9 +64,15 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
     if (c < 1.0f) amax = round_h(amax * c);                 // :168-169
     const float s = round_h(opaque(amax) / qmax);           // :170
     const float so = opaque(s);
+    // w / scales with ONE IEEE divide per group: q1 = fma(fma(-q0,s,v), r, q0), q0 = v*r, r = 1/s is the correctly
+    // rounded FP32 quotient for EVERY finite fp16 v and positive fp16 s (all 2.0e9 pairs checked on gfx950,
+    // tools/probes/div_probe.cpp; only -0/s comes out as +0, which quantises to the same code)
+    const float rs = 1.0f / so;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float t = rintf(round_h(v[i] / so));                  // :181 torch.round(w / scales), half
+      const float q0 = v[i] * rs;
+      const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, so, v[i]), rs, q0);
+      float t = rintf(round_h(q1));                         // :181 torch.round(w / scales), half
       t = fminf(fmaxf(t, qmin), qmax);
       q[i] = (int)t;
       dq[i] = (float)q[i] * s;                             // (q + 0) * s: a code of -0.0 de-quantises to +0.0
@@ -294,12 +300,14 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(WeightQuantParams p) 
     if (c < 1.0f) amax = round_h(amax * c);
     const float s = round_h(opaque(amax) / qmax);
     const float so = opaque(s);
+    const float rs = 1.0f / so;
     int q[4];
     v2u o;
     half_t *ov = reinterpret_cast<half_t *>(&o);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float t = rintf(round_h(v[k] / so));
+      const float q0 = v[k] * rs;
+      float t = rintf(round_h(__builtin_fmaf(__builtin_fmaf(-q0, so, v[k]), rs, q0)));
       t = fminf(fmaxf(t, qmin), qmax);
       q[k] = (int)t;
       ov[k] = f2h((float)q[k] * s);

@@ -1,0 +1,44 @@
+// Native bench of the fused activation-quant ops (HBM-bound): hipEvent timing, algorithmic GB/s.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#include <algorithm>
+#include <numeric>
+#include "../include/atom_hip.h"
+int main(int argc, char **argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 4096, H = argc > 2 ? atoi(argv[2]) : 4096, iters = argc > 3 ? atoi(argv[3]) : 200;
+  std::mt19937 rng(1);
+  std::vector<_Float16> hx((size_t)M * H), hw(H);
+  std::normal_distribution<float> nd(0, 1);
+  for (auto &v : hx) v = (_Float16)nd(rng);
+  for (auto &v : hw) v = (_Float16)(1.0f + 0.1f * nd(rng));
+  std::vector<int16_t> hidx(H); std::iota(hidx.begin(), hidx.end(), 0); std::shuffle(hidx.begin(), hidx.end(), rng);
+  void *x, *b, *w, *idx, *o8, *o4, *s8, *s4, *xq;
+  hipMalloc(&x, hx.size() * 2); hipMalloc(&b, hx.size() * 2); hipMalloc(&w, H * 2); hipMalloc(&idx, H * 2);
+  hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(b, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(w, hw.data(), H * 2, hipMemcpyHostToDevice); hipMemcpy(idx, hidx.data(), H * 2, hipMemcpyHostToDevice);
+  hipMalloc(&o8, (size_t)M * 128); hipMalloc(&o4, (size_t)M * (H - 128) / 2); hipMalloc(&s8, (size_t)M * 8 + 256); hipMalloc(&s4, (size_t)(H / 128) * (M * 8 + 256));
+  hipMalloc(&xq, hx.size() * 2);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const double out_bytes = (double)M * ((H - 128) / 2 + 128 + 2.0 * (H / 128));
+  for (int op = 0; op < 3; ++op) for (int mode = 0; mode < 2; ++mode) for (int dq = 0; dq < 2; ++dq) {
+    auto run = [&]() {
+      void *xo = dq ? xq : nullptr;
+      if (op == 0) return atom_reorder_quant_f16(x, (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      if (op == 1) return atom_rmsnorm_reorder_quant_f16(x, w, 1e-5f, (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      return atom_silu_mul_quant_f16(x, b, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+    };
+    for (int i = 0; i < 10; ++i) if (run()) { printf("error\n"); return 1; }
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) run();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    const double in_bytes = (double)M * H * 2 * (op == 2 ? 2 : 1);
+    const double bytes = in_bytes + out_bytes + (dq ? (double)M * H * 2 : 0);
+    printf("QRESULT op=%s mode=%s dequant_out=%d M=%d H=%d  %.2f us  %.0f GB/s algorithmic (%.1f MB)\n",
+           op == 0 ? "reorder" : op == 1 ? "rmsnorm" : "silu_mul", mode ? "sim" : "kernel", dq, M, H, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / 1e6);
+  }
+  return 0;
+}
