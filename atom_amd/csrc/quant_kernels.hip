@@ -47,7 +47,7 @@ __device__ __forceinline__ float round_half_away(float t) {
 // Quantise the 8 values this lane owns; the 16 lanes of a group cooperate on the absmax.
 // Returns codes in q[], the scale to store (as float, exact value of the stored half in SIM mode) and
 // the de-quantised values (float, to be rounded to half by the caller).
-template <bool SIM>
+template <bool SIM, bool DQ>
 __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, float clip, float &scale_store,
                                            int (&q)[8], float (&dq)[8]) {
   float amax = 0.f;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
 #pragma unroll
   for (int m = 1; m < 16; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
   const float qmax = keeper ? 127.f : 7.f;
-  const float qmin = keeper ? -128.f : -8.f;
+  const int qhi = keeper ? 127 : 7, qlo = keeper ? -128 : -8;
   const float c = keeper ? 1.0f : clip;
   if constexpr (SIM) {
     // quant.py:141-142: w.abs().amax().clamp(min=1e-5)  (the scalar is cast to half)
@@ -72,10 +72,11 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
     for (int i = 0; i < 8; ++i) {
       const float q0 = v[i] * rs;
       const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, so, v[i]), rs, q0);
-      float t = rintf(round_h(q1));                         // :181 torch.round(w / scales), half
-      t = fminf(fmaxf(t, qmin), qmax);
-      q[i] = (int)t;
-      dq[i] = (float)q[i] * s;                             // (q + 0) * s: a code of -0.0 de-quantises to +0.0
+      const float t = rintf(round_h(q1));                   // :181 torch.round(w / scales), half
+      // clamp in the integer domain (one v_med3_i32); |t| <= 65504/1e-6 fits int32 only after saturation, so
+      // saturate in float first when it could overflow (never for sane data; keeps the cast defined)
+      q[i] = min(max((int)fminf(fmaxf(t, -1e9f), 1e9f), qlo), qhi);
+      if constexpr (DQ) dq[i] = (float)q[i] * s;           // (q + 0) * s: a code of -0.0 de-quantises to +0.0
     }
     scale_store = s;
   } else {
@@ -87,16 +88,15 @@ __device__ __forceinline__ void quant_tail(const float (&v)[8], bool keeper, flo
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float t = round_half_away(v[i] * r);
-      t = fminf(fmaxf(t, qmin), qmax);
-      if (sf == 0.f) t = 0.f;
-      q[i] = (int)t;
-      dq[i] = (float)q[i] * sh;
+      if (!(sf != 0.f)) t = 0.f;                            // all-zero group: 0*inf = NaN in the reference; codes 0 here
+      q[i] = min(max((int)fminf(fmaxf(t, -1e9f), 1e9f), qlo), qhi);
+      if constexpr (DQ) dq[i] = (float)q[i] * sh;
     }
     scale_store = sf;
   }
 }
 
-template <int OP, bool SIM>
+template <int OP, bool SIM, bool DQ>
 __global__ __launch_bounds__(256) void act_quant_kernel(ActQuantParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t *row = reinterpret_cast<half_t *>(smem);           // H halves (unused for SILU_MUL)
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void act_quant_kernel(ActQuantParams p) {
     int q[8];
     float dq[8];
     float sc;
-    quant_tail<SIM>(v, keeper, p.clip, sc, q, dq);
+    quant_tail<SIM, DQ>(v, keeper, p.clip, sc, q, dq);
 
     if (keeper) {
       v2u w;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void act_quant_kernel(ActQuantParams p) {
         dst[r] = sh;
       }
     }
-    if (p.xq) {
+    if constexpr (DQ) {
       v4u o;
       half_t *ov = reinterpret_cast<half_t *>(&o);
 #pragma unroll
@@ -240,10 +240,14 @@ static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_
   dim3 grid((unsigned)p.M), block(256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define ATOM_LAUNCH(OPV)                                                                   \
-  if (p.sim)                                                                               \
-    hipLaunchKernelGGL((act_quant_kernel<OPV, true>), grid, block, lds, s, p);             \
+  if (p.sim && p.xq)                                                                       \
+    hipLaunchKernelGGL((act_quant_kernel<OPV, true, true>), grid, block, lds, s, p);       \
+  else if (p.sim)                                                                          \
+    hipLaunchKernelGGL((act_quant_kernel<OPV, true, false>), grid, block, lds, s, p);      \
+  else if (p.xq)                                                                           \
+    hipLaunchKernelGGL((act_quant_kernel<OPV, false, true>), grid, block, lds, s, p);      \
   else                                                                                     \
-    hipLaunchKernelGGL((act_quant_kernel<OPV, false>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((act_quant_kernel<OPV, false, false>), grid, block, lds, s, p);
   switch (op) {
     case OP_REORDER: ATOM_LAUNCH(OP_REORDER) break;
     case OP_RMSNORM: ATOM_LAUNCH(OP_RMSNORM) break;

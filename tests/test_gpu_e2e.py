@@ -1,0 +1,83 @@
+"""The reference's real-kernel call graph (punica LinearInt4 / LlamaRMSNormInt4 / LlamaMLP) on the HIP ops, checked op by
+op against the oracle's kernel-flavoured restatement, plus C-ABI misuse."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import atom_oracle as O
+from tests.helpers import t2n
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rmsnorm_mlp_chain_kernel_mode():
+    from atom_amd.e2e import LlamaMLP, LlamaRMSNormInt4
+    torch.manual_seed(0)
+    H, I, M = 512, 1408, 37
+    cfg = types.SimpleNamespace(hidden_size=H, intermediate_size=I)
+    norm = LlamaRMSNormInt4(H, eps=1e-5).cuda()
+    norm.weight.data = (1 + 0.1 * torch.randn(H)).half().cuda()
+    mlp = LlamaMLP(cfg).cuda()
+    Wg, Wu = (torch.randn(I, H) * 0.05).half().cuda(), (torch.randn(I, H) * 0.05).half().cuda()
+    Wd = (torch.randn(H, I) * 0.03).half().cuda()
+    mlp.gate_proj.load_fp16_weight(Wg); mlp.up_proj.load_fp16_weight(Wu); mlp.down_proj.load_fp16_weight(Wd)
+    x = (torch.randn(M, H) * 2).half().cuda()
+    y = mlp(norm(x))
+    assert y.shape == (M, H) and y.dtype == torch.float16
+
+    # oracle, stage by stage (each stage fed with the HIP output of the previous one: teacher forcing)
+    idx = t2n(norm.reorder_index)
+    a = O.rmsnorm_reorder_quant(t2n(x), t2n(norm.weight), 1e-5, idx, "kernel", 1.0)
+    o8, o4, s8, s4 = norm(x)
+    assert np.array_equal(O.unpack_int4(t2n(o4).view(np.uint8)), a["q4"]) and np.array_equal(t2n(o8), a["q8"])
+    wg, wu, wd = (O.quant_weight_sim(t2n(w), 0.85, 2) for w in (Wg, Wu, Wd))
+    gemm = lambda act, w: O.gemm_w4a4_exact(act["q4"], w["q4"], act["s4"], w["s4"], act["q8"], w["q8"], act["s8"], w["s8"])
+    g_hip, u_hip = mlp.gate_proj((o8, o4, s8, s4)), mlp.up_proj((o8, o4, s8, s4))
+    for got, want in ((g_hip, gemm(a, wg)), (u_hip, gemm(a, wu))):
+        assert np.abs(t2n(got).astype(np.float64) - want).max() <= 2e-3 * np.sqrt((want ** 2).mean()) + 1e-3 * np.abs(want).max()
+    b = O.silu_mul_quant(t2n(g_hip), t2n(u_hip), "kernel", 1.0)
+    act = __import__("atom_amd").ops.activate_fp16_i4(g_hip, u_hip)
+    d4 = np.abs(O.unpack_int4(t2n(act[1]).view(np.uint8)).astype(int) - b["q4"])
+    assert d4.max() <= 1 and (d4 > 0).mean() < 2e-3
+    # final GEMM from the HIP activation codes
+    bh = dict(q4=O.unpack_int4(t2n(act[1]).view(np.uint8)), q8=t2n(act[0]),
+              s4=O.scales_from_ref_layout(t2n(act[3]), M).T, s8=O.scales_from_ref_layout(t2n(act[2]), M))
+    want = gemm(bh, wd)
+    assert np.abs(t2n(y).astype(np.float64) - want).max() <= 2e-3 * np.sqrt((want ** 2).mean()) + 1e-3 * np.abs(want).max()
+
+
+def test_linear_int4_o4_output():
+    from atom_amd.e2e import LinearInt4
+    from atom_amd import ops
+    torch.manual_seed(1)
+    lin = LinearInt4(512, 256, out_dtype="int4").cuda().load_fp16_weight((torch.randn(256, 512) * 0.05).half().cuda())
+    x = torch.randn(20, 512).half().cuda()
+    q, sz = lin(ops.reorder_fp16_i4(x, torch.randperm(512).to(torch.int16).cuda()))
+    assert q.shape == (20, 128) and q.dtype == torch.uint8 and sz.shape == (20, 4)
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Validation happens before any launch and is reported as a status code, never as a fault."""
+    import ctypes
+    from atom_amd import _lib as L
+    lib = L.lib()
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = t.data_ptr()
+    ok_args = [p, p, p, p, p, p, p, p, p]
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 4, 64, 256, 128, 128, 1, None) == 0
+    assert lib.atom_gemm_w4a4_f16(None, *ok_args[1:], 4, 64, 256, 128, 128, 1, None) == -22        # null pointer
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 4, 64, 256, 64, 128, 1, None) == -33                   # group != 128
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 4, 64, 256, 128, 64, 1, None) == -33                   # keeper != 128
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 4, 64, 300, 128, 128, 1, None) == -33                  # K4 % 128 != 0
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 0, 64, 256, 128, 128, 1, None) == -33                  # M = 0
+    assert lib.atom_gemm_w4a4_f16(*ok_args, 4, 64, 256, 128, 128, 7, None) == -22                  # bad layout enum
+    assert lib.atom_gemm_w4a4_f16(p + 4, *ok_args[1:], 4, 64, 256, 128, 128, 1, None) == -14       # misaligned A4
+    assert lib.atom_gemm_w4a4_o4(*ok_args, p, 4, 64, 256, 128, 128, 1, None) == -33                # o4 needs N % 128 == 0
+    assert lib.atom_reorder_quant_f16(p, None, 4, 512, 5, 1.0, 1, p, p, p, p, None, None) == -22   # bad quant mode
+    assert lib.atom_reorder_quant_f16(p, None, 4, 32768, 0, 1.0, 1, p, p, p, p, None, None) == -33 # hidden too large
+    assert lib.atom_quant_weight_w4(p, 3, 256, 0.85, 2, p, p, p, p, None, None) == -33             # odd N
+    assert lib.atom_quant_weight_w4(p, 4, 256, 0.85, 3, p, p, p, p, None, None) == -22             # channel_group 3
+    assert lib.atom_strerror(-33).startswith(b"unsupported")
+    torch.cuda.synchronize()

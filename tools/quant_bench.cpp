@@ -9,12 +9,14 @@
 #include "../include/atom_hip.h"
 int main(int argc, char **argv) {
   int M = argc > 1 ? atoi(argv[1]) : 4096, H = argc > 2 ? atoi(argv[2]) : 4096, iters = argc > 3 ? atoi(argv[3]) : 200;
+  const bool noidx = argc > 4 && atoi(argv[4]) == 1;   // 1: identity order (no gather)
+  const bool seqidx = argc > 4 && atoi(argv[4]) == 2;  // 2: identity permutation passed as an index
   std::mt19937 rng(1);
   std::vector<_Float16> hx((size_t)M * H), hw(H);
   std::normal_distribution<float> nd(0, 1);
   for (auto &v : hx) v = (_Float16)nd(rng);
   for (auto &v : hw) v = (_Float16)(1.0f + 0.1f * nd(rng));
-  std::vector<int16_t> hidx(H); std::iota(hidx.begin(), hidx.end(), 0); std::shuffle(hidx.begin(), hidx.end(), rng);
+  std::vector<int16_t> hidx(H); std::iota(hidx.begin(), hidx.end(), 0); if (!seqidx) std::shuffle(hidx.begin(), hidx.end(), rng);
   void *x, *b, *w, *idx, *o8, *o4, *s8, *s4, *xq;
   hipMalloc(&x, hx.size() * 2); hipMalloc(&b, hx.size() * 2); hipMalloc(&w, H * 2); hipMalloc(&idx, H * 2);
   hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(b, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
@@ -26,7 +28,7 @@ int main(int argc, char **argv) {
   for (int op = 0; op < 3; ++op) for (int mode = 0; mode < 2; ++mode) for (int dq = 0; dq < 2; ++dq) {
     auto run = [&]() {
       void *xo = dq ? xq : nullptr;
-      if (op == 0) return atom_reorder_quant_f16(x, (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      if (op == 0) return atom_reorder_quant_f16(x, noidx ? nullptr : (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
       if (op == 1) return atom_rmsnorm_reorder_quant_f16(x, w, 1e-5f, (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
       return atom_silu_mul_quant_f16(x, b, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
     };
