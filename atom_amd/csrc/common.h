@@ -49,6 +49,8 @@ struct GemmParams {
   half_t *D;
   uint8_t *D4;      // o4 epilogue: packed u4 [M, N/2]
   half_t *Dsz;      // o4 epilogue: (scale, zero) [M, N/128, 2]
+  float *ws;        // split-K: FP32 partial sums [splits, M, N]
+  int splits;       // split-K factor (1 = none)
   int M, N;
   int K4h;          // packed bytes per row of A4/B4 = K4/2
   int G;            // int4 groups

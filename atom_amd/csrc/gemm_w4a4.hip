@@ -280,6 +280,12 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
                        const void *B8, const void *sA8, const void *sB8, int64_t M, int64_t N, int64_t K_total, int group,
                        int keeper, int scale_layout);
 
+// largest M served by the weight-streaming decode kernel (ATOM_GEMV_MAXM overrides it for tuning)
+static int gemv_max_m() {
+  static const int v = [] { const char *e = getenv("ATOM_GEMV_MAXM"); return e ? atoi(e) : 7; }();
+  return v;
+}
+
 extern "C" {
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }
@@ -329,7 +335,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       return launch_gemm_v3(p, variant - 300, hs);
     }
     default:                                                        // product path
-      if (M <= 16) {                                                // decode: weight-streaming dot-product kernel
+      if (M <= gemv_max_m()) {                                      // decode: weight-streaming dot-product kernel
         const int st = launch_gemv(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
       }
@@ -363,13 +369,49 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.sA = (const half_t *)sA;  p.sB = (const half_t *)sB;
   p.A8 = (const uint8_t *)A8; p.B8 = (const uint8_t *)B8;
   p.sA8 = (const half_t *)sA8; p.sB8 = (const half_t *)sB8;
-  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr;
+  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr; p.ws = nullptr; p.splits = 1;
   p.M = (int)M; p.N = (int)N;
   p.K4h = (int)((K_total - kKeeper) / 2);
   p.G = (int)((K_total - kKeeper) / kGroup);
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
   p.ldA = (int64_t)atom_scale_size(M, scale_layout);
   return ATOM_OK;
+}
+
+// Split-K policy: shapes that yield fewer than 256 workgroups of the smallest tile are latency-bound (one pass over K per
+// workgroup at ~1 us per K-group); split the K loop over up to 8 workgroups and reduce FP32 partials in a second launch.
+static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
+  if (M <= gemv_max_m()) return 1;                         // decode kernel
+  const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
+  const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
+  if (tiles >= 256 || nsteps < 8) return 1;
+  int64_t s = 512 / tiles;
+  if (s > 8) s = 8;
+  if (s > nsteps / 4) s = nsteps / 4;
+  return s < 2 ? 1 : (int)s;
+}
+
+size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
+  if (M < 1 || N < 64 || K_total < 256) return 0;
+  const int s = choose_splits(M, N, K_total);
+  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                          const void *sA8, const void *sB8, void *D, int64_t M, int64_t N, int64_t K_total, int group,
+                          int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream) {
+  const size_t need = atom_gemm_w4a4_workspace_bytes(M, N, K_total);
+  if (need == 0 || !workspace || workspace_bytes < need)
+    return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
+  if (!D) return ATOM_ERR_INVALID_ARG;
+  GemmParams p;
+  const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+  if (st != ATOM_OK) return st;
+  if (!aligned16(D) || !aligned16(workspace) || (N % 8) != 0) return ATOM_ERR_ALIGN;
+  p.D = (half_t *)D;
+  p.ws = (float *)workspace;
+  p.splits = choose_splits(M, N, K_total);
+  return launch_gemm_v3(p, 5, reinterpret_cast<hipStream_t>(stream));
 }
 
 int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,

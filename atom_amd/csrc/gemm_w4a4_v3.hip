@@ -175,7 +175,7 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   }
 }
 
-template <class C, bool TRACE = false>
+template <class C, bool TRACE = false, bool SK = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {   // <= 256 VGPRs: two waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
@@ -205,11 +205,15 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
 
-  const int nsteps = p.G + 2;
+  // split-K (SK): blockIdx.y owns the K steps [s_begin, s_end) and writes FP32 partial sums to p.ws
+  const int total_steps = p.G + 2;
+  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
+  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;   // == s_end
   StageAddr<C> sa_;
   make_stage_addr<C>(p, wave, lane, m0, n0, sa_);
 #pragma unroll
-  for (int s = 0; s < C::NS - 1; ++s) issue_stage<C>(p, min(s, nsteps - 1), lds + s * C::STAGE_BYTES, wave, sa_);
+  for (int s = 0; s < C::NS - 1; ++s)
+    issue_stage<C>(p, min(s_begin + s, nsteps - 1), lds + ((s_begin + s) % C::NS) * C::STAGE_BYTES, wave, sa_);
 
   // TRACE (tuning only): s_memtime stamps of block 0 into p.Dsz as u64[wave][step][4]
   unsigned long long *trace = reinterpret_cast<unsigned long long *>(p.Dsz);
@@ -227,14 +231,34 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
     if (tr) trace[(wave * 64 + step) * 4 + 3] = __builtin_amdgcn_s_memtime();                                        \
     compute_step<C, INT4>(lds + (step % C::NS) * C::STAGE_BYTES, wm, wn, lane, c);                                   \
   }
-  int step = 0;
-  for (; step < p.G; ++step) ATOM_V3_STEP(true)
+  int step = s_begin;
+  for (; step < min(p.G, nsteps); ++step) ATOM_V3_STEP(true)
   for (; step < nsteps; ++step) ATOM_V3_STEP(false)
 #undef ATOM_V3_STEP
   if (tr) trace[(wave * 64 + step) * 4 + 0] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  if constexpr (SK) {
+    // FP32 partial tile: lane owns token m and 4 consecutive features per (tile, q) -> one 16-byte store each
+    const int l31 = lane & 31, h = lane >> 5;
+    float *wsp = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * C::WM + tm * 32 + l31;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + tn * 32 + 8 * q + 4 * h;
+          if (n >= p.N) continue;
+          v4f o = {c[tn][tm][4 * q], c[tn][tm][4 * q + 1], c[tn][tm][4 * q + 2], c[tn][tm][4 * q + 3]};
+          *reinterpret_cast<v4f *>(wsp + (int64_t)m * p.N + n) = o;
+        }
+    }
+    return;
+  }
   constexpr int EP_STRIDE = 144;
   char *ep = lds + wave * (64 * EP_STRIDE);
   const int l31 = lane & 31, h = lane >> 5;
@@ -268,6 +292,43 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
 
 }  // namespace v3
 
+// D[m][n] = half( sum over splits, in split order, of the FP32 partials ): 8 features per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, half_t *D, int64_t MN, int splits) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= MN) return;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const v4f a = *reinterpret_cast<const v4f *>(ws + s * MN + i);
+    const v4f b = *reinterpret_cast<const v4f *>(ws + s * MN + i + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acc[k] += a[k]; acc[4 + k] += b[k]; }
+  }
+  v4u o;
+  half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ov[k] = f2h(acc[k]);
+  *reinterpret_cast<v4u *>(D + i) = o;
+}
+
+template <class C>
+static int launch_v3_splitk(const GemmParams &p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return ATOM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.splits), dim3(C::NT),
+                     C::LDS_BYTES, s, p);
+  const int64_t MN = (int64_t)p.M * p.N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.ws, p.D, MN, p.splits);
+  return check_launch();
+}
+
 template <class C, bool TRACE = false>
 static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
@@ -283,6 +344,9 @@ static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
 }
 
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
+  if (p.splits > 1 && p.ws) {
+    return cfg == 4 ? launch_v3_splitk<v3::Cfg<64, 64, 3, 2>>(p, s) : launch_v3_splitk<v3::Cfg<64, 128, 3, 2>>(p, s);
+  }
   switch (cfg) {
     case 1: return launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
     case 2: return launch_v3_cfg<v3::Cfg<128, 256, 3>>(p, s);   // 4 waves (1 x 4), two workgroups per CU

@@ -1,4 +1,4 @@
-// W4A4 GEMM, decode path (M <= 16) for gfx950: weight streaming, HBM-bound.
+// W4A4 GEMM, decode path (M <= 7; the kernel itself handles up to 16 rows) for gfx950: weight streaming, HBM-bound.
 //
 // BASELINE config 2 (M=1, N=K=4096): 8.9 MB of packed weights + scales must cross HBM once; the 256x256 MFMA tile
 // kernel would launch 16 workgroups on a 256-CU chip (55 us measured).  Here instead:

@@ -110,6 +110,18 @@ def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="k
     return _ret(*outs)
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Per-device scratch for split-K partial sums, grown on demand (same-stream reuse is ordered by the stream)."""
+    t = _WS.get(device)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[device] = t
+    return t
+
+
 def _gemm_dims(a, b, a_keeper):
     m = a.size(0)
     n = b.size(0)
@@ -127,11 +139,14 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
             raise L.AtomHipError("all GEMM operands must live on the GPU: no CPU fallback")
     m, n, k = _gemm_dims(a, b, a_keeper)
     d = torch.empty((m, n), dtype=torch.float16, device=a.device)
-    st = L.lib().atom_gemm_w4a4_f16(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
-                                     a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
-                                     b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
-                                     _LAYOUTS[scale_layout], L.current_stream(a.device))
-    L.check(st, "atom_gemm_w4a4_f16")
+    lib = L.lib()
+    ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k)     # > 0 only for skinny shapes that gain from split-K
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
+                                   a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
+                                   b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
+                                   _LAYOUTS[scale_layout], L.ptr(ws), ws_bytes, L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_f16_ws")
     return d
 
 

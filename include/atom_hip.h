@@ -72,6 +72,21 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
                        int group, int keeper, int scale_layout, void *stream);
 
 /*
+ * Same result, with an optional caller-owned scratch buffer that lets skinny shapes (16 < M, few output tiles) split
+ * the K loop over several workgroups: FP32 partial sums [splits, M, N] are written to `workspace` and reduced, in split
+ * order, by a second launch on the same stream.  atom_gemm_w4a4_workspace_bytes() returns the size that enables it
+ * (0 = the shape does not benefit; then, or with a NULL / too small workspace, this is atom_gemm_w4a4_f16).
+ * The reference has no counterpart (its 128x128 tile kernel runs every M, bench_dense_layer_gemm_i4_o16.cu:64-69).
+ * FP32 summation order differs from the unsplit kernel (per-split partial sums, then their sum): same tolerance.
+ */
+size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total);
+int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB,
+                          const void *A8, const void *B8, const void *sA8, const void *sB8,
+                          void *D, int64_t M, int64_t N, int64_t K_total,
+                          int group, int keeper, int scale_layout,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Same GEMM; epilogue asymmetric-quantises every 128-wide output group to u4:
  *   scale = (max-min)/15, zero = -min, q = round((x+zero)/scale) & 0xF
  * D_u4 uint8 [M, N/2] (same nibble order), D_scale_zero fp16 [M, N/128, 2] = (scale, zero).

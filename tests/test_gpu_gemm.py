@@ -168,3 +168,24 @@ def test_gemm_o4_epilogue(M, N, K):
     deq = codes.reshape(M, N // 128, 128) * s[..., 0:1] - s[..., 1:2]
     ref = t2n(ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")).astype(np.float32).reshape(M, N // 128, 128)
     assert np.abs(deq - ref).max() <= 0.51 * s[..., 0].max() + 0.1
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (17, 1408, 2176), (64, 5120, 5120), (100, 256, 4096), (256, 5120, 1152)])
+def test_gemm_split_k_path(M, N, K):
+    """Skinny shapes go through atom_gemm_w4a4_f16_ws (split-K over FP32 partials + reduce launch) when the policy
+    grants a workspace; same tolerance as the unsplit kernels, and the plain entry point agrees to fp16 rounding."""
+    from atom_amd import _lib as L
+    ops = _ops()
+    lib = L.lib()
+    d = rand_gemm_operands(M, N, K, seed=M * 3 + K)
+    dev = to_device(d, "plain")
+    out = ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")            # uses the workspace variant
+    assert_gemm_close(t2n(out), gemm_ref_torch_f64(d).cpu().numpy(), f"split-K {M}x{N}x{K}")
+    plain = torch.empty_like(out)
+    st = lib.atom_gemm_w4a4_f16(*[t.data_ptr() for t in dev], plain.data_ptr(), M, N, K, 128, 128, 1,
+                                torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    a, b = t2n(out).astype(np.float64), t2n(plain).astype(np.float64)
+    assert (np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-3 * np.sqrt((b ** 2).mean())).all()    # different FP32 summation order
+    if lib.atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+        assert np.array_equal(bits16(t2n(out)), bits16(t2n(plain)))

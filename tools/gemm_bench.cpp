@@ -57,6 +57,10 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&D, (size_t)M * N * 2));
   CK(hipMemset(D, 0xFF, (size_t)M * N * 2));
 
+  size_t wsb = getenv("ATOM_WS") ? atom_gemm_w4a4_workspace_bytes(M, N, K) : 0;
+  void *ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
+  printf("workspace bytes %zu\n", wsb);
+#define atom_gemm_w4a4_f16(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p) atom_gemm_w4a4_f16_ws(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, ws, wsb, p)
   int st = atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, ATOM_SCALE_LAYOUT_PLAIN, nullptr);
   if (st) { printf("atom_gemm_w4a4_f16: %s\n", atom_strerror(st)); return 1; }
   CK(hipDeviceSynchronize());
