@@ -153,8 +153,7 @@ class QLlamaAttention(nn.Module):
         self.max_position_embeddings = _cfg(originalAttn, "max_position_embeddings")
         self.rope_theta = _cfg(originalAttn, "rope_theta")
         if self.head_dim * self.num_heads != self.hidden_size:
-            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
-                             f" and `num_heads`: {self.num_heads}).")
+            raise ValueError(f"hidden_size {self.hidden_size} is not a multiple of num_heads {self.num_heads}")
         self.q_proj = QLinearLayer(originalAttn.q_proj, args)
         self.k_proj = QLinearLayer(originalAttn.k_proj, args)
         self.v_proj = QLinearLayer(originalAttn.v_proj, args)
@@ -205,21 +204,18 @@ class QLlamaAttention(nn.Module):
         v = repeat_kv(v, self.num_key_value_groups)
 
         attn_weights = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.head_dim)
-        if attn_weights.size() != (bsz, self.num_heads, q_len, kv_seq_len):
-            raise ValueError(f"Attention weights should be of size {(bsz * self.num_heads, q_len, kv_seq_len)}, but is"
-                             f" {attn_weights.size()}")
+        if tuple(attn_weights.shape) != (bsz, self.num_heads, q_len, kv_seq_len):
+            raise ValueError(f"score tensor has shape {tuple(attn_weights.shape)}, expected "
+                             f"{(bsz, self.num_heads, q_len, kv_seq_len)}")
         if attention_mask is not None:
-            if attention_mask.size() != (bsz, 1, q_len, kv_seq_len):
-                raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, "
-                                 f"but is {attention_mask.size()}")
+            if tuple(attention_mask.shape) != (bsz, 1, q_len, kv_seq_len):
+                raise ValueError(f"mask has shape {tuple(attention_mask.shape)}, expected {(bsz, 1, q_len, kv_seq_len)}")
             attn_weights = attn_weights + attention_mask
         attn_weights = nn.functional.softmax(attn_weights, dim=-1, dtype=torch.float32).to(q.dtype)
         if self.q_kv_cache:
             v = self.v_quant(v)
         attn_output = torch.matmul(attn_weights, v)
-        if attn_output.size() != (bsz, self.num_heads, q_len, self.head_dim):
-            raise ValueError(f"`attn_output` should be of size {(bsz, self.num_heads, q_len, self.head_dim)}, but is"
-                             f" {attn_output.size()}")
+        assert tuple(attn_output.shape) == (bsz, self.num_heads, q_len, self.head_dim)
         attn_output = attn_output.transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
 
         # gather (reorder_index) + quantise the context for o_proj: one HIP kernel in the hot configuration
