@@ -102,12 +102,34 @@ __device__ __forceinline__ void widen(const v4u p, v4i &lo, v4i &hi) {
   hi = __builtin_bit_cast(v4i, h);
 }
 
+// Loop-invariant per-lane byte offsets inside a stage.  Every LDS address of the K loop is then
+//   stage base (one v_add per step)  +  one of these VGPRs  +  a compile-time immediate (tile * 2048, region offsets),
+// instead of ~20 v_add_u32 per step: with a VALU instruction costing the SIMD 4 cycles that is 4 % of the kernel.
+struct LaneOff {
+  int w0, w1;     // weight rows:      (wn*64 + l31)*64 + swizzled chunk (0+h) / (2+h)
+  int a0, a1;     // activation rows:  (BN + wm*WM + l31)*64 + swizzled chunk
+  int sa;         // activation scale: SA_OFF + (wm*WM + l31)*4
+  int sb;         // weight scales:    SB_OFF + (wn*64 + 4h)*2
+};
+
+template <class C>
+__device__ __forceinline__ LaneOff make_lane_off(int wm, int wn, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int sw = (l31 >> 2) & 3;                 // tile offsets are multiples of 32 rows: they do not touch bits 2,3
+  LaneOff o;
+  o.w0 = (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4);
+  o.w1 = (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
+  o.a0 = (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4);
+  o.a1 = (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
+  o.sa = C::SA_OFF + (wm * C::WM + l31) * 4;
+  o.sb = C::SB_OFF + (wn * 64 + 4 * h) * 2;
+  return o;
+}
+
 template <bool INT4>
-__device__ __forceinline__ void load_frag(const char *slot, int row, int h, v4i (&f)[4]) {
-  const int sw = (row >> 2) & 3;
-  const char *rb = slot + row * 64;
-  const v4u c0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
-  const v4u c1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
+__device__ __forceinline__ void load_frag(const char *p0, const char *p1, v4i (&f)[4]) {
+  const v4u c0 = *reinterpret_cast<const v4u *>(p0);
+  const v4u c1 = *reinterpret_cast<const v4u *>(p1);
   if constexpr (INT4) {
     widen(c0, f[0], f[1]);
     widen(c1, f[2], f[3]);
@@ -118,26 +140,24 @@ __device__ __forceinline__ void load_frag(const char *slot, int row, int h, v4i 
 }
 
 template <class C, bool INT4>
-__device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+__device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo, float (&c)[TN][C::TM][16]) {
   constexpr int TM = C::TM;
   constexpr int KS = INT4 ? 4 : 2;
-  const int l31 = lane & 31, h = lane >> 5;
+  const char *pw0 = slot + lo.w0, *pw1 = slot + lo.w1, *pa0 = slot + lo.a0, *pa1 = slot + lo.a1;
+  const char *psa = slot + lo.sa, *psb = slot + lo.sb;
   v16i magic;
 #pragma unroll
   for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
   v4i af[TN][4];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) load_frag<INT4>(slot, wn * 64 + tn * 32 + l31, h, af[tn]);
+  for (int tn = 0; tn < TN; ++tn) load_frag<INT4>(pw0 + tn * 2048, pw1 + tn * 2048, af[tn]);
 
   v4u pk0, pk1;
   half_t sah;
   auto request = [&](int tm) {
-    const int row = C::BN + wm * C::WM + tm * 32 + l31;
-    const int sw = (row >> 2) & 3;
-    const char *rb = slot + row * 64;
-    pk0 = *reinterpret_cast<const v4u *>(rb + (((0 + h) ^ sw) << 4));
-    pk1 = *reinterpret_cast<const v4u *>(rb + (((2 + h) ^ sw) << 4));
-    sah = *reinterpret_cast<const half_t *>(slot + C::SA_OFF + (wm * C::WM + tm * 32 + l31) * 4);
+    pk0 = *reinterpret_cast<const v4u *>(pa0 + tm * 2048);
+    pk1 = *reinterpret_cast<const v4u *>(pa1 + tm * 2048);
+    sah = *reinterpret_cast<const half_t *>(psa + tm * 128);
   };
   request(0);
 #pragma unroll
@@ -163,7 +183,7 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
       v2u sbp[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        sbp[q] = *reinterpret_cast<const v2u *>(slot + C::SB_OFF + (wn * 64 + tn * 32 + 8 * q + 4 * h) * 2);
+        sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
   const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;   // == s_end
   StageAddr<C> sa_;
   make_stage_addr<C>(p, wave, lane, m0, n0, sa_);
+  const LaneOff lo_ = make_lane_off<C>(wm, wn, lane);
 #pragma unroll
   for (int s = 0; s < C::NS - 1; ++s)
     issue_stage<C>(p, min(s_begin + s, nsteps - 1), lds + ((s_begin + s) % C::NS) * C::STAGE_BYTES, wave, sa_);
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
                    sa_);                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     if (tr) trace[(wave * 64 + step) * 4 + 3] = __builtin_amdgcn_s_memtime();                                        \
-    compute_step<C, INT4>(lds + (step % C::NS) * C::STAGE_BYTES, wm, wn, lane, c);                                   \
+    compute_step<C, INT4>(lds + (step % C::NS) * C::STAGE_BYTES, lo_, c);                                            \
   }
   int step = s_begin;
   for (; step < min(p.G, nsteps); ++step) ATOM_V3_STEP(true)
