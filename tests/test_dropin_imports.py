@@ -1,0 +1,49 @@
+"""Drop-in check at import level (build container only: needs /root/reference): the reference's own callers
+(gptq.py, outlier.py, modelutils_llama.py) import `quant` / `qLinearLayer` / `qLlamaLayer` as top-level modules; with
+atom_amd/dropin first on sys.path they get OUR classes.  No compute (CPU)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/model"
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+def test_reference_callers_resolve_to_our_modules(tmp_path):
+    # stubs for modules that are NOT ours and fail to import for unrelated reasons: bitsandbytes (not installed) and
+    # the reference's qMixtralLayer (needs transformers 4.39's MixtralBlockSparseTop2MLP)
+    (tmp_path / "bitsandbytes").mkdir()
+    (tmp_path / "bitsandbytes" / "__init__.py").write_text("")
+    (tmp_path / "bitsandbytes" / "functional.py").write_text("def quantize_fp4(*a, **k): raise NotImplementedError\n"
+                                                             "def dequantize_fp4(*a, **k): raise NotImplementedError\n")
+    (tmp_path / "qMixtralLayer.py").write_text("class QMixtralDecoderLayer: pass\n")
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(os.path.join(ROOT, 'atom_amd', 'dropin'))!r}, {ROOT!r}, {str(tmp_path)!r}]
+        sys.path.append({REF!r})
+        import quant, qLinearLayer, qLlamaLayer
+        assert quant.__file__.startswith({ROOT!r}) and qLlamaLayer.__file__.startswith({ROOT!r})
+        import gptq, outlier, modelutils_llama
+        import atom_amd.model.qLinearLayer as ours
+        assert gptq.QLinearLayer is ours.QLinearLayer and outlier.QLinearLayer is ours.QLinearLayer
+        assert modelutils_llama.QLlamaDecoderLayer.__module__ == 'atom_amd.model.qLlamaLayer'
+        assert modelutils_llama.find_qlinear_layers is ours.find_qlinear_layers
+        from functools import partial
+        import types, torch
+        args = types.SimpleNamespace(abits=4, static=False)
+        q = quant.Quantizer(args)
+        q.configure(partial(modelutils_llama.quantize_activation_wrapper, args=args), None)
+        assert q.act_quant.func is quant.quantize_activation_wrapper
+        # the same exact-type registry walk the reference does (qLinearLayer.py:5-14) finds our layers
+        lin = ours.QLinearLayer(torch.nn.Linear(256, 64, bias=False).half(), types.SimpleNamespace(wbits=4))
+        box = torch.nn.Sequential(lin)
+        assert list(modelutils_llama.find_qlinear_layers(box).values()) == [lin]
+        print("DROPIN_OK")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert "DROPIN_OK" in out.stdout, out.stderr[-3000:]
