@@ -329,6 +329,130 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(WeightQuantParams p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pack an ALREADY fake-quantised weight: recover (codes, fp16 scale) per (channel_group rows x 128 columns) block of
+// a weight whose values are half(s*c), c in [-8,7] (INT4 part) / [-128,127] (last 128 columns, one scale per row).
+// This is what GPTQ leaves behind: gptq.py:38-39 computes q = scale*(clamp(round(x/scale)+zero,0,maxq)-zero) with an
+// FP32 scale found on the error-compensated weight (gptq.py:285-287) and stores half(q) (gptq.py:331); the scale
+// itself is thrown away.  Same wave geometry as weight_quant_kernel.  Per block:
+//   for k = kmax..1 (the code magnitude of the largest |v|):  s = amax/k, c_i = rint(v_i/s); accept k when every c_i
+//   is in range and |c_i*s - v_i| <= tol(v_i) = 2^-9|v_i| + 2^-24 (half(s32*c) carries 2^-11 relative rounding, so
+//   does amax); refine s by least squares (sum v c / sum c^2), try the 5 fp16 values around it and keep the
+//   (k, s) whose half(c*s) reproduces v best -- stopping at the first EXACT reproduction (always exists for weights
+//   written by QLinearLayer.quant, whose scale is fp16).  A block with no acceptable k is re-quantised round-to-nearest
+//   and counted in *bad.  Offline path; not tuned.
+struct WeightPackParams {
+  const half_t *W;
+  int64_t N;
+  int K;
+  int cg;
+  uint8_t *B4;
+  int8_t *B8;
+  half_t *sB;
+  half_t *sB8;
+  int *bad;
+};
+
+__global__ __launch_bounds__(256) void weight_pack_kernel(WeightPackParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t pair = blockIdx.x;
+  const int K = p.K;
+  const int K4 = K - kKeeper;
+  const int G = K4 >> 7;
+  const int64_t n = pair * 2 + (lane >> 5);
+  const int c0 = (lane & 31) * 4;
+  for (int g = wave; g <= G; g += 4) {
+    const bool keeper = (g == G);
+    const bool whole = !keeper && p.cg == 2;              // the unit is the whole wave (two rows), else one 32-lane half
+    const half_t *src = p.W + n * (int64_t)K + g * kGroup + c0;
+    v2u raw = *reinterpret_cast<const v2u *>(src);
+    const half_t *hv = reinterpret_cast<const half_t *>(&raw);
+    float v[4], tol[4];
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = (float)hv[k];
+      amax = fmaxf(amax, fabsf(v[k]));
+      tol[k] = fabsf(v[k]) * 0x1p-9f + 0x1p-24f;
+    }
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+    if (whole) amax = fmaxf(amax, __shfl_xor(amax, 32));
+    const unsigned long long umask = whole ? ~0ull : (lane < 32 ? 0xFFFFFFFFull : 0xFFFFFFFF00000000ull);
+    const float qmax = keeper ? 127.f : 7.f, qmin = keeper ? -128.f : -8.f;
+    const int kmax = keeper ? 128 : 8;
+
+    int best_q[4] = {0, 0, 0, 0};
+    float best_s = 0.f, best_err = 3.0e38f;               // err: max_i |half(c*s)-v| / tol_i ; 0 = exact
+    bool done = (amax == 0.f);                            // all-zero block: codes 0, scale 0
+    if (done) best_err = 0.f;
+    for (int k = kmax; k >= 1; --k) {
+      if (__ballot(!done) == 0ull) break;                 // both units finished
+      const float s = amax / (float)k;
+      int q[4];
+      bool ok = !done;
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = rintf(v[i] / s);
+        ok = ok && t >= qmin && t <= qmax && fabsf(t * s - v[i]) <= tol[i];
+        q[i] = (int)fminf(fmaxf(t, qmin), qmax);
+        num += v[i] * (float)q[i];
+        den += (float)(q[i] * q[i]);
+      }
+      const bool unit_ok = !done && ((__ballot(!ok) & umask) == 0ull);
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) {
+        num += __shfl_xor(num, m);
+        den += __shfl_xor(den, m);
+      }
+      if (whole) {
+        num += __shfl_xor(num, 32);
+        den += __shfl_xor(den, 32);
+      }
+      const half_t sh0 = (half_t)(den > 0.f ? num / den : s);
+      const unsigned short b0 = __builtin_bit_cast(unsigned short, sh0);
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const int off = d == 0 ? 0 : (d & 1 ? -((d + 1) >> 1) : (d >> 1));     // 0,-1,+1,-2,+2 ulp
+        const unsigned short bits = (unsigned short)((int)b0 + off);
+        const float sc = (float)__builtin_bit_cast(half_t, bits);
+        float e = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e = fmaxf(e, fabsf(round_h((float)q[i] * sc) - v[i]) / tol[i]);
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) e = fmaxf(e, __shfl_xor(e, m));
+        if (whole) e = fmaxf(e, __shfl_xor(e, 32));
+        if (!(sc > 0.f) || !(sc < 65504.f)) e = 3.0e38f;
+        if (unit_ok && e < best_err) {
+          best_err = e;
+          best_s = sc;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) best_q[i] = q[i];
+        }
+      }
+      if (unit_ok && best_err == 0.f) done = true;
+    }
+    if (best_err > 1.0f) {                                // not on any 16/256-level grid: plain round-to-nearest
+      if ((lane & 31) == 0 && (whole ? lane == 0 : true) && p.bad) atomicAdd(p.bad, 1);
+      best_s = round_h(fmaxf(amax, 1e-5f) / qmax);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) best_q[i] = (int)fminf(fmaxf(rintf(v[i] / best_s), qmin), qmax);
+    }
+    const int *q = best_q;
+    if (keeper) {
+      const unsigned w = (q[0] & 0xFF) | ((q[1] & 0xFF) << 8) | ((q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);
+      *reinterpret_cast<unsigned *>(p.B8 + n * kKeeper + c0) = w;
+      if ((lane & 31) == 0) p.sB8[n] = (half_t)best_s;
+    } else {
+      const unsigned short w = (unsigned short)((q[0] & 0xF) | ((q[1] & 0xF) << 4) | ((q[2] & 0xF) << 8) | ((q[3] & 0xF) << 12));
+      *reinterpret_cast<unsigned short *>(p.B4 + n * (int64_t)(K4 >> 1) + g * 64 + (c0 >> 1)) = w;
+      if ((lane & 31) == 0) p.sB[(int64_t)g * p.N + n] = (half_t)best_s;
+    }
+  }
+}
+
 }  // namespace atom
 
 using namespace atom;
@@ -382,6 +506,20 @@ int atom_quant_weight_w4(const void *W_f16, int64_t N, int64_t K_total, float w_
                       (int8_t *)B8,          (half_t *)sB, (half_t *)sB8, (half_t *)Wq_f16};
   hipLaunchKernelGGL(weight_quant_kernel, dim3((unsigned)(N / 2)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+int atom_pack_weight_w4(const void *Wq_f16, int64_t N, int64_t K_total, int channel_group, void *B4, void *B8,
+                        void *sB, void *sB8, int32_t *bad_blocks, void *stream) {
+  if (!Wq_f16 || !B4 || !B8 || !sB || !sB8) return ATOM_ERR_INVALID_ARG;
+  if (channel_group != 1 && channel_group != 2) return ATOM_ERR_INVALID_ARG;
+  if (N < 2 || (N % 2) != 0 || K_total < 256 || (K_total % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if (!aligned16(Wq_f16) || !aligned16(B4) || !aligned16(B8)) return ATOM_ERR_ALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (bad_blocks && hipMemsetAsync(bad_blocks, 0, sizeof(int32_t), s) != hipSuccess) return ATOM_ERR_LAUNCH;
+  WeightPackParams p{(const half_t *)Wq_f16, N, (int)K_total, channel_group, (uint8_t *)B4,
+                     (int8_t *)B8,           (half_t *)sB, (half_t *)sB8, (int *)bad_blocks};
+  hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)(N / 2)), dim3(256), 0, s, p);
   return check_launch();
 }
 

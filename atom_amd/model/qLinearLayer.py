@@ -7,7 +7,8 @@ packed INT4/INT8 form the W4A4 GEMM consumes (the bridge the reference lacks, SU
     quant()    ->  atom_quant_weight_w4: one HIP kernel writes B4 / B8 / sB / sB8 and the fake-quant fp16 weight
     forward(x) ->  atom_gemm_w4a4_f16 when x carries activation codes (quant.ActCodes) and the packed weight is
                    current; ``F.linear`` (the reference's own forward, qLinearLayer.py:32-35) otherwise, e.g. for
-                   16-bit configurations or a weight rewritten after packing.
+                   16-bit configurations or a weight that is not (yet) quantised.
+    GPTQ       ->  atom_pack_weight_w4 on the first forward after ``layer.weight.data = Q`` (codes/scales recovered).
 """
 from __future__ import annotations
 
@@ -50,6 +51,7 @@ class QLinearLayer(nn.Module):
             self.bias = None
         self._packed = None          # (B4, B8, sB, sB8)
         self._packed_key = None      # identity of the fp16 weight the packed form was made from
+        self._unpackable_key = None  # identity of a weight that pack_weight_w4 found to be off the grid
 
     # ------------------------------------------------------------------------------------------------ forward
     def _weight_key(self):
@@ -57,9 +59,26 @@ class QLinearLayer(nn.Module):
         return (w.data_ptr(), w._version, tuple(w.shape), w.device)
 
     def packed_weight(self):
-        """Packed operands if they are current for ``self.weight``, else None."""
-        if self._packed is not None and self._packed_key == self._weight_key():
+        """Packed operands if they are current for ``self.weight``, else None.  A weight that was rewritten since the
+        last packing (GPTQ: ``layer.weight.data = Q``, gptq.py:331 -- ``quant()`` is never called on that path,
+        modelutils_llama.py:224-258) is packed lazily, once per weight version, by recovering its codes and scales
+        (atom_pack_weight_w4); a weight that is not on the INT4-g128 / INT8 grid (e.g. still unquantised while GPTQ
+        collects its Hessian) is remembered as such and served by ``F.linear``."""
+        key = self._weight_key()
+        if self._packed is not None and self._packed_key == key:
             return self._packed
+        if self._unpackable_key == key:
+            return None
+        a = self.args
+        n, k = self.weight.shape
+        if (self.enable_quant and self.weight.is_cuda and self.weight.dtype == torch.float16
+                and self.weight.is_contiguous() and _is_hot_weight_config(a, n, k)):
+            b4, b8, sb, sb8, bad = _ops.pack_weight_w4(self.weight, int(a.weight_channel_group), strict=False)
+            if bad == 0:
+                self._packed = (b4, b8, sb, sb8)
+                self._packed_key = key
+                return self._packed
+        self._unpackable_key = key
         return None
 
     @torch.no_grad()

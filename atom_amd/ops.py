@@ -183,3 +183,26 @@ def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: i
                                        L.current_stream(dev))
     L.check(st, "atom_quant_weight_w4")
     return (b4, b8, sb, sb8, wq) if return_fake_quant else (b4, b8, sb, sb8)
+
+
+def pack_weight_w4(weight_fq: torch.Tensor, channel_group: int = 2, strict: bool = True):
+    """NEW: pack an ALREADY fake-quantised FP16 weight [N,K] -- the tensor GPTQ assigns to
+    ``layer.weight.data`` (gptq.py:331) or ``QLinearLayer.quant`` leaves behind -- by recovering codes and fp16 scales.
+    Returns (B4, B8, sB, sB8, bad) with ``bad`` = number of (channel_group x 128) blocks that are on no INT4/INT8 grid;
+    ``strict`` raises when bad != 0 (costs one device->host sync; this is an offline op)."""
+    _require_cuda_half(weight_fq, "weight_fq")
+    n, k = weight_fq.shape
+    dev = weight_fq.device
+    w = weight_fq.contiguous()
+    b4 = torch.empty((n, (k - GROUP_SIZE) // 2), dtype=torch.uint8, device=dev)
+    b8 = torch.empty((n, GROUP_SIZE), dtype=torch.int8, device=dev)
+    sb = torch.empty(((k - GROUP_SIZE) // GROUP_SIZE, n), dtype=torch.float16, device=dev)
+    sb8 = torch.empty((n,), dtype=torch.float16, device=dev)
+    bad = torch.empty((1,), dtype=torch.int32, device=dev)
+    st = L.lib().atom_pack_weight_w4(w.data_ptr(), n, k, int(channel_group), b4.data_ptr(), b8.data_ptr(),
+                                      sb.data_ptr(), sb8.data_ptr(), bad.data_ptr(), L.current_stream(dev))
+    L.check(st, "atom_pack_weight_w4")
+    nbad = int(bad.item())
+    if strict and nbad:
+        raise L.AtomHipError(f"pack_weight_w4: {nbad} weight blocks are not INT4-g128/INT8 fake-quantised values")
+    return b4, b8, sb, sb8, nbad

@@ -147,6 +147,20 @@ int atom_quant_weight_w4(const void *W_f16, int64_t N, int64_t K_total, float w_
                          int channel_group, void *B4, void *B8, void *sB, void *sB8, void *Wq_f16,
                          void *stream);
 
+/*
+ * NEW (the bridge for GPTQ-written weights): pack a weight that is ALREADY fake-quantised -- every
+ * value half(s*c) with c in [-8,7] sharing s per (`channel_group` rows x 128 columns), last 128 columns c in
+ * [-128,127] with one s per row -- by recovering (c, s).  This is what GPTQ leaves in `layer.weight.data`
+ * (model/gptq.py:38-39 quantises with an FP32 scale found on the error-compensated weight, :285-287, stores half(q),
+ * :331, and discards the scale) and also what QLinearLayer.quant leaves (model/qLinearLayer.py:42-78; reproduced
+ * exactly, the scale there is fp16).  For FP32-scale weights sB is the fp16 value that reproduces Wq best:
+ * |c*sB - Wq| <= 2^-9 |Wq| + 2^-24 per element.  Outputs as atom_quant_weight_w4.  `bad_blocks` (device int32, may be
+ * NULL) receives the number of blocks that are on no such grid; those are re-quantised round-to-nearest (the caller
+ * decides whether that is an error -- the Python mirror raises).
+ */
+int atom_pack_weight_w4(const void *Wq_f16, int64_t N, int64_t K_total, int channel_group,
+                        void *B4, void *B8, void *sB, void *sB8, int32_t *bad_blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

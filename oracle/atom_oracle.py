@@ -292,6 +292,86 @@ def quant_weight_sim(W16: np.ndarray, w_clip: float = 0.85, channel_group: int =
     return dict(q4=q4, s4=s4, q8=q8, s8=s8, wq=wq)
 
 
+def gptq_codes(q16: np.ndarray, s32: np.ndarray, n_bits: int, channel_group: int):
+    """Codes the reference GPTQ wrote: quantize_gptq (gptq.py:38-39) computes ``scale*(clamp(round(x/scale)+zero,0,maxq)
+    -zero)`` in FP32 with zero=(maxq+1)/2 (sym, gptq.py:139-140); the stored weight is half() of that (gptq.py:331), so
+    code = round(float(q16)/scale).  ``q16`` [N,128] one group, ``s32`` [N/channel_group] the scale find_params produced
+    for it (gptq.py:285-287)."""
+    N = q16.shape[0]
+    sc = np.repeat(np.asarray(s32, dtype=np.float32).reshape(-1), channel_group).reshape(N, 1)
+    c = np.rint(q16.astype(np.float32) / sc)
+    lo, hi = -(1 << (n_bits - 1)), (1 << (n_bits - 1)) - 1
+    assert c.min() >= lo and c.max() <= hi
+    return c.astype(np.int8)
+
+
+def _recover_blocks(v: np.ndarray, n_bits: int):
+    """Recover (codes, fp16 scale) of blocks whose values are half(s*c) -- CPU restatement of weight_pack_kernel
+    (atom_amd/csrc/quant_kernels.hip), the packer for what gptq.py:331 / qLinearLayer.py:42-78 leave in ``weight``.
+    v [B, L] float32 (exact fp16 values).  Returns codes int8 [B,L], scale f16 [B], bad bool [B]."""
+    v = np.asarray(v, dtype=np.float32)
+    B, L = v.shape
+    qmax, qmin = float((1 << (n_bits - 1)) - 1), float(-(1 << (n_bits - 1)))
+    kmax = 1 << (n_bits - 1)
+    tol = np.abs(v) * np.float32(2.0 ** -9) + np.float32(2.0 ** -24)
+    amax = np.abs(v).max(axis=1)
+    best_err = np.full(B, np.inf, dtype=np.float32)
+    best_s = np.zeros(B, dtype=np.float32)
+    best_q = np.zeros((B, L), dtype=np.float32)
+    done = amax == 0
+    best_err[done] = 0
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for k in range(kmax, 0, -1):
+            live = ~done
+            if not live.any():
+                break
+            s = (amax / np.float32(k)).astype(np.float32)[:, None]
+            t = np.rint(v / s)
+            ok = live & np.all((t >= qmin) & (t <= qmax) & (np.abs(t * s - v) <= tol), axis=1)
+            if not ok.any():
+                continue
+            q = np.clip(t, qmin, qmax)
+            den = (q * q).sum(axis=1, dtype=np.float32)
+            num = (v * q).sum(axis=1, dtype=np.float32)
+            s0 = np.where(den > 0, num / np.where(den > 0, den, 1), s[:, 0]).astype(f16)
+            bits0 = s0.view(np.uint16).astype(np.int32)
+            for off in (0, -1, 1, -2, 2):
+                sc = (bits0 + off).astype(np.uint16).view(f16).astype(np.float32)
+                e = (np.abs((q * sc[:, None]).astype(f16).astype(np.float32) - v) / tol).max(axis=1)
+                e = np.where((sc > 0) & (sc < 65504), e, np.inf).astype(np.float32)
+                upd = ok & (e < best_err)
+                best_err[upd] = e[upd]
+                best_s[upd] = sc[upd]
+                best_q[upd] = q[upd]
+            done = done | (ok & (best_err == 0))
+    bad = best_err > 1
+    if bad.any():
+        sb = (np.maximum(amax[bad], np.float32(1e-5)) / np.float32(qmax)).astype(f16).astype(np.float32)
+        best_s[bad] = sb
+        best_q[bad] = np.clip(np.rint(v[bad] / sb[:, None]), qmin, qmax)
+    return best_q.astype(np.int8), best_s.astype(f16), bad
+
+
+def pack_weight_fq(Wq16: np.ndarray, channel_group: int = 2):
+    """atom_pack_weight_w4 on the CPU: same outputs as quant_weight_sim (minus wq) + ``bad`` = number of blocks on no grid."""
+    Wq16 = np.asarray(Wq16, dtype=f16)
+    N, K = Wq16.shape
+    K4 = K - KEEPER
+    G = K4 // GROUP
+    cg = channel_group
+    q8, s8, bad8 = _recover_blocks(Wq16[:, K4:].astype(np.float32), 8)
+    q4 = np.empty((N, K4), dtype=np.int8)
+    s4 = np.empty((G, N), dtype=f16)
+    nbad = int(bad8.sum())
+    for g in range(G):
+        blk = Wq16[:, g * GROUP:(g + 1) * GROUP].astype(np.float32).reshape(N // cg, cg * GROUP)
+        q, s, b = _recover_blocks(blk, 4)
+        q4[:, g * GROUP:(g + 1) * GROUP] = q.reshape(N, GROUP)
+        s4[g] = np.repeat(s, cg)
+        nbad += int(b.sum())
+    return dict(q4=q4, s4=s4, q8=q8, s8=s8, bad=nbad)
+
+
 # --------------------------------------------------------------------------- GEMM
 def _group_int_dots(qa4, qb4, g):
     a = qa4[:, g * GROUP:(g + 1) * GROUP].astype(f32)

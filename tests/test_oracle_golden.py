@@ -119,3 +119,43 @@ def test_kernel_mode_matches_reference_cpu_golden_semantics():
     q = np.clip(np.sign(body) * np.floor(np.abs(body / s[..., None]) + 0.5), -8, 7).reshape(64, -1)
     assert np.abs(q - t["q4"]).max() <= 1
     assert np.abs(s - t["s4"].astype(np.float32)).max() <= 1e-3
+
+
+def _dequant_weight(r):
+    G = r["s4"].shape[0]
+    N = r["q4"].shape[0]
+    w = np.empty((N, G * 128 + 128), dtype=np.float16)
+    for g in range(G):
+        w[:, g * 128:(g + 1) * 128] = O.dequant_sim(r["q4"][:, g * 128:(g + 1) * 128], r["s4"][g])
+    w[:, G * 128:] = O.dequant_sim(r["q8"], r["s8"])
+    return w
+
+
+def test_pack_recovers_reference_gptq_codes(golden_dir):
+    """The packer's CPU restatement against what the UNMODIFIED reference GPTQ wrote (gptq.py:197-331, fixture made by
+    tests/golden/gen_golden_gptq.py): every block is on the grid, the recovered codes are the reference's
+    round(q/scale_fp32) (gptq.py:38-39) and codes*scale_fp16 reproduces the stored weight to 2^-9."""
+    z = _load(golden_dir, "gptq_layer_64x512.npz")
+    q, s32, cg = z["q"], z["s32"], int(z["channel_group"])
+    r = O.pack_weight_fq(q, cg)
+    assert r["bad"] == 0
+    for g in range(s32.shape[0]):
+        blk = slice(g * 128, (g + 1) * 128)
+        assert np.array_equal(r["q4"][:, blk], O.gptq_codes(q[:, blk], s32[g], 4, cg))
+        assert np.abs(r["s4"][g].astype(np.float32) / np.repeat(s32[g], cg) - 1).max() < 2.0 ** -10
+    assert np.array_equal(r["s4"][:, 0::2], r["s4"][:, 1::2])
+    assert np.abs(r["q8"]).max(axis=1).min() == 127            # INT8 keeper, per-row symmetric (gptq.py:316-325)
+    w = _dequant_weight(r).astype(np.float32)
+    assert np.all(np.abs(w - q.astype(np.float32)) <= np.abs(q.astype(np.float32)) * 2.0 ** -9 + 2.0 ** -24)
+
+
+def test_pack_is_exact_on_rtn_weights_and_flags_off_grid(golden_dir):
+    z = _load(golden_dir, "weight_quant_256x640.npz")
+    ref = O.quant_weight_sim(z["W"], 0.85, 2)
+    r = O.pack_weight_fq(z["Wq"], 2)
+    assert r["bad"] == 0
+    assert np.array_equal(_bits(_dequant_weight(r)), _bits(z["Wq"]))     # the reference's own QLinearLayer.quant output
+    same = np.array_equal(r["q4"], ref["q4"]) and np.array_equal(_bits(r["s4"]), _bits(ref["s4"]))
+    assert same or np.array_equal(_bits(_dequant_weight(r)), _bits(ref["wq"]))
+    n, k = z["W"].shape
+    assert O.pack_weight_fq(z["W"], 2)["bad"] == (n // 2) * ((k - 128) // 128) + n   # unquantised: every block off grid
