@@ -18,6 +18,8 @@ SCALE_LAYOUT_REF = 0
 SCALE_LAYOUT_PLAIN = 1
 QUANT_KERNEL = 0
 QUANT_SIM = 1
+QUANT_WIDE_CODES = 0x100   # ATOM_QUANT_WIDE_CODES
+A_WIDE = 0x100             # ATOM_A_WIDE
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

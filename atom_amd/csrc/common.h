@@ -55,6 +55,7 @@ struct GemmParams {
   int K4h;          // packed bytes per row of A4/B4 = K4/2
   int G;            // int4 groups
   int ref_layout;
+  int a_wide;       // A4 is the wide activation format: int8 [M, K4] = code*16, even/odd de-interleaved per 32 channels
   int64_t ldA;      // halves between groups of sA
 };
 

@@ -312,7 +312,9 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
   p.D = (half_t *)D;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int variant = [] { const char *e = getenv("ATOM_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  if (p.a_wide && variant != 0 && !(variant >= 320 && variant <= 330)) return ATOM_ERR_INVALID_ARG;
   switch (variant) {   // tuning / ablation variants; 0 is the product path
+    case 320: case 324: case 325: return launch_gemm_v3(p, variant - 300, hs);
     case 101: return launch_gemm<GemmCfg<128, 256, 2, 4>, 1>(p, hs);
     case 102: return launch_gemm<GemmCfg<128, 256, 2, 4>, 2>(p, hs);
     case 103: return launch_gemm<GemmCfg<128, 256, 2, 4>, 3>(p, hs);
@@ -328,13 +330,18 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
     case 1: return launch_gemm<GemmCfg<128, 256, 2, 4>>(p, hs);    // v1: register-staged, int8-expanded LDS tiles
     case 2: return launch_gemm_v2(p, 4, hs);
     case 300: case 301: case 302: case 303: case 304: case 305: case 306: return launch_gemm_v3(p, variant - 300, hs);
-    case 310: case 311: {   // traced run: the trace buffer pointer arrives in ATOM_TRACE_PTR (tools/trace_gemm.cpp)
+    case 310: case 311: case 330: {   // traced run: the trace buffer pointer arrives in ATOM_TRACE_PTR (tools/trace_gemm.cpp)
       const char *e = getenv("ATOM_TRACE_PTR");
       if (!e) return ATOM_ERR_INVALID_ARG;
       p.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
       return launch_gemm_v3(p, variant - 300, hs);
     }
     default:                                                        // product path
+      if (p.a_wide) {   // activations pre-widened by the quant kernels: 256x256 tiles once they fill half the chip
+        const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
+        const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
+        return launch_gemm_v3(p, cfg, hs);
+      }
       if (M <= gemv_max_m()) {                                      // decode: weight-streaming dot-product kernel
         const int st = launch_gemv(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
@@ -358,11 +365,14 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
                        const void *B8, const void *sA8, const void *sB8, int64_t M, int64_t N, int64_t K_total, int group,
                        int keeper, int scale_layout) {
   if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8) return ATOM_ERR_INVALID_ARG;
+  const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
+  scale_layout &= ~ATOM_A_WIDE;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
   if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return ATOM_ERR_SHAPE;
   if (M > (1 << 24) || N > (1 << 24) || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
   if ((M > N ? M : N) * ((K_total - kKeeper) / 2) >= (int64_t(1) << 32)) return ATOM_ERR_SHAPE;   // 32-bit DMA offsets
+  if (a_wide && M * (K_total - kKeeper) >= (int64_t(1) << 32)) return ATOM_ERR_SHAPE;
   if (!aligned16(A4) || !aligned16(B4) || !aligned16(A8) || !aligned16(B8)) return ATOM_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(sB) & 3u) || (reinterpret_cast<uintptr_t>(sB8) & 3u)) return ATOM_ERR_ALIGN;
   p.A4 = (const uint8_t *)A4; p.B4 = (const uint8_t *)B4;
@@ -374,6 +384,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.K4h = (int)((K_total - kKeeper) / 2);
   p.G = (int)((K_total - kKeeper) / kGroup);
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
+  p.a_wide = a_wide;
   p.ldA = (int64_t)atom_scale_size(M, scale_layout);
   return ATOM_OK;
 }
@@ -411,7 +422,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.D = (half_t *)D;
   p.ws = (float *)workspace;
   p.splits = choose_splits(M, N, K_total);
-  return launch_gemm_v3(p, 5, reinterpret_cast<hipStream_t>(stream));
+  return launch_gemm_v3(p, p.a_wide ? 25 : 5, reinterpret_cast<hipStream_t>(stream));
 }
 
 int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
@@ -422,6 +433,7 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
   const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
   if (st != ATOM_OK) return st;
   if ((N % 128) != 0) return ATOM_ERR_SHAPE;
+  if (p.a_wide) return ATOM_ERR_INVALID_ARG;                 // the u4 epilogue kernel takes packed activations only
   if (!aligned16(D_u4)) return ATOM_ERR_ALIGN;
   p.D4 = (uint8_t *)D_u4;
   p.Dsz = (half_t *)D_scale_zero;

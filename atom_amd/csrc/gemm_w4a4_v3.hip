@@ -14,44 +14,63 @@ constexpr int TN = 2;                          // wave tile (32*TM)(m) x 64(n); 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int BM_, int BN_, int NS_, int TM_ = 4>
+// AW ("wide activations"): the activation operand arrives already widened to int8 (code * 16), 128 bytes per token and
+// group, with the even / odd channels of every 32-channel block de-interleaved into two 16-byte chunks -- exactly the
+// two operands widen() makes from one packed chunk -- so the kernel skips 3.0 of its 4.5 widening VALU per MFMA.
+// Produced by the activation-quant kernels (ATOM_QUANT_WIDE_CODES); the weights stay packed INT4.
+template <int BM_, int BN_, int NS_, int TM_ = 4, bool AW_ = false>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, NS = NS_, TM = TM_;
+  static constexpr bool AW = AW_;
   static constexpr int WM = 32 * TM;                         // rows of activations per wave
   static constexpr int WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
-  static constexpr int ROWS = BM + BN;                       // weights rows [0,BN), activation rows [BN, BN+BM)
-  static constexpr int DATA_BYTES = ROWS * 64;
+  static constexpr int A_ROWB = AW ? 128 : 64;               // bytes per activation row and stage
+  static constexpr int GW = BN / 16;                         // 1 KiB DMA granules: 16 weight rows ...
+  static constexpr int GA = BM * A_ROWB / 1024;              // ... 16 packed / 8 wide activation rows
+  static constexpr int A_OFF = BN * 64;                      // weights rows first, then the activation rows
+  static constexpr int DATA_BYTES = (GW + GA) * 1024;
   static constexpr int SB_BYTES = (BN < 128 ? 128 : BN) * 2; // BN fp16, dense (one dword DMA always moves 128 of them)
   static constexpr int SB_OFF = DATA_BYTES;
   static constexpr int SA_OFF = DATA_BYTES + SB_BYTES;       // BM dwords (fp16 in the low half)
   static constexpr int STAGE_BYTES = DATA_BYTES + SB_BYTES + BM * 4;
-  static constexpr int IPW = ROWS / 16 / NW;                 // data DMA instructions per wave per stage
+  static constexpr int IPW = (GW + GA) / NW;                 // data DMA instructions per wave per stage
   static constexpr int NSA = BM / 64, NSB = (BN + 127) / 128; // scale DMA instructions per stage (ushort / dword)
   static constexpr int SPW = (NSA + NSB + NW - 1) / NW;      // scale DMA slots per wave (padded with duplicates)
   static constexpr int GLDS = IPW + SPW;
   static constexpr int EP_BYTES = NW * 64 * 144;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
-  static_assert(ROWS % (16 * NW) == 0 && BN % 64 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4), "geometry");
+  static_assert((GW + GA) % NW == 0 && BN % 64 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4), "geometry");
   static_assert(STAGE_BYTES % 16 == 0, "stage alignment");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <class C>
 struct StageAddr {
-  unsigned data[C::IPW];
-  unsigned data8[C::IPW];
+  unsigned idx[C::IPW];       // clamped global row (feature n or token m) this lane fetches for granule i
+  unsigned jw, ja, ja1;       // 16 * logical chunk this lane's LDS slot must receive (weights / activation granules;
+                              // wide activation granules: even / odd granule)
   unsigned scale[C::SPW];
 };
 
 template <class C>
 __device__ __forceinline__ void make_stage_addr(const GemmParams &p, int wave, int lane, int m0, int n0, StageAddr<C> &a) {
+  // XOR swizzle: granule rows are 16-aligned (8-aligned for wide rows), so the logical chunk only depends on the lane
+  a.jw = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  // wide rows are 128 B = half of the 64 LDS banks: the 16 lanes of a ds_read_b128 phase read rows r..r+15, two rows
+  // per 256-byte bank line, so the key is (row >> 1) & 7 (with row & 7, rows r and r+8 collide: 12x the conflicts)
+  a.ja = C::AW ? (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) * 16) : a.jw;
+  a.ja1 = C::AW ? (unsigned)(((lane & 7) ^ (4 | ((lane >> 4) & 3))) * 16) : a.jw;
 #pragma unroll
   for (int i = 0; i < C::IPW; ++i) {
-    const int row = (wave * C::IPW + i) * 16 + (lane >> 2);   // row inside the stage
-    const bool isW = row < C::BN;                             // wave-uniform (16-row granules, BN % 16 == 0)
-    const int j = (lane & 3) ^ ((row >> 2) & 3);              // logical chunk that must land in slot lane&3
-    const int idx = isW ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1);
-    a.data[i] = (unsigned)idx * (unsigned)p.K4h + j * 16;
-    a.data8[i] = (unsigned)idx * kKeeper + j * 16;
+    const int gidx = wave * C::IPW + i;                       // 1 KiB granule inside the stage (wave-uniform)
+    const bool isW = gidx < C::GW;
+    if (isW || !C::AW) {
+      const int row = gidx * 16 + (lane >> 2);                // 16 rows x 64 B; weights rows [0,BN), then activations
+      a.idx[i] = (unsigned)(isW ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
+    } else {
+      const int ra = (gidx - C::GW) * 8 + (lane >> 3);        // 8 rows x 128 B of wide activations
+      a.idx[i] = (unsigned)min(m0 + ra, p.M - 1);
+    }
   }
 #pragma unroll
   for (int s = 0; s < C::SPW; ++s) {
@@ -71,13 +90,20 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
   const bool int4 = step < p.G;
   const int koff = (int4 ? step : step - p.G) * 64;
   const uint8_t *wb = (int4 ? p.B4 : p.B8) + koff;
-  const uint8_t *ab = (int4 ? p.A4 : p.A8) + koff;
+  const uint8_t *ab = (int4 ? p.A4 + (C::AW ? koff : 0) : p.A8) + koff;   // wide rows advance 128 B per group
+  // byte offset of a lane's 16-byte chunk = row * row stride + 16 * logical chunk; in the keeper half-steps a wide
+  // activation row still fills 8 slots, logical chunks 4..7 with copies of 0..3 (never read)
+  const unsigned strideW = int4 ? (unsigned)p.K4h : (unsigned)kKeeper;
+  const unsigned strideA = int4 ? (unsigned)(C::AW ? 2 * p.K4h : p.K4h) : (unsigned)kKeeper;
+  const unsigned kmask = (C::AW && !int4) ? 0x30u : 0x70u;
 #pragma unroll
   for (int i = 0; i < C::IPW; ++i) {
-    const int row0 = (wave * C::IPW + i) * 16;
-    const uint8_t *base = row0 < C::BN ? wb : ab;
-    const unsigned off = int4 ? a.data[i] : a.data8[i];
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(slot + row0 * 64), 16, 0, 0);
+    const int gidx = wave * C::IPW + i;
+    const bool isW = gidx < C::GW;
+    const uint8_t *base = isW ? wb : ab;
+    const unsigned ja = (((gidx - C::GW) & 1) ? a.ja1 : a.ja) & kmask;
+    const unsigned off = a.idx[i] * (isW ? strideW : strideA) + (isW ? a.jw : ja);
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(slot + gidx * 1024), 16, 0, 0);
   }
   const bool keeper = step >= p.G;
   const int g = min(step, p.G - 1);
@@ -108,6 +134,8 @@ __device__ __forceinline__ void widen(const v4u p, v4i &lo, v4i &hi) {
 struct LaneOff {
   int w0, w1;     // weight rows:      (wn*64 + l31)*64 + swizzled chunk (0+h) / (2+h)
   int a0, a1;     // activation rows:  (BN + wm*WM + l31)*64 + swizzled chunk
+  int a2, a3;     // wide activations: A_OFF + (wm*WM + l31)*128 + swizzled chunks 2h, 2h+1 (a0,a1) and 4+2h, 5+2h (a2,a3)
+  int ak0, ak1;   // wide activations, keeper half-steps: logical chunks 0+h, 2+h
   int sa;         // activation scale: SA_OFF + (wm*WM + l31)*4
   int sb;         // weight scales:    SB_OFF + (wn*64 + 4h)*2
 };
@@ -119,8 +147,19 @@ __device__ __forceinline__ LaneOff make_lane_off(int wm, int wn, int lane) {
   LaneOff o;
   o.w0 = (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4);
   o.w1 = (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
-  o.a0 = (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4);
-  o.a1 = (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
+  if constexpr (C::AW) {
+    const int base = C::A_OFF + (wm * C::WM + l31) * 128, s8 = (l31 >> 1) & 7;
+    o.a0 = base + (((2 * h) ^ s8) << 4);
+    o.a1 = base + (((2 * h + 1) ^ s8) << 4);
+    o.a2 = base + (((4 + 2 * h) ^ s8) << 4);
+    o.a3 = base + (((5 + 2 * h) ^ s8) << 4);
+    o.ak0 = base + (((0 + h) ^ s8) << 4);
+    o.ak1 = base + (((2 + h) ^ s8) << 4);
+  } else {
+    o.a0 = (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4);
+    o.a1 = (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
+    o.a2 = o.a3 = o.ak0 = o.ak1 = 0;
+  }
   o.sa = C::SA_OFF + (wm * C::WM + l31) * 4;
   o.sb = C::SB_OFF + (wn * 64 + 4 * h) * 2;
   return o;
@@ -143,7 +182,11 @@ template <class C, bool INT4>
 __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo, float (&c)[TN][C::TM][16]) {
   constexpr int TM = C::TM;
   constexpr int KS = INT4 ? 4 : 2;
-  const char *pw0 = slot + lo.w0, *pw1 = slot + lo.w1, *pa0 = slot + lo.a0, *pa1 = slot + lo.a1;
+  constexpr bool AW = C::AW;
+  constexpr int ASTR = AW ? 4096 : 2048;                 // bytes between consecutive 32-token tiles
+  const char *pw0 = slot + lo.w0, *pw1 = slot + lo.w1;
+  const char *pa0 = slot + (AW && !INT4 ? lo.ak0 : lo.a0), *pa1 = slot + (AW && !INT4 ? lo.ak1 : lo.a1);
+  const char *pa2 = slot + lo.a2, *pa3 = slot + lo.a3;
   const char *psa = slot + lo.sa, *psb = slot + lo.sb;
   v16i magic;
 #pragma unroll
@@ -152,11 +195,54 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) load_frag<INT4>(pw0 + tn * 2048, pw1 + tn * 2048, af[tn]);
 
+  if constexpr (AW) {
+    // Wide activations need no VALU between LDS and the MFMA, so the 4 (keeper: 2) K slices of a token tile live in
+    // ONE set of registers that is refilled in place: as soon as the last chain of tile tm has consumed slice s, the
+    // slice s of tile tm+1 is requested into the same registers and lands under that chain's de-quantisation.
+    const char *pa[4] = {pa0, pa1, pa2, pa3};
+    v4i bf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bf[s] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa[s]));
+    half_t sah = *reinterpret_cast<const half_t *>(psa);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
+      if (tm + 1 < TM) sah = *reinterpret_cast<const half_t *>(psa + (tm + 1) * 128);
+      const float nms = -kMagic * sa;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        __builtin_amdgcn_sched_barrier(0);
+        v16i a = magic;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[s], a, 0, 0, 0);
+          if (tn == TN - 1 && tm + 1 < TM) {
+            __builtin_amdgcn_sched_barrier(0);             // keep the refill BEHIND the MFMA that reads the old value
+            bf[s] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa[s] + (tm + 1) * ASTR));
+          }
+        }
+        v2u sbp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+          const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
+          c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+          asm volatile("" : "+v"(c[tn][tm][r]));
+        }
+      }
+    }
+    return;
+  }
+
   v4u pk0, pk1;
   half_t sah;
   auto request = [&](int tm) {
-    pk0 = *reinterpret_cast<const v4u *>(pa0 + tm * 2048);
-    pk1 = *reinterpret_cast<const v4u *>(pa1 + tm * 2048);
+    pk0 = *reinterpret_cast<const v4u *>(pa0 + tm * ASTR);
+    pk1 = *reinterpret_cast<const v4u *>(pa1 + tm * ASTR);
     sah = *reinterpret_cast<const half_t *>(psa + tm * 128);
   };
   request(0);
@@ -194,6 +280,7 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
     }
   }
 }
+
 
 template <class C, bool TRACE = false, bool SK = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {   // <= 256 VGPRs: two waves per SIMD
@@ -366,6 +453,7 @@ static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
 
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
   if (p.splits > 1 && p.ws) {
+    if (cfg >= 20) return launch_v3_splitk<v3::Cfg<64, 128, 3, 2, true>>(p, s);
     return cfg == 4 ? launch_v3_splitk<v3::Cfg<64, 64, 3, 2>>(p, s) : launch_v3_splitk<v3::Cfg<64, 128, 3, 2>>(p, s);
   }
   switch (cfg) {
@@ -377,6 +465,10 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     case 6: return launch_v3_cfg<v3::Cfg<128, 64, 3, 4>>(p, s);    // one wave, 128x64 tile
     case 10: return launch_v3_cfg<v3::Cfg<256, 256, 4>, true>(p, s);   // traced (p.Dsz = u64 trace buffer)
     case 11: return launch_v3_cfg<v3::Cfg<256, 128, 3>, true>(p, s);
+    case 30: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>, true>(p, s);   // traced
+    case 20: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>>(p, s);   // wide activations (p.A4 = int8 [M, K4])
+    case 24: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2, true>>(p, s);
+    case 25: return launch_v3_cfg<v3::Cfg<64, 128, 3, 2, true>>(p, s);
     default: return launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
   }
 }

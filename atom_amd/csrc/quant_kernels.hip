@@ -38,6 +38,7 @@ struct ActQuantParams {
   int64_t M;
   int H;
   int sim;                // 1 = ATOM_QUANT_SIM
+  int wide;               // 1 = ATOM_QUANT_WIDE_CODES: o4 is int8 [M, H-128] (code*16, even/odd de-interleaved per 32)
   float clip;
   float eps;
   int ref_layout;         // 1 = ATOM_SCALE_LAYOUT_REF
@@ -139,7 +140,14 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
       hi = __builtin_fmaf(tr[8 * k + 7], 4096.f, hi);
       w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x88888888u;
     }
-    *reinterpret_cast<v2u *>(p.o4 + r * (int64_t)K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
+    if (p.wide) {
+      // my 16 channels are half `j & 1` of 32-channel block g*4 + j/2: even channels -> chunk 0, odd -> chunk 1
+      uint8_t *dst = p.o4 + r * (int64_t)(2 * K4h) + g * 128 + (j >> 1) * 32 + (j & 1) * 8;
+      *reinterpret_cast<v2u *>(dst) = v2u{(w[0] << 4) & 0xF0F0F0F0u, (w[1] << 4) & 0xF0F0F0F0u};
+      *reinterpret_cast<v2u *>(dst + 16) = v2u{w[0] & 0xF0F0F0F0u, w[1] & 0xF0F0F0F0u};
+    } else {
+      *reinterpret_cast<v2u *>(p.o4 + r * (int64_t)K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
+    }
   }
   if (j == 0) {
     half_t *dst = keeper ? p.s8 : (p.s4 + (int64_t)g * p.ld);
@@ -364,6 +372,8 @@ static void launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
 static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_layout, void *stream) {
   if (!p.x || !p.o8 || !p.o4 || !p.s8 || !p.s4) return ATOM_ERR_INVALID_ARG;
   if (op != OP_REORDER && !p.b) return ATOM_ERR_INVALID_ARG;
+  p.wide = (quant_mode & ATOM_QUANT_WIDE_CODES) != 0;
+  quant_mode &= ~ATOM_QUANT_WIDE_CODES;
   if (quant_mode != ATOM_QUANT_KERNEL && quant_mode != ATOM_QUANT_SIM) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN)
     return ATOM_ERR_INVALID_ARG;

@@ -88,7 +88,7 @@ class QLinearLayer(nn.Module):
         if packed is not None and codes.hidden == self.weight.shape[1] and x.is_cuda:
             b4, b8, sb, sb8 = packed
             y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
-                                              scale_layout=codes.layout)
+                                              scale_layout=codes.layout, a_wide=codes.wide)
             y = y.view(*x.shape[:-1], self.weight.shape[0])
             if self.bias is not None:
                 y = y + self.bias

@@ -20,7 +20,8 @@ from torch import nn
 
 from .. import ops as _ops
 from .qLinearLayer import QLinearLayer
-from .quant import ActCodes, Quantizer, _reorder_index_i16, attach_codes, hip_act_quant  # noqa: F401
+from .quant import (ActCodes, Quantizer, _reorder_index_i16, attach_codes, hip_act_quant,  # noqa: F401
+                    want_wide_codes)
 
 
 def rotate_half(x):
@@ -116,10 +117,11 @@ class QLlamaRMSNorm(nn.Module):
             idx = self.reorder_index
             if idx is None:
                 idx = torch.arange(hidden, device=x2.device)
+            wide = want_wide_codes(x2.shape[0])
             o8, o4, s8, s4, xq = _ops.rmsnorm_fp16_i4(x2, w, _reorder_index_i16(idx, x2.device), float(eps),
                                                       quant_mode="sim", clip=float(hot.a_clip_ratio),
-                                                      scale_layout="plain", return_dequant=True)
-            return attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, x2.shape[0], hidden))
+                                                      scale_layout="plain", return_dequant=True, wide_codes=wide)
+            return attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, x2.shape[0], hidden, wide=wide))
         result = self.originalNorm(hidden_states)
         if self.reorder_index is not None:
             assert result.shape[-1] == self.reorder_index.shape[0]
@@ -263,9 +265,10 @@ class QLlamaMLP(nn.Module):
         if hot is not None and gate.is_cuda and gate.dtype == torch.float16 and self._act_is_silu():
             shape = gate.shape
             g2, u2 = gate.reshape(-1, inter), up.reshape(-1, inter)
+            wide = want_wide_codes(g2.shape[0])
             o8, o4, s8, s4, xq = _ops.activate_fp16_i4(g2, u2, quant_mode="sim", clip=float(hot.a_clip_ratio),
-                                                       scale_layout="plain", return_dequant=True)
-            act = attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, g2.shape[0], inter))
+                                                       scale_layout="plain", return_dequant=True, wide_codes=wide)
+            act = attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, g2.shape[0], inter, wide=wide))
         else:
             act = self.act_quant(self.act_fn(gate) * up)
         return self.down_proj(act)

@@ -29,11 +29,18 @@ GROUP = 128
 
 class ActCodes:
     """Integer-domain view of a fake-quantised activation: what the W4A4 GEMM consumes."""
-    __slots__ = ("o8", "o4", "s8", "s4", "rows", "hidden", "layout")
+    __slots__ = ("o8", "o4", "s8", "s4", "rows", "hidden", "layout", "wide")
 
-    def __init__(self, o8, o4, s8, s4, rows, hidden, layout="plain"):
+    def __init__(self, o8, o4, s8, s4, rows, hidden, layout="plain", wide=False):
         self.o8, self.o4, self.s8, self.s4 = o8, o4, s8, s4
         self.rows, self.hidden, self.layout = rows, hidden, layout
+        self.wide = wide          # o4 is the native int8 (code*16, de-interleaved) format instead of packed nibbles
+
+
+def want_wide_codes(rows: int) -> bool:
+    """Prefill-sized batches feed the MFMA tile kernel, which is faster on pre-widened activation codes; decode-sized
+    ones (rows <= 7) run the weight-streaming dot-product kernel, which consumes the packed nibbles."""
+    return rows >= 8
 
 
 def is_hot_act_config(args, hidden: int) -> bool:
@@ -141,10 +148,11 @@ def hip_act_quant(x: torch.Tensor, args, reorder_index: torch.Tensor | None = No
     x2 = x.reshape(-1, shape[-1])
     if not x2.is_contiguous():
         x2 = x2.contiguous()
+    wide = want_wide_codes(x2.shape[0])
     o8, o4, s8, s4, xq = _ops.reorder_fp16_i4(x2, _reorder_index_i16(reorder_index, x.device), quant_mode="sim",
                                               clip=float(args.a_clip_ratio), scale_layout="plain",
-                                              return_dequant=True)
-    return attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, x2.shape[0], shape[-1]))
+                                              return_dequant=True, wide_codes=wide)
+    return attach_codes(xq.view(shape), ActCodes(o8, o4, s8, s4, x2.shape[0], shape[-1], wide=wide))
 
 
 @torch.no_grad()

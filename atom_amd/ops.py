@@ -8,6 +8,9 @@ Keyword-only extras (defaults reproduce the reference CUDA kernels exactly):
   clip         clip ratio applied to the INT4 groups' absmax (1.0 = none, the kernels' behaviour)
   scale_layout "ref" (ldmatrix-replicated layout, scale_size(M) halves per group) | "plain" ([G, M])
   return_dequant  also return the de-quantised FP16 tensor (what quantize_activation_wrapper returns)
+  wide_codes   (activation ops) / a_wide (GEMM): the native activation format of include/atom_hip.h -- o_norms is
+               int8 [bs, H-128] = code*16 with the even/odd channels of every 32-channel block de-interleaved, i.e.
+               already the INT8 MFMA operand; the prefill GEMM then skips 2/3 of its widening instructions
 """
 from __future__ import annotations
 
@@ -39,11 +42,11 @@ def _require_cuda_half(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be contiguous")
 
 
-def _alloc_act_outputs(bs, hidden_dim, device, layout, return_dequant):
+def _alloc_act_outputs(bs, hidden_dim, device, layout, return_dequant, wide=False):
     # zeros, not empty, for the replicated layout: it has slots no row ever writes
     alloc = torch.zeros if layout == "ref" else torch.empty
     o_outlier = torch.empty((bs, GROUP_SIZE), dtype=torch.int8, device=device)
-    o_norms = torch.empty((bs, (hidden_dim - GROUP_SIZE) // 2), dtype=torch.int8, device=device)
+    o_norms = torch.empty((bs, (hidden_dim - GROUP_SIZE) // (1 if wide else 2)), dtype=torch.int8, device=device)
     outlier_scales = alloc((_ld(bs, layout),), dtype=torch.float16, device=device)
     norm_scales = alloc((hidden_dim // GROUP_SIZE - 1, _ld(bs, layout)), dtype=torch.float16, device=device)
     xq = torch.empty((bs, hidden_dim), dtype=torch.float16, device=device) if return_dequant else None
@@ -56,8 +59,12 @@ def _ret(o_outlier, o_norms, outlier_scales, norm_scales, xq):
     return o_outlier, o_norms, outlier_scales, norm_scales, xq
 
 
+def _mode(quant_mode, wide_codes):
+    return _MODES[quant_mode] | (L.QUANT_WIDE_CODES if wide_codes else 0)
+
+
 def activate_fp16_i4(a: torch.Tensor, b: torch.Tensor, *, quant_mode="kernel", clip=1.0, scale_layout="ref",
-                     return_dequant=False):
+                     return_dequant=False, wide_codes=False):
     """quant(silu(a) * b) -> (o_outlier i8[bs,128], o_norms i8[bs,(H-128)/2], outlier_scales, norm_scales).
     Reference: punica/ops/__init__.py:141-156 -> run_activate_fp16_i4 (Activate.cuh:194-217).  Any H % 128 == 0
     (the reference is hard-instantiated for 11008, punica_ops.cc:76)."""
@@ -65,8 +72,8 @@ def activate_fp16_i4(a: torch.Tensor, b: torch.Tensor, *, quant_mode="kernel", c
     _require_cuda_half(b, "b")
     bs, hidden_dim = a.shape
     assert b.shape == a.shape
-    outs = _alloc_act_outputs(bs, hidden_dim, a.device, scale_layout, return_dequant)
-    st = L.lib().atom_silu_mul_quant_f16(a.data_ptr(), b.data_ptr(), bs, hidden_dim, _MODES[quant_mode], clip,
+    outs = _alloc_act_outputs(bs, hidden_dim, a.device, scale_layout, return_dequant, wide_codes)
+    st = L.lib().atom_silu_mul_quant_f16(a.data_ptr(), b.data_ptr(), bs, hidden_dim, _mode(quant_mode, wide_codes), clip,
                                           _LAYOUTS[scale_layout], outs[0].data_ptr(), outs[1].data_ptr(),
                                           outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
                                           L.current_stream(a.device))
@@ -75,16 +82,17 @@ def activate_fp16_i4(a: torch.Tensor, b: torch.Tensor, *, quant_mode="kernel", c
 
 
 def rmsnorm_fp16_i4(hidden_states: torch.Tensor, weight: torch.Tensor, reorder_index: torch.Tensor, eps: float, *,
-                    quant_mode="kernel", clip=1.0, scale_layout="ref", return_dequant=False):
+                    quant_mode="kernel", clip=1.0, scale_layout="ref", return_dequant=False, wide_codes=False):
     """quant(index_select(RMSNorm(x)*w, reorder_index)).  Reference: punica/ops/__init__.py:183-200 ->
     run_rmsnorm_fp16_i4 (RMSNorm.cuh:255-285).  reorder_index is int16 [H] as in the reference."""
     _require_cuda_half(hidden_states, "hidden_states")
     _require_cuda_half(weight, "weight")
     assert reorder_index.dtype == torch.int16 and reorder_index.is_cuda
     bs, hidden_dim = hidden_states.shape
-    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant)
+    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant, wide_codes)
     st = L.lib().atom_rmsnorm_reorder_quant_f16(hidden_states.data_ptr(), weight.data_ptr(), float(eps),
-                                                 reorder_index.data_ptr(), bs, hidden_dim, _MODES[quant_mode], clip,
+                                                 reorder_index.data_ptr(), bs, hidden_dim,
+                                                 _mode(quant_mode, wide_codes), clip,
                                                  _LAYOUTS[scale_layout], outs[0].data_ptr(), outs[1].data_ptr(),
                                                  outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
                                                  L.current_stream(hidden_states.device))
@@ -93,7 +101,7 @@ def rmsnorm_fp16_i4(hidden_states: torch.Tensor, weight: torch.Tensor, reorder_i
 
 
 def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="kernel", clip=1.0,
-                    scale_layout="ref", return_dequant=False):
+                    scale_layout="ref", return_dequant=False, wide_codes=False):
     """quant(index_select(x, reorder_index)).  Reference: punica/ops/__init__.py:203-219 ->
     run_reorder_fp16_i4 (Reorder.cuh:205-228).  ``reorder_index=None`` quantises x in its given channel order
     (the tail of quantize_activation_wrapper, model/quant.py:187-231)."""
@@ -101,9 +109,9 @@ def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="k
     if reorder_index is not None:
         assert reorder_index.dtype == torch.int16 and reorder_index.is_cuda
     bs, hidden_dim = hidden_states.shape
-    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant)
+    outs = _alloc_act_outputs(bs, hidden_dim, hidden_states.device, scale_layout, return_dequant, wide_codes)
     st = L.lib().atom_reorder_quant_f16(hidden_states.data_ptr(), L.ptr(reorder_index), bs, hidden_dim,
-                                         _MODES[quant_mode], clip, _LAYOUTS[scale_layout], outs[0].data_ptr(),
+                                         _mode(quant_mode, wide_codes), clip, _LAYOUTS[scale_layout], outs[0].data_ptr(),
                                          outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
                                          L.current_stream(hidden_states.device))
     L.check(st, "atom_reorder_quant_f16")
@@ -122,22 +130,22 @@ def _workspace(device, nbytes):
     return t
 
 
-def _gemm_dims(a, b, a_keeper):
+def _gemm_dims(a, b, a_keeper, a_wide=False):
     m = a.size(0)
     n = b.size(0)
-    k = a.size(1) * 2 + a_keeper.size(1)       # punica_ops.cc:228-241
+    k = a.size(1) * (1 if a_wide else 2) + a_keeper.size(1)       # punica_ops.cc:228-241
     return m, n, k
 
 
 def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
-                             scale_layout="ref"):
+                             scale_layout="ref", a_wide=False):
     """d[M,N] fp16 = W4A4 group-128 GEMM + INT8 keeper.  Reference: punica/ops/__init__.py:159-167 ->
     DenseLayerGEMM_i4<nv_half> (DenseLayerGEMM_i4.cu:722-791).  b_scale is read flat as [G][N] and b_keeper_scale
     as [N], exactly like the reference kernel (Dense_layer_gemm_i4_o16.cuh:497), whatever the tensor's shape."""
     for t in (a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale):
         if not t.is_cuda:
             raise L.AtomHipError("all GEMM operands must live on the GPU: no CPU fallback")
-    m, n, k = _gemm_dims(a, b, a_keeper)
+    m, n, k = _gemm_dims(a, b, a_keeper, a_wide)
     d = torch.empty((m, n), dtype=torch.float16, device=a.device)
     lib = L.lib()
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k)     # > 0 only for skinny shapes that gain from split-K
@@ -145,7 +153,8 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
-                                   _LAYOUTS[scale_layout], L.ptr(ws), ws_bytes, L.current_stream(a.device))
+                                   _LAYOUTS[scale_layout] | (L.A_WIDE if a_wide else 0), L.ptr(ws), ws_bytes,
+                                   L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
     return d
 

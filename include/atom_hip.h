@@ -51,6 +51,19 @@ extern "C" {
 #define ATOM_QUANT_SIM 1    /* the reference simulated path: FP16 opmath, amax.clamp(1e-5)*clip, q = rint(x/s)
                                (model/quant.py:141-142,166-172,181).  clip = args.a_clip_ratio. */
 
+/*
+ * Native activation format (no reference counterpart): OR ATOM_QUANT_WIDE_CODES into `quant_mode` of the three
+ * activation ops and ATOM_A_WIDE into `scale_layout` of atom_gemm_w4a4_f16 / _ws.  o_norms / A4 is then
+ *   int8 [M, K4]   byte[m, 32c + 16p + j] = 16 * code[m, 32c + 2j + p]   (c = 32-channel block, p = parity, j < 16)
+ * i.e. the INT4 codes already widened to the INT8 MFMA operand (x16, the factor 1/256 is folded into the scales as for
+ * packed operands) with the even / odd channels of every 32-channel block de-interleaved -- exactly the two operands the
+ * GEMM otherwise makes from one packed 16-byte chunk with 3 VALU instructions per MFMA.  Costs K4/2 more bytes per
+ * token in HBM, transient.  Same results bit for bit.  Not accepted by atom_gemm_w4a4_o4; M <= 7 runs the tile kernel
+ * (use the packed format for decode).
+ */
+#define ATOM_QUANT_WIDE_CODES 0x100
+#define ATOM_A_WIDE 0x100
+
 const char *atom_version(void);
 const char *atom_strerror(int code);
 

@@ -91,3 +91,12 @@ def assert_gemm_close(d_hip, d_exact, what=""):
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.4g}, rms {rms:.4g}"
     rel = np.linalg.norm(d_hip - d_exact) / max(np.linalg.norm(d_exact), 1e-30)
     assert rel < 5e-4, f"{what}: relative Frobenius error {rel:.3g}"
+
+
+def wide_codes(q4):
+    """int8 codes [M, K4] -> the native wide activation format (include/atom_hip.h): byte[m, 32c+16p+j] = 16*q[m, 32c+2j+p]."""
+    q = np.asarray(q4, dtype=np.int8)
+    M, K4 = q.shape
+    blk = q.reshape(M, K4 // 32, 16, 2)                      # [.., j, p]
+    out = np.transpose(blk, (0, 1, 3, 2)).reshape(M, K4)     # [.., p, j]
+    return (out.astype(np.int16) * 16).astype(np.int8)

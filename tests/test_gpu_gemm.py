@@ -189,3 +189,39 @@ def test_gemm_split_k_path(M, N, K):
     assert (np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-3 * np.sqrt((b ** 2).mean())).all()    # different FP32 summation order
     if lib.atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
         assert np.array_equal(bits16(t2n(out)), bits16(t2n(plain)))
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 512, 512), (129, 320, 384), (257, 1024, 1152), (300, 64, 1280), (8, 4096, 4096),
+                                   (64, 5120, 5120), (1024, 1024, 2176), (5, 256, 640)])
+@pytest.mark.parametrize("layout", ["ref", "plain"])
+def test_gemm_wide_activations_bit_identical(M, N, K, layout):
+    """ATOM_A_WIDE: the activation operand pre-widened to int8 (x16, even/odd de-interleaved) is the same arithmetic in
+    the same order: results equal the packed call bit for bit wherever both run the same kernel family (MFMA tiles:
+    M >= 8), and match the exact oracle everywhere (ragged M / N tails, split-K shapes, M <= 7 on the tile kernel)."""
+    from tests.helpers import wide_codes
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M * 5 + N + K)
+    t = to_device(d, layout)
+    aw = torch.from_numpy(wide_codes(d["qa4"])).cuda()
+    out_w = ops.dense_layer_gemm_i4_fp16(aw, *t[1:], scale_layout=layout, a_wide=True)
+    assert_gemm_close(t2n(out_w), _exact(d), f"wide {M}x{N}x{K} {layout}")
+    if M >= 8 and not (M == 64 and N == 5120):          # same tile family and no split-K regrouping of partial sums
+        out_p = ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout)
+        if ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+            assert torch.equal(out_w, out_p)
+
+
+def test_gemm_wide_full_size_and_errors():
+    from tests.helpers import wide_codes
+    from atom_amd._lib import AtomHipError
+    ops = _ops()
+    d = rand_gemm_operands(4096, 4096, 4096, seed=11)
+    t = to_device(d, "plain")
+    aw = torch.from_numpy(wide_codes(d["qa4"])).cuda()
+    out_w = ops.dense_layer_gemm_i4_fp16(aw, *t[1:], scale_layout="plain", a_wide=True)
+    out_p = ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain")
+    assert torch.equal(out_w, out_p)                      # both: per-group FMAs in group order, keeper halves last
+    with pytest.raises(AtomHipError):                     # the u4-epilogue kernel takes packed activations only
+        st = ops.L.lib().atom_gemm_w4a4_o4(aw.data_ptr(), *[x.data_ptr() for x in t[1:]], t[0].data_ptr(),
+                                           t[2].data_ptr(), 4096, 4096, 4096, 128, 128, 1 | ops.L.A_WIDE, None)
+        ops.L.check(st, "atom_gemm_w4a4_o4")

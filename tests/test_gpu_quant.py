@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import atom_oracle as O
-from tests.helpers import bits16, rand_act, scales_plain, t2n
+from tests.helpers import bits16, rand_act, scales_plain, t2n, wide_codes
 
 pytestmark = pytest.mark.gpu
 
@@ -167,3 +167,30 @@ def test_error_behaviour():
         ops.reorder_fp16_i4(torch.zeros((2, 256), dtype=torch.float16), None)                    # CPU tensor
     with pytest.raises(AtomHipError):
         ops.reorder_fp16_i4(torch.zeros((0, 256), dtype=torch.float16, device="cuda"), None)     # empty
+
+
+@pytest.mark.parametrize("M,H", [(1, 256), (9, 1024), (33, 4096), (3, 11008), (300, 512)])
+@pytest.mark.parametrize("mode,clip", [("sim", 0.9), ("kernel", 1.0)])
+def test_wide_codes_are_the_packed_codes_widened(M, H, mode, clip):
+    """ATOM_QUANT_WIDE_CODES: same codes, stored as the INT8 MFMA operand (x16, even/odd de-interleaved per 32 channels);
+    everything else (keeper, scales, de-quantised tensor) identical to the packed call."""
+    ops = _ops()
+    x = rand_act(M, H, seed=M * 3 + H)
+    idx = np.random.default_rng(H).permutation(H).astype(np.int16)
+    ref = O.reorder_quant(x, idx, mode, clip)
+    xt, it = torch.from_numpy(x).cuda(), torch.from_numpy(idx).cuda()
+    p = ops.reorder_fp16_i4(xt, it, quant_mode=mode, clip=clip, scale_layout="plain", return_dequant=True)
+    w = ops.reorder_fp16_i4(xt, it, quant_mode=mode, clip=clip, scale_layout="plain", return_dequant=True, wide_codes=True)
+    assert w[1].shape == (M, H - 128) and w[1].dtype == torch.int8
+    assert np.array_equal(t2n(w[1]), wide_codes(ref["q4"]))
+    for a, b in zip((p[0], p[2], p[3], p[4]), (w[0], w[2], w[3], w[4])):
+        assert torch.equal(a, b)
+    # the two fused producers share the store path
+    wgt = torch.from_numpy((1 + 0.1 * np.random.default_rng(1).standard_normal(H)).astype(np.float16)).cuda()
+    rp = ops.rmsnorm_fp16_i4(xt, wgt, it, 1e-5, quant_mode=mode, clip=clip, scale_layout="plain")
+    rw = ops.rmsnorm_fp16_i4(xt, wgt, it, 1e-5, quant_mode=mode, clip=clip, scale_layout="plain", wide_codes=True)
+    assert np.array_equal(t2n(rw[1]), wide_codes(O.unpack_int4(t2n(rp[1]).view(np.uint8))))
+    b = torch.from_numpy(rand_act(M, H, seed=7, outliers=False)).cuda()
+    sp = ops.activate_fp16_i4(xt, b, quant_mode=mode, clip=clip, scale_layout="plain")
+    sw = ops.activate_fp16_i4(xt, b, quant_mode=mode, clip=clip, scale_layout="plain", wide_codes=True)
+    assert np.array_equal(t2n(sw[1]), wide_codes(O.unpack_int4(t2n(sp[1]).view(np.uint8))))

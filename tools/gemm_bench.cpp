@@ -57,11 +57,26 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&D, (size_t)M * N * 2));
   CK(hipMemset(D, 0xFF, (size_t)M * N * 2));
 
+  // ATOM_AWIDE=1: feed the GEMM the wide activation format (int8 code*16, even/odd de-interleaved per 32 channels)
+  const bool awide = getenv("ATOM_AWIDE") != nullptr;
+  void *Ain = A4;
+  const int layout = ATOM_SCALE_LAYOUT_PLAIN | (awide ? ATOM_A_WIDE : 0);
+  if (awide) {
+    std::vector<uint8_t> hw((size_t)M * K4);
+    for (size_t m = 0; m < (size_t)M; ++m)
+      for (int c = 0; c < K4 / 32; ++c)
+        for (int j = 0; j < 16; ++j) {
+          const uint8_t b = hA4[m * (K4 / 2) + c * 16 + j];        // channels 32c+2j (low nibble), 32c+2j+1 (high)
+          hw[m * K4 + c * 32 + j] = (uint8_t)(b << 4);
+          hw[m * K4 + c * 32 + 16 + j] = (uint8_t)(b & 0xF0);
+        }
+    up(&Ain, hw.data(), hw.size());
+  }
   size_t wsb = getenv("ATOM_WS") ? atom_gemm_w4a4_workspace_bytes(M, N, K) : 0;
   void *ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
   printf("workspace bytes %zu\n", wsb);
 #define atom_gemm_w4a4_f16(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p) atom_gemm_w4a4_f16_ws(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, ws, wsb, p)
-  int st = atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, ATOM_SCALE_LAYOUT_PLAIN, nullptr);
+  int st = atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
   if (st) { printf("atom_gemm_w4a4_f16: %s\n", atom_strerror(st)); return 1; }
   CK(hipDeviceSynchronize());
 
@@ -88,12 +103,12 @@ int main(int argc, char **argv) {
   }
 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1, nullptr);
+  for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
   CK(hipDeviceSynchronize());
   float best = 1e30f, tot = 0;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1, nullptr);
+    for (int i = 0; i < iters; ++i) atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters; tot += ms; if (ms < best) best = ms;
   }

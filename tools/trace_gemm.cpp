@@ -12,12 +12,13 @@ int main(int argc, char **argv) {
   auto mk = [&](size_t bytes, bool scale) { void *d; hipMalloc(&d, bytes); std::vector<uint8_t> h(bytes);
     if (!scale) for (auto &x : h) x = rng() & 0xFF; else { _Float16 *p = (_Float16 *)h.data(); for (size_t i = 0; i < bytes / 2; ++i) p[i] = (_Float16)(0.005f + 0.045f * ((rng() >> 11) * (1.0 / 9007199254740992.0))); }
     hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice); return d; };
-  void *A4 = mk((size_t)M * K4 / 2, false), *B4 = mk((size_t)N * K4 / 2, false), *A8 = mk((size_t)M * 128, false), *B8 = mk((size_t)N * 128, false);
+  const bool wide = atoi(variant) == 330;
+  void *A4 = mk((size_t)M * K4 / (wide ? 1 : 2), false), *B4 = mk((size_t)N * K4 / 2, false), *A8 = mk((size_t)M * 128, false), *B8 = mk((size_t)N * 128, false);
   void *sA = mk((size_t)G * M * 2, true), *sB = mk((size_t)G * N * 2, true), *sA8 = mk(M * 2, true), *sB8 = mk(N * 2, true);
   void *D; hipMalloc(&D, (size_t)M * N * 2);
   unsigned long long *tr; hipMalloc(&tr, 8 * 64 * 4 * 8); hipMemset(tr, 0, 8 * 64 * 4 * 8);
   char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)tr); setenv("ATOM_TRACE_PTR", buf, 1); setenv("ATOM_GEMM_VARIANT", variant, 1);
-  for (int i = 0; i < 20; ++i) { int st = atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1, nullptr); if (st) { printf("err %d\n", st); return 1; } }
+  for (int i = 0; i < 20; ++i) { int st = atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, 1 | (wide ? ATOM_A_WIDE : 0), nullptr); if (st) { printf("err %d\n", st); return 1; } }
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(8 * 64 * 4); hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
   int nw = atoi(variant) == 311 ? 4 : 8;
