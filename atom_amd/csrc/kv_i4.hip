@@ -1,0 +1,353 @@
+// INT4 paged KV cache for Atom on gfx950: append (prefill / decode) and batch-decode attention.
+//
+//   atom_kv_append_i4     <- FlashInferInitKvKernel_i4 / FlashInferAppendKvKernel_i4
+//                            (e2e/punica-atom/punica/ops/csrc/flashinfer_adapter/flashinfer_impl.cuh:48-96 ->
+//                             AppendPagedKVCachePrefillKernel / ...DecodeKernel, kernels/include/flashinfer/page.cuh:119-227)
+//   atom_batch_decode_i4  <- FlashInferBatchDecodeKernel_i4 (flashinfer_impl.cuh:9-46 ->
+//                             BatchDecodeWithPagedKVCacheKernel, kernels/include/flashinfer/decode.cuh:480-676)
+//
+// Layouts are the reference's (punica/utils/kvcache.py:17-26, page.cuh:78-110):
+//   kv_data  u8  [pages, L, 2, N, P, D/2]   asymmetric u4, element 2j in the low nibble; value = nibble*scale - zero
+//   kv_param f16 [pages, L, 2, N, P, 2]     (scale, zero) per token and head            (quantization.cuh:59-84)
+//   sequence b owns pages kv_indices[kv_indptr[b] .. kv_indptr[b+1]); its length is
+//   (npages-1)*P + last_page_offset[b].
+// Both ops are pure HBM streaming (68 bytes per token, head and K/V); D = 128 as in the reference (CHECK_EQ(head_dim,128),
+// punica_ops.cc:112), P a multiple of 16.
+//
+// Append: the reference walks a sequence's new tokens in a serial loop per (sequence, head) block; here every token is
+// one workgroup (binary search of its sequence in append_indptr), 16-byte chunks per thread.
+//
+// Decode: one wave per (sequence, head, KV split); a 16-token tile of one page and head is exactly 1 KiB of K and 1 KiB
+// of V, i.e. one coalesced wave access.  Lane (t, u) = (token of the tile, quarter): it loads K as two 8-byte pieces,
+// dims [16u,16u+16) and [64+16u, 64+16u+16) -- the two halves of its 16 RoPE pairs -- and V as one 16-byte piece.
+// RoPE is never applied to the keys: <R(pq) q, R(j) k> = <R(pq - j) q, k>, so each lane keeps q rotated by (pq - j) for
+// ITS token j and turns it back by the constant angle 16*f_i per tile (4 FMAs per pair, no sincos in the loop).
+// De-quantisation is folded: the zero point of V is accumulated as a scalar (o = sum p*s*u - sum p*z).  Every quad runs
+// its own online softmax over its token subsequence; the 16 quads (and the KV splits, through a small FP32 workspace)
+// are merged once at the end.
+#include <math.h>
+
+#include "common.h"
+
+namespace atom {
+
+constexpr int kHeadDim = 128;
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct KvParams {
+  uint8_t *data;
+  half_t *param;
+  const int32_t *indptr, *indices, *last_page_offset;
+  int batch, L, layer, N, P;
+};
+
+// ------------------------------------------------------------------------------------------------ append
+struct AppendParams {
+  KvParams kv;
+  const uint8_t *k, *v;
+  const half_t *k_param, *v_param;
+  const int32_t *append_indptr;   // NULL: one token per sequence
+  int64_t T;
+};
+
+__global__ __launch_bounds__(256) void kv_append_kernel(AppendParams p) {
+  const int64_t t = blockIdx.x;
+  const int tid = threadIdx.x;
+  int b, j, n;
+  if (p.append_indptr) {
+    int lo = 0, hi = p.kv.batch;                       // largest b with append_indptr[b] <= t
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (p.append_indptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    b = lo;
+    j = (int)(t - p.append_indptr[b]);
+    n = p.append_indptr[b + 1] - p.append_indptr[b];
+  } else {
+    b = (int)t; j = 0; n = 1;
+  }
+  const int P = p.kv.P, N = p.kv.N;
+  const int seq_len = (p.kv.indptr[b + 1] - p.kv.indptr[b] - 1) * P + p.kv.last_page_offset[b];
+  const int pos = seq_len - n + j;                     // page.cuh:186-192
+  if (pos < 0) return;
+  const int64_t page = p.kv.indices[p.kv.indptr[b] + pos / P];
+  const int e = pos % P;
+  const int64_t base = (page * p.kv.L + p.kv.layer) * 2;             // [.., 2, N, P, ..]
+  for (int i = tid; i < 2 * N * 4; i += 256) {                       // (k|v, head, 16-byte chunk)
+    const int kv = i / (N * 4), h = (i >> 2) % N, ch = i & 3;
+    const uint8_t *src = (kv ? p.v : p.k) + ((int64_t)t * N + h) * 64 + ch * 16;
+    uint8_t *dst = p.kv.data + (((base + kv) * N + h) * P + e) * 64 + ch * 16;
+    *reinterpret_cast<v4u *>(dst) = *reinterpret_cast<const v4u *>(src);
+  }
+  for (int i = tid; i < 2 * N; i += 256) {                           // (scale, zero) half2 per (k|v, head)
+    const int kv = i / N, h = i % N;
+    const unsigned *src = reinterpret_cast<const unsigned *>((kv ? p.v_param : p.k_param) + ((int64_t)t * N + h) * 2);
+    unsigned *dst = reinterpret_cast<unsigned *>(p.kv.param + (((base + kv) * N + h) * P + e) * 2);
+    *dst = *src;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+struct DecodeParams {
+  KvParams kv;
+  const half_t *q;      // [B, N, 128]
+  half_t *o;            // [B, N, 128]
+  float *ws;            // splits > 1: [B, N, splits, 130] = o[128] (not normalised), m, d
+  int splits;
+  float sm_scale, log2_theta, rope_inv_scale;
+};
+
+// 8 packed u4 -> 8 floats (element 2j in the low nibble of byte j)
+__device__ __forceinline__ void nib8(unsigned x, float (&f)[8]) {
+  const unsigned lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
+  f[0] = (float)(lo & 0xFF); f[1] = (float)(hi & 0xFF);
+  f[2] = (float)((lo >> 8) & 0xFF); f[3] = (float)((hi >> 8) & 0xFF);
+  f[4] = (float)((lo >> 16) & 0xFF); f[5] = (float)((hi >> 16) & 0xFF);
+  f[6] = (float)(lo >> 24); f[7] = (float)(hi >> 24);
+}
+
+__device__ __forceinline__ float quad_sum_f(float x) {
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  return x;
+}
+
+__global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
+  const int lane = threadIdx.x;
+  const int t = lane >> 2, u = lane & 3;
+  const int N = p.kv.N, P = p.kv.P;
+  const int h = blockIdx.x % N, b = blockIdx.x / N, sp = blockIdx.y;
+  const int pg0 = p.kv.indptr[b];
+  const int seq_len = (p.kv.indptr[b + 1] - pg0 - 1) * P + p.kv.last_page_offset[b];
+  const int ntiles = (seq_len + 15) >> 4;
+  const int chunk = (ntiles + p.splits - 1) / p.splits;
+  const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
+  const int tpp = P >> 4;                               // 16-token tiles per page
+
+  // q rotated to the relative position of MY token of the first tile, and the per-tile back-rotation
+  float A1[16], A2[16], C16[16], S16[16];
+  {
+    const half_t *qp = p.q + ((int64_t)b * N + h) * kHeadDim;
+    v4u r1[2], r2[2];
+    r1[0] = *reinterpret_cast<const v4u *>(qp + 16 * u);
+    r1[1] = *reinterpret_cast<const v4u *>(qp + 16 * u + 8);
+    r2[0] = *reinterpret_cast<const v4u *>(qp + 64 + 16 * u);
+    r2[1] = *reinterpret_cast<const v4u *>(qp + 64 + 16 * u + 8);
+    const half_t *h1 = reinterpret_cast<const half_t *>(r1), *h2 = reinterpret_cast<const half_t *>(r2);
+    const float delta = (float)((seq_len - 1) - (tile0 * 16 + t));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      // decode.cuh:535-539: freq = rope_inv_scale * theta^(-2 (i mod 64) / 128)
+      const float f = p.rope_inv_scale * exp2f(-p.log2_theta * (float)(2 * (16 * u + i)) * (1.0f / kHeadDim));
+      float s, c;
+      sincosf(delta * f, &s, &c);
+      const float q1 = (float)h1[i], q2 = (float)h2[i];
+      A1[i] = q1 * c - q2 * s;                          // R(+delta) q
+      A2[i] = q2 * c + q1 * s;
+      sincosf(16.0f * f, &S16[i], &C16[i]);
+    }
+  }
+
+  float o[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) o[i] = 0.f;
+  float m = -INFINITY, d = 0.f, zacc = 0.f;
+  const float qk_scale = p.sm_scale * kLog2e;           // decode.cuh:500: softmax in base 2
+
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int64_t page = p.kv.indices[pg0 + tile / tpp];
+    const int e = (tile % tpp) * 16 + t;                // entry inside the page
+    const int64_t base = ((page * p.kv.L + p.kv.layer) * 2 * N + h) * P;           // K block of (page, layer, head)
+    const uint8_t *kp = p.kv.data + (base + e) * 64;
+    const uint8_t *vp = kp + (int64_t)N * P * 64;
+    const v2u k1 = *reinterpret_cast<const v2u *>(kp + 8 * u);
+    const v2u k2 = *reinterpret_cast<const v2u *>(kp + 32 + 8 * u);
+    const v4u vv = *reinterpret_cast<const v4u *>(vp + 16 * u);
+    const unsigned kq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + e) * 2);
+    const unsigned vq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + (int64_t)N * P + e) * 2);
+    const bool valid = tile * 16 + t < seq_len;
+
+    // scores: sum over my 16 pairs of (u1*s - z) * A1 + (u2*s - z) * A2
+    const float ks = (float)__builtin_bit_cast(half_t, (unsigned short)(kq & 0xFFFF));
+    const float nkz = -(float)__builtin_bit_cast(half_t, (unsigned short)(kq >> 16));
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      float f1[8], f2[8];
+      nib8(k1[w], f1);
+      nib8(k2[w], f2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc = __builtin_fmaf(__builtin_fmaf(f1[i], ks, nkz), A1[8 * w + i], acc);
+        acc = __builtin_fmaf(__builtin_fmaf(f2[i], ks, nkz), A2[8 * w + i], acc);
+      }
+    }
+    float s = quad_sum_f(acc) * qk_scale;
+    if (!valid) s = -INFINITY;
+    // online softmax of this quad's token subsequence (decode.cuh update_partial_state / state.cuh)
+    const float mn = fmaxf(m, s);
+    if (__any(mn > m)) {                               // rescale only when some running maximum moved
+      const float alpha = mn == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m - mn);
+      d *= alpha;
+      zacc *= alpha;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) o[i] *= alpha;
+      m = mn;
+    }
+    const float pr = valid ? __builtin_amdgcn_exp2f(s - m) : 0.f;
+    d += pr;
+    const float vs = (float)__builtin_bit_cast(half_t, (unsigned short)(vq & 0xFFFF));
+    const float vz = (float)__builtin_bit_cast(half_t, (unsigned short)(vq >> 16));
+    const float ps = pr * vs;
+    zacc = __builtin_fmaf(pr, vz, zacc);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float f[8];
+      nib8(vv[w], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[8 * w + i] = __builtin_fmaf(ps, f[i], o[8 * w + i]);
+    }
+    // my token of the next tile is 16 positions later: turn q back by 16*f
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float a1 = A1[i], a2 = A2[i];
+      A1[i] = __builtin_fmaf(a1, C16[i], a2 * S16[i]);
+      A2[i] = __builtin_fmaf(a2, C16[i], -(a1 * S16[i]));
+    }
+  }
+
+  // merge the 16 quads: lanes with equal u hold the same 32 output dims
+  float mall = m;
+#pragma unroll
+  for (int x = 4; x < 64; x <<= 1) mall = fmaxf(mall, __shfl_xor(mall, x));
+  const float sc = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mall);
+  d *= sc;
+  zacc *= sc;
+#pragma unroll
+  for (int x = 4; x < 64; x <<= 1) {
+    d += __shfl_xor(d, x);
+    zacc += __shfl_xor(zacc, x);
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    float v = o[i] * sc;
+#pragma unroll
+    for (int x = 4; x < 64; x <<= 1) v += __shfl_xor(v, x);
+    o[i] = v - zacc;                                    // sum p*(s*u - z)
+  }
+  if (t != 0) return;
+  if (p.splits == 1) {
+    const float rd = 1.0f / d;
+    half_t *op = p.o + ((int64_t)b * N + h) * kHeadDim + 32 * u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      v4u pk;
+      half_t *hv = reinterpret_cast<half_t *>(&pk);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = (half_t)(o[8 * w + i] * rd);
+      *reinterpret_cast<v4u *>(op + 8 * w) = pk;
+    }
+  } else {
+    float *wp = p.ws + (((int64_t)b * N + h) * p.splits + sp) * (kHeadDim + 2);
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+      *reinterpret_cast<v4f *>(wp + 32 * u + 4 * w) = v4f{o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]};
+    if (u == 0) {
+      wp[kHeadDim] = mall;
+      wp[kHeadDim + 1] = d;
+    }
+  }
+}
+
+// out[b,h,:] = sum_s o_s * 2^(m_s - M) / sum_s d_s * 2^(m_s - M)
+__global__ __launch_bounds__(128) void decode_merge_kernel(const float *ws, half_t *o, int splits) {
+  const int64_t bh = blockIdx.x;
+  const int dim = threadIdx.x;
+  const float *wp = ws + bh * splits * (kHeadDim + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < splits; ++s) M = fmaxf(M, wp[s * (kHeadDim + 2) + kHeadDim]);
+  float acc = 0.f, den = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float ms = wp[s * (kHeadDim + 2) + kHeadDim];
+    const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+    acc = __builtin_fmaf(wp[s * (kHeadDim + 2) + dim], w, acc);
+    den = __builtin_fmaf(wp[s * (kHeadDim + 2) + kHeadDim + 1], w, den);
+  }
+  o[bh * kHeadDim + dim] = (half_t)(acc / den);
+}
+
+static int check_kv(const void *kv_data, const void *kv_param, const int32_t *indptr, const int32_t *indices,
+                    const int32_t *lpo, int batch, int L, int layer, int N, int P, int D) {
+  if (!kv_data || !kv_param || !indptr || !indices || !lpo) return ATOM_ERR_INVALID_ARG;
+  if (D != kHeadDim || batch < 1 || L < 1 || layer < 0 || layer >= L || N < 1 || P < 16 || (P % 16) != 0) return ATOM_ERR_SHAPE;
+  if (!aligned16(kv_data) || (reinterpret_cast<uintptr_t>(kv_param) & 3u)) return ATOM_ERR_ALIGN;
+  return ATOM_OK;
+}
+
+// KV splits so that batch*heads*splits waves fill the chip (about 8 waves per CU), at least 2 tiles per split
+static int decode_splits(int batch, int N, int max_pages, int P) {
+  if (max_pages <= 0) return 1;
+  const int64_t tiles = (int64_t)max_pages * (P / 16);
+  int64_t s = (2048 + (int64_t)batch * N - 1) / ((int64_t)batch * N);
+  if (s > tiles / 2) s = tiles / 2;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (int)s;
+}
+
+}  // namespace atom
+
+using namespace atom;
+
+extern "C" {
+
+int atom_kv_append_i4(void *kv_data, void *kv_param, const int32_t *kv_indptr, const int32_t *kv_indices,
+                      const int32_t *last_page_offset, const void *k, const void *v, const void *k_param,
+                      const void *v_param, const int32_t *append_indptr, int64_t total_tokens, int batch,
+                      int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, void *stream) {
+  const int st = check_kv(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
+                          num_heads, page_size, head_dim);
+  if (st != ATOM_OK) return st;
+  if (!k || !v || !k_param || !v_param) return ATOM_ERR_INVALID_ARG;
+  if (total_tokens < 1 || total_tokens > 0x7fffffff || (!append_indptr && total_tokens != batch)) return ATOM_ERR_SHAPE;
+  if (!aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(k_param) & 3u) ||
+      (reinterpret_cast<uintptr_t>(v_param) & 3u))
+    return ATOM_ERR_ALIGN;
+  AppendParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
+                  layer_idx, num_heads, page_size},
+                 (const uint8_t *)k, (const uint8_t *)v, (const half_t *)k_param, (const half_t *)v_param,
+                 append_indptr, total_tokens};
+  hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)total_tokens), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_size, int max_pages_per_seq) {
+  if (batch < 1 || num_heads < 1 || page_size < 16) return 0;
+  const int s = decode_splits(batch, num_heads, max_pages_per_seq, page_size);
+  return s > 1 ? (size_t)batch * num_heads * s * (kHeadDim + 2) * sizeof(float) : 0;
+}
+
+int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,
+                         const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
+                         int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
+                         int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream) {
+  const int st = check_kv(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
+                          num_heads, page_size, head_dim);
+  if (st != ATOM_OK) return st;
+  if (!o || !q || !(rope_theta > 0.f) || !(rope_scale > 0.f)) return ATOM_ERR_INVALID_ARG;
+  if (!aligned16(o) || !aligned16(q)) return ATOM_ERR_ALIGN;
+  int splits = decode_splits(batch, num_heads, max_pages_per_seq, page_size);
+  const size_t need = (size_t)batch * num_heads * splits * (kHeadDim + 2) * sizeof(float);
+  if (splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) splits = 1;
+  DecodeParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
+                  layer_idx, num_heads, page_size},
+                 (const half_t *)q, (half_t *)o, (float *)workspace, splits,
+                 1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(batch_decode_kernel, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
+  if (splits > 1)
+    hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace,
+                       (half_t *)o, splits);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -215,3 +215,59 @@ def pack_weight_w4(weight_fq: torch.Tensor, channel_group: int = 2, strict: bool
     if strict and nbad:
         raise L.AtomHipError(f"pack_weight_w4: {nbad} weight blocks are not INT4-g128/INT8 fake-quantised values")
     return b4, b8, sb, sb8, nbad
+
+
+# ------------------------------------------------------------------------------------------------ INT4 paged KV cache
+def _kv_dims(kv):
+    _c, num_layers, _2, num_heads, page_size, half_dim = kv.data.shape
+    return num_layers, num_heads, page_size, half_dim * 2
+
+
+def _kv_append(kv, k, v, k_param, v_param, append_indptr, layer_idx, what):
+    for t in (kv.data, kv.param, k, v, k_param, v_param):
+        if not t.is_cuda:
+            raise L.AtomHipError("KV-cache operands must live on the GPU: no CPU fallback")
+    num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
+    total = k.size(0)
+    assert k.shape == v.shape == (total, num_heads, head_dim // 2) and k.dtype == v.dtype == torch.uint8
+    assert k_param.numel() == v_param.numel() == total * num_heads * 2 and k_param.dtype == torch.float16
+    batch = kv.last_page_offset.numel()
+    st = L.lib().atom_kv_append_i4(kv.data.data_ptr(), kv.param.data_ptr(), kv.indptr.data_ptr(),
+                                    kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), k.contiguous().data_ptr(),
+                                    v.contiguous().data_ptr(), k_param.contiguous().data_ptr(),
+                                    v_param.contiguous().data_ptr(), L.ptr(append_indptr), total, batch, num_layers,
+                                    int(layer_idx), num_heads, page_size, head_dim, L.current_stream(k.device))
+    L.check(st, what)
+
+
+def init_kv_i4(kv, k, v, k_param, v_param, seqlen_indptr, layer_idx: int):
+    """Write the prefill tokens' quantised K/V into the pages.  Reference: punica/ops/__init__.py:33-45 ->
+    FlashInferInitKvKernel_i4.  k, v uint8 [sum(len), heads, 64]; k_param, v_param fp16 [sum(len), heads, 2];
+    seqlen_indptr int32 [batch+1]."""
+    assert seqlen_indptr.dtype == torch.int32 and seqlen_indptr.is_cuda
+    _kv_append(kv, k, v, k_param, v_param, seqlen_indptr, layer_idx, "atom_kv_append_i4 (init)")
+
+
+def append_kv_i4(kv, k, v, k_param, v_param, layer_idx: int):
+    """Append ONE token per sequence.  Reference: punica/ops/__init__.py:48-59 -> FlashInferAppendKvKernel_i4."""
+    _kv_append(kv, k, v, k_param, v_param, None, layer_idx, "atom_kv_append_i4")
+
+
+def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0):
+    """Decode attention over the INT4 paged cache, RoPE fused.  Reference: punica/ops/__init__.py:21-30 ->
+    FlashInferBatchDecodeKernel_i4 (rope_theta 1e4, rope_scale 1 hard-coded there).  q fp16 [batch, heads, 128]."""
+    _require_cuda_half(q, "q")
+    num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
+    batch = q.size(0)
+    assert q.shape == (batch, num_heads, head_dim)
+    o = torch.empty_like(q)
+    lib = L.lib()
+    max_pages = int(getattr(kv, "max_pages", 0))
+    ws_bytes = lib.atom_batch_decode_i4_workspace_bytes(batch, num_heads, page_size, max_pages)
+    ws = _workspace(q.device, ws_bytes) if ws_bytes else None
+    st = lib.atom_batch_decode_i4(o.data_ptr(), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
+                                  kv.indptr.data_ptr(), kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), batch,
+                                  num_layers, int(layer_idx), num_heads, page_size, head_dim, float(rope_theta),
+                                  float(rope_scale), max_pages, L.ptr(ws), ws_bytes, L.current_stream(q.device))
+    L.check(st, "atom_batch_decode_i4")
+    return o

@@ -174,6 +174,39 @@ int atom_quant_weight_w4(const void *W_f16, int64_t N, int64_t K_total, float w_
 int atom_pack_weight_w4(const void *Wq_f16, int64_t N, int64_t K_total, int channel_group,
                         void *B4, void *B8, void *sB, void *sB8, int32_t *bad_blocks, void *stream);
 
+/*
+ * INT4 paged KV cache -- the two ops that follow the k/v projections (atom_gemm_w4a4_o4) in the
+ * reference's decoder layer (e2e/punica-atom/punica/models/llama.py:196-211).  Layouts are the reference's
+ * (punica/utils/kvcache.py:17-26, kernels/include/flashinfer/page.cuh:78-110):
+ *   kv_data  uint8 [pages, num_layers, 2, num_heads, page_size, head_dim/2]  u4, element 2j in the low nibble
+ *   kv_param fp16  [pages, num_layers, 2, num_heads, page_size, 2]           (scale, zero): value = u4*scale - zero
+ *   kv_indptr int32 [batch+1], kv_indices int32 [kv_indptr[batch]], last_page_offset int32 [batch] (1..page_size);
+ *   sequence b has (npages_b - 1)*page_size + last_page_offset[b] tokens.
+ * head_dim must be 128 (as in the reference, punica_ops.cc:112), page_size a multiple of 16.
+ */
+
+/* Copy new tokens' quantised K/V (the d / d_scale outputs of atom_gemm_w4a4_o4, viewed [T, heads, 64] / [T, heads, 2])
+ * into the pages.  append_indptr int32 [batch+1] (device): the tokens are the LAST append_indptr[b+1]-append_indptr[b]
+ * positions of sequence b (pages already allocated, lengths already updated), total_tokens = append_indptr[batch];
+ * append_indptr == NULL: one token per sequence (total_tokens == batch).
+ * Replaces: FlashInferInitKvKernel_i4 / FlashInferAppendKvKernel_i4 (punica/ops/csrc/flashinfer_adapter/
+ * flashinfer_impl.cuh:48-96; page.cuh:119-227) = punica_ops.cc:122-209 init_kv_i4 / append_kv_i4. */
+int atom_kv_append_i4(void *kv_data, void *kv_param, const int32_t *kv_indptr, const int32_t *kv_indices,
+                      const int32_t *last_page_offset, const void *k, const void *v, const void *k_param,
+                      const void *v_param, const int32_t *append_indptr, int64_t total_tokens, int batch,
+                      int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, void *stream);
+
+/* o[b,h,:] (fp16) = softmax_j( <RoPE(q[b,h], len_b-1), RoPE(dequant K[b,h,j], j)> / sqrt(128) ) . dequant V[b,h,j].
+ * Replaces: FlashInferBatchDecodeKernel_i4 (flashinfer_impl.cuh:9-46; decode.cuh:480-676) = punica_ops.cc:82-120
+ * batch_decode_i4 (rope_theta 1e4, rope_scale 1 there).  max_pages_per_seq (host-side upper bound of npages_b, 0 =
+ * unknown) lets long sequences at small batch split their KV range over several waves: FP32 partial states go to
+ * `workspace` (atom_batch_decode_i4_workspace_bytes; NULL / too small = no split) and a second launch merges them. */
+size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_size, int max_pages_per_seq);
+int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,
+                         const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
+                         int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
+                         int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

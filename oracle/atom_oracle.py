@@ -449,3 +449,79 @@ def sim_linear_torch(xq, wq):
     """The literal reference call, torch CPU kernels: used as bench.py's cpu_baseline ("port")."""
     import torch
     return torch.nn.functional.linear(xq, wq, None)
+
+
+# --------------------------------------------------------------------------- INT4 paged KV cache (SURVEY 8(f) N1 / N3)
+# Parity unpinned: the reference holds no golden vector for these (tests/test_batch_decode_int4.py only checks that the
+# CUDA kernel runs) and its kernels cannot run here; the restatement follows the CUDA sources line by line instead.
+def kv_seq_len(indptr, last_page_offset, page_size, b):
+    """page.cuh:170-172 / decode.cuh:510-512."""
+    return (int(indptr[b + 1]) - int(indptr[b]) - 1) * page_size + int(last_page_offset[b])
+
+
+def kv_append_i4(data, param, indptr, indices, last_page_offset, k, v, k_param, v_param, layer, append_indptr=None):
+    """AppendPagedKVCachePrefillKernel / ...DecodeKernel (kernels/include/flashinfer/page.cuh:119-227), in place.
+    data  u8  [pages, L, 2, N, P, D/2]   param f16 [pages, L, 2, N, P, 2]   (punica/utils/kvcache.py:17-26)
+    k, v  u8  [T, N, D/2]                k_param, v_param f16 [T, N, 2] = (scale, zero)
+    append_indptr int32 [B+1] (prefill: the LAST append_len tokens of every sequence) or None (decode: one token each)."""
+    B = len(last_page_offset)
+    P = data.shape[4]
+    for b in range(B):
+        seq_len = kv_seq_len(indptr, last_page_offset, P, b)
+        if append_indptr is None:
+            t0, n = b, 1
+        else:
+            t0, n = int(append_indptr[b]), int(append_indptr[b + 1]) - int(append_indptr[b])
+        for j in range(n):
+            pos = seq_len - n + j
+            page = int(indices[int(indptr[b]) + pos // P])
+            e = pos % P
+            data[page, layer, 0, :, e, :] = k[t0 + j]
+            data[page, layer, 1, :, e, :] = v[t0 + j]
+            param[page, layer, 0, :, e, :] = k_param[t0 + j]
+            param[page, layer, 1, :, e, :] = v_param[t0 + j]
+
+
+def _dequant_u4_rows(packed, prm):
+    """quantization.cuh:59-84: float(nibble) * scale - zero, element 2j in the low nibble.  packed u8 [S, D/2],
+    prm f16 [S, 2] -> float64 [S, D]."""
+    u = np.empty((packed.shape[0], packed.shape[1] * 2), dtype=np.float64)
+    u[:, 0::2] = packed & 0xF
+    u[:, 1::2] = packed >> 4
+    p = prm.astype(np.float64)
+    return u * p[:, 0:1] - p[:, 1:2]
+
+
+def _rope_llama(x, pos, theta=1e4):
+    """decode.cuh:40-72 (apply_llama_rope): pairs (i, i + D/2), freq_i = theta^(-2 (i mod D/2) / D).  x [.., S, D],
+    pos [S]."""
+    D = x.shape[-1]
+    i = np.arange(D) % (D // 2)
+    freq = (1.0 / theta) ** (2.0 * i / D)
+    ang = np.asarray(pos, dtype=np.float64)[:, None] * freq[None, :]
+    rot = np.concatenate([-x[..., D // 2:], x[..., :D // 2]], axis=-1)
+    return x * np.cos(ang) + rot * np.sin(ang)
+
+
+def batch_decode_i4(q16, data, param, indptr, indices, last_page_offset, layer, theta=1e4):
+    """BatchDecodeWithPagedKVCacheKernel (decode.cuh:480-676) as called by flashinfer_impl.cuh:9-46: RoPE (llama) on q at
+    position seq_len-1 and on every de-quantised key at its own position, sm_scale = 1/sqrt(D), softmax, P.V on the
+    de-quantised values; FP64 here.  q16 f16 [B, N, D] -> float64 [B, N, D]."""
+    B, N, D = q16.shape
+    P = data.shape[4]
+    out = np.zeros((B, N, D), dtype=np.float64)
+    for b in range(B):
+        S = kv_seq_len(indptr, last_page_offset, P, b)
+        pages = [int(x) for x in indices[int(indptr[b]):int(indptr[b + 1])]]
+        for h in range(N):
+            kp = np.concatenate([data[pg, layer, 0, h] for pg in pages], axis=0)[:S]
+            vp = np.concatenate([data[pg, layer, 1, h] for pg in pages], axis=0)[:S]
+            kq = np.concatenate([param[pg, layer, 0, h] for pg in pages], axis=0)[:S]
+            vq = np.concatenate([param[pg, layer, 1, h] for pg in pages], axis=0)[:S]
+            kf = _rope_llama(_dequant_u4_rows(kp, kq), np.arange(S), theta)
+            vf = _dequant_u4_rows(vp, vq)
+            qf = _rope_llama(q16[b, h].astype(np.float64)[None, :], [S - 1], theta)[0]
+            s = kf @ qf / np.sqrt(D)
+            p = np.exp(s - s.max())
+            out[b, h] = (p / p.sum()) @ vf
+    return out
