@@ -97,14 +97,19 @@ struct DecodeParams {
   float sm_scale, log2_theta, rope_inv_scale;
 };
 
-// 8 packed u4 -> 8 floats (element 2j in the low nibble of byte j)
-__device__ __forceinline__ void nib8(unsigned x, float (&f)[8]) {
-  const unsigned lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
-  f[0] = (float)(lo & 0xFF); f[1] = (float)(hi & 0xFF);
-  f[2] = (float)((lo >> 8) & 0xFF); f[3] = (float)((hi >> 8) & 0xFF);
-  f[4] = (float)((lo >> 16) & 0xFF); f[5] = (float)((hi >> 16) & 0xFF);
-  f[6] = (float)(lo >> 24); f[7] = (float)(hi >> 24);
+// 8 packed u4 (nibble e at bits 4e) -> 4 half2 registers holding 1024 + nibble: m[k] = {1024 + n_k, 1024 + n_(k+4)}.
+// (x >> 4k) & 0x000F000F | 0x64006400 is one v_and_or_b32 (plus one shift for k > 0): 7 instructions per 8 elements,
+// and v_fma_mix_f32 reads the halves directly.  The bias 1024 is removed once per token, never per element.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nib8h(unsigned x, h2 (&m)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned r;                                        // hipcc emits v_and + v_or for the C expression
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x >> (4 * k)), "s"(0x000F000Fu), "v"(0x64006400u));
+    m[k] = __builtin_bit_cast(h2, r);
+  }
 }
+constexpr float kNibBias = 1024.0f;
 
 __device__ __forceinline__ float quad_sum_f(float x) {
   x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -112,7 +117,37 @@ __device__ __forceinline__ float quad_sum_f(float x) {
   return x;
 }
 
-__global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
+// sin / cos of 2*pi*rev (v_sin_f32 / v_cos_f32 take revolutions; the reference uses the __sincosf fast intrinsic too,
+// decode.cuh:63-66)
+__device__ __forceinline__ void sincos_rev(float rev, float &s, float &c) {
+  const float fr = rev - floorf(rev);
+  s = __builtin_amdgcn_sinf(fr);
+  c = __builtin_amdgcn_cosf(fr);
+}
+
+struct TileRegs {     // one 16-token tile's operands of this lane, as loaded
+  v2u k1, k2;         // K dims [16u,16u+16) and [64+16u, 64+16u+16)
+  v4u v;              // V dims [32u, 32u+32)
+  unsigned kq, vq;    // (scale, zero) half2 of my token
+};
+
+__device__ __forceinline__ TileRegs load_tile(const DecodeParams &p, int pg0, int tile, int tpp, int t, int u, int h) {
+  const int N = p.kv.N, P = p.kv.P;
+  const int64_t page = p.kv.indices[pg0 + tile / tpp];
+  const int e = (tile % tpp) * 16 + t;                  // entry inside the page
+  const int64_t base = ((page * p.kv.L + p.kv.layer) * 2 * N + h) * P;             // K block of (page, layer, head)
+  const uint8_t *kp = p.kv.data + (base + e) * 64;
+  const uint8_t *vp = kp + (int64_t)N * P * 64;
+  TileRegs r;
+  r.k1 = *reinterpret_cast<const v2u *>(kp + 8 * u);
+  r.k2 = *reinterpret_cast<const v2u *>(kp + 32 + 8 * u);
+  r.v = *reinterpret_cast<const v4u *>(vp + 16 * u);
+  r.kq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + e) * 2);
+  r.vq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + (int64_t)N * P + e) * 2);
+  return r;
+}
+
+__global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   const int lane = threadIdx.x;
   const int t = lane >> 2, u = lane & 3;
   const int N = p.kv.N, P = p.kv.P;
@@ -124,7 +159,11 @@ __global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
   const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
   const int tpp = P >> 4;                               // 16-token tiles per page
 
-  // q rotated to the relative position of MY token of the first tile, and the per-tile back-rotation
+  TileRegs cur, nxt;                                    // two tiles in flight ahead of the one being computed
+  if (tile0 < tile1) cur = load_tile(p, pg0, tile0, tpp, t, u, h);
+  if (tile0 + 1 < tile1) nxt = load_tile(p, pg0, tile0 + 1, tpp, t, u, h);
+
+  // q rotated to the relative position of MY token of the first tile: A = R((len-1 - j) f) q, pairs (i, i+64)
   float A1[16], A2[16], C16[16], S16[16];
   {
     const half_t *qp = p.q + ((int64_t)b * N + h) * kHeadDim;
@@ -133,18 +172,19 @@ __global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
     r1[1] = *reinterpret_cast<const v4u *>(qp + 16 * u + 8);
     r2[0] = *reinterpret_cast<const v4u *>(qp + 64 + 16 * u);
     r2[1] = *reinterpret_cast<const v4u *>(qp + 64 + 16 * u + 8);
-    const half_t *h1 = reinterpret_cast<const half_t *>(r1), *h2 = reinterpret_cast<const half_t *>(r2);
+    const half_t *h1 = reinterpret_cast<const half_t *>(r1), *h2p = reinterpret_cast<const half_t *>(r2);
     const float delta = (float)((seq_len - 1) - (tile0 * 16 + t));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      // decode.cuh:535-539: freq = rope_inv_scale * theta^(-2 (i mod 64) / 128)
-      const float f = p.rope_inv_scale * exp2f(-p.log2_theta * (float)(2 * (16 * u + i)) * (1.0f / kHeadDim));
+      // decode.cuh:535-539: freq = rope_inv_scale * theta^(-2 (i mod 64) / 128); here in revolutions
+      const float fr = p.rope_inv_scale * 0.15915494309189535f *
+                       __builtin_amdgcn_exp2f(-p.log2_theta * (float)(2 * (16 * u + i)) * (1.0f / kHeadDim));
       float s, c;
-      sincosf(delta * f, &s, &c);
-      const float q1 = (float)h1[i], q2 = (float)h2[i];
-      A1[i] = q1 * c - q2 * s;                          // R(+delta) q
+      sincos_rev(delta * fr, s, c);
+      const float q1 = (float)h1[i], q2 = (float)h2p[i];
+      A1[i] = q1 * c - q2 * s;
       A2[i] = q2 * c + q1 * s;
-      sincosf(16.0f * f, &S16[i], &C16[i]);
+      sincos_rev(16.0f * fr, S16[i], C16[i]);
     }
   }
 
@@ -155,34 +195,31 @@ __global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
   const float qk_scale = p.sm_scale * kLog2e;           // decode.cuh:500: softmax in base 2
 
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int64_t page = p.kv.indices[pg0 + tile / tpp];
-    const int e = (tile % tpp) * 16 + t;                // entry inside the page
-    const int64_t base = ((page * p.kv.L + p.kv.layer) * 2 * N + h) * P;           // K block of (page, layer, head)
-    const uint8_t *kp = p.kv.data + (base + e) * 64;
-    const uint8_t *vp = kp + (int64_t)N * P * 64;
-    const v2u k1 = *reinterpret_cast<const v2u *>(kp + 8 * u);
-    const v2u k2 = *reinterpret_cast<const v2u *>(kp + 32 + 8 * u);
-    const v4u vv = *reinterpret_cast<const v4u *>(vp + 16 * u);
-    const unsigned kq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + e) * 2);
-    const unsigned vq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + (int64_t)N * P + e) * 2);
+    const TileRegs r = cur;
+    cur = nxt;
+    if (tile + 2 < tile1) nxt = load_tile(p, pg0, tile + 2, tpp, t, u, h);
     const bool valid = tile * 16 + t < seq_len;
 
-    // scores: sum over my 16 pairs of (u1*s - z) * A1 + (u2*s - z) * A2
-    const float ks = (float)__builtin_bit_cast(half_t, (unsigned short)(kq & 0xFFFF));
-    const float nkz = -(float)__builtin_bit_cast(half_t, (unsigned short)(kq >> 16));
-    float acc = 0.f;
+    // score = sum over my 16 pairs of (u1*ks - kz) * A1 + (u2*ks - kz) * A2 = ks * sum((1024+u) . A) - (kz + 1024 ks) * sum(A)
+    float acc = 0.f, sumA = 0.f;
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-      float f1[8], f2[8];
-      nib8(k1[w], f1);
-      nib8(k2[w], f2);
+      h2 m1[4], m2[4];
+      nib8h(r.k1[w], m1);
+      nib8h(r.k2[w], m2);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        acc = __builtin_fmaf(__builtin_fmaf(f1[i], ks, nkz), A1[8 * w + i], acc);
-        acc = __builtin_fmaf(__builtin_fmaf(f2[i], ks, nkz), A2[8 * w + i], acc);
+      for (int k = 0; k < 4; ++k) {
+        acc = __builtin_fmaf((float)m1[k].x, A1[8 * w + k], acc);
+        acc = __builtin_fmaf((float)m1[k].y, A1[8 * w + 4 + k], acc);
+        acc = __builtin_fmaf((float)m2[k].x, A2[8 * w + k], acc);
+        acc = __builtin_fmaf((float)m2[k].y, A2[8 * w + 4 + k], acc);
       }
     }
-    float s = quad_sum_f(acc) * qk_scale;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sumA += A1[i] + A2[i];
+    const float ks = (float)__builtin_bit_cast(half_t, (unsigned short)(r.kq & 0xFFFF));
+    const float kz = (float)__builtin_bit_cast(half_t, (unsigned short)(r.kq >> 16));
+    float s = quad_sum_f(__builtin_fmaf(acc, ks, -(__builtin_fmaf(kNibBias, ks, kz) * sumA))) * qk_scale;
     if (!valid) s = -INFINITY;
     // online softmax of this quad's token subsequence (decode.cuh update_partial_state / state.cuh)
     const float mn = fmaxf(m, s);
@@ -196,23 +233,26 @@ __global__ __launch_bounds__(64) void batch_decode_kernel(DecodeParams p) {
     }
     const float pr = valid ? __builtin_amdgcn_exp2f(s - m) : 0.f;
     d += pr;
-    const float vs = (float)__builtin_bit_cast(half_t, (unsigned short)(vq & 0xFFFF));
-    const float vz = (float)__builtin_bit_cast(half_t, (unsigned short)(vq >> 16));
+    const float vs = (float)__builtin_bit_cast(half_t, (unsigned short)(r.vq & 0xFFFF));
+    const float vz = (float)__builtin_bit_cast(half_t, (unsigned short)(r.vq >> 16));
     const float ps = pr * vs;
-    zacc = __builtin_fmaf(pr, vz, zacc);
+    zacc = __builtin_fmaf(pr, __builtin_fmaf(kNibBias, vs, vz), zacc);     // o = sum ps*(1024+u) - sum pr*(vz + 1024 vs)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      float f[8];
-      nib8(vv[w], f);
+      h2 mv[4];
+      nib8h(r.v[w], mv);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[8 * w + i] = __builtin_fmaf(ps, f[i], o[8 * w + i]);
+      for (int k = 0; k < 4; ++k) {
+        o[8 * w + k] = __builtin_fmaf(ps, (float)mv[k].x, o[8 * w + k]);
+        o[8 * w + 4 + k] = __builtin_fmaf(ps, (float)mv[k].y, o[8 * w + 4 + k]);
+      }
     }
-    // my token of the next tile is 16 positions later: turn q back by 16*f
+    // my token of the next tile is 16 positions later: A <- R(-16 f) A = (A1 C + A2 S, A2 C - A1 S)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float a1 = A1[i], a2 = A2[i];
       A1[i] = __builtin_fmaf(a1, C16[i], a2 * S16[i]);
-      A2[i] = __builtin_fmaf(a2, C16[i], -(a1 * S16[i]));
+      A2[i] = __builtin_fmaf(-a1, S16[i], a2 * C16[i]);
     }
   }
 
@@ -284,12 +324,13 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
   return ATOM_OK;
 }
 
-// KV splits so that batch*heads*splits waves fill the chip (about 8 waves per CU), at least 2 tiles per split
+// KV splits so that batch*heads*splits waves give the chip about two rounds of its 12 resident waves per CU, at least 8
+// tiles per split (a split costs a prologue of 32 sincos and a 16-quad merge)
 static int decode_splits(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
   const int64_t tiles = (int64_t)max_pages * (P / 16);
-  int64_t s = (2048 + (int64_t)batch * N - 1) / ((int64_t)batch * N);
-  if (s > tiles / 2) s = tiles / 2;
+  int64_t s = (6144 + (int64_t)batch * N - 1) / ((int64_t)batch * N);      // ~2 rounds of 12 resident waves per CU
+  if (s > tiles / 8) s = tiles / 8;                                        // prologue + merge cost about 2 tiles
   if (s > 64) s = 64;
   return s < 2 ? 1 : (int)s;
 }
