@@ -233,8 +233,11 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     }
     const float pr = valid ? __builtin_amdgcn_exp2f(s - m) : 0.f;
     d += pr;
-    const float vs = (float)__builtin_bit_cast(half_t, (unsigned short)(r.vq & 0xFFFF));
-    const float vz = (float)__builtin_bit_cast(half_t, (unsigned short)(r.vq >> 16));
+    // entries past the sequence end are uninitialised memory (possibly NaN / Inf parameters): they must contribute
+    // exactly nothing (the reference guards the whole update, decode.cuh:153)
+    const unsigned vq = valid ? r.vq : 0u;
+    const float vs = (float)__builtin_bit_cast(half_t, (unsigned short)(vq & 0xFFFF));
+    const float vz = (float)__builtin_bit_cast(half_t, (unsigned short)(vq >> 16));
     const float ps = pr * vs;
     zacc = __builtin_fmaf(pr, __builtin_fmaf(kNibBias, vs, vz), zacc);     // o = sum ps*(1024+u) - sum pr*(vz + 1024 vs)
 #pragma unroll

@@ -1,14 +1,18 @@
 """``LinearInt4`` / ``LlamaRMSNormInt4`` / ``LlamaMLP`` over atom_amd.ops -- the reference's real-kernel call graph
 (e2e/punica-atom/punica/models/llama.py:35-87, 233-244) with the same parameter names, shapes and dtypes, so a state
 dict written for the reference classes loads here.  Kernel-flavoured arithmetic and the replicated scale layout, i.e.
-exactly what the reference's CUDA ops compute.  (Attention / paged INT4 KV: out of the hot-path scope, SURVEY 2a #12.)
+exactly what the reference's CUDA ops compute.  ``LlamaAttention`` / ``LlamaDecoderLayer`` (reference llama.py:90-292)
+run the INT4 paged-KV ops of csrc/kv_i4.hip.
 """
 from __future__ import annotations
 
 import torch
 from torch import nn
 
+import math
+
 from .. import ops
+from ..utils import BatchedKvCacheInt4, BatchLenInfo
 
 GROUP = 128
 
@@ -80,3 +84,104 @@ class LlamaMLP(nn.Module):
 
     def forward(self, x):
         return self.down_proj(ops.activate_fp16_i4(self.gate_proj(x), self.up_proj(x)))
+
+
+def dequant_kv_u4(packed: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
+    """[T, heads, 64] u8 + [T, heads, 2] fp16 (scale, zero) -> [T, heads, 128] fp32: nibble * scale - zero, element 2j in
+    the low nibble (quantization.cuh:59-84)."""
+    u = torch.stack([packed & 0xF, packed >> 4], dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2).float()
+    p = param.float()
+    return u * p[..., 0:1] - p[..., 1:2]
+
+
+def rope_llama(x: torch.Tensor, pos: torch.Tensor, theta: float = 1e4) -> torch.Tensor:
+    """x [T, heads, 128] fp32, pos [T]: pairs (i, i + 64), freq_i = theta^(-2i/128) (decode.cuh:40-72)."""
+    d = x.shape[-1]
+    inv = theta ** (-torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d)
+    ang = pos.to(torch.float32)[:, None] * inv[None, :]
+    cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :]
+    sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+    rot = torch.cat([-x[..., d // 2:], x[..., :d // 2]], -1)
+    return x * cos + rot * sin
+
+
+class LlamaAttention(nn.Module):
+    """reference llama.py:90-230: q/k/v projections (k, v with the u4 epilogue), KV written to the INT4 paged cache,
+    decode requests through the RoPE-fused batch-decode kernel, output reordered + quantised + projected.
+    Prefill requests: the reference attends to RANDOM keys and values there (llama.py:164-167, "HACK": a latency
+    harness); this class attends to the de-quantised projections it has just written to the cache (causal, RoPE at
+    positions 0..len-1) -- the values a later decode step reads back."""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self._scale = 1 / math.sqrt(self.head_dim)
+        self.layer_idx = layer_idx
+        if self.head_dim * self.num_heads != self.hidden_size:
+            raise ValueError(f"hidden_size {self.hidden_size} is not divisible by num_heads {self.num_heads}")
+        if self.head_dim != 128:
+            raise ValueError("the INT4 KV kernels are built for head_dim 128 (as the reference's, punica_ops.cc:112)")
+        self.q_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False)
+        self.k_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False)
+        self.v_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False)
+        self.o_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False)
+        self.reorder_index = nn.Parameter(torch.randperm(self.hidden_size).to(torch.int16), requires_grad=False)
+        self.rope_theta = float(getattr(config, "rope_theta", 1e4))
+
+    def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv: BatchedKvCacheInt4 | None,
+                decode_kv: BatchedKvCacheInt4 | None) -> torch.Tensor:
+        q_proj = self.q_proj(hidden_states)
+        k_u4, k_sz = self.k_proj(hidden_states)
+        v_u4, v_sz = self.v_proj(hidden_states)
+        nh, hd = self.num_heads, self.head_dim
+        outs = []
+        if len(blen.prefills) > 0:
+            assert prefill_kv is not None
+            k = k_u4[:blen.doff].view(-1, nh, hd // 2)
+            v = v_u4[:blen.doff].view(-1, nh, hd // 2)
+            ks = k_sz[:blen.doff].view(-1, nh, 2)
+            vs = v_sz[:blen.doff].view(-1, nh, 2)
+            ops.init_kv_i4(prefill_kv, k, v, ks, vs, blen.indptr, self.layer_idx)
+            kf, vf = dequant_kv_u4(k, ks), dequant_kv_u4(v, vs)
+            beg = 0
+            for q_len in blen.prefills:
+                sl = slice(beg, beg + q_len)
+                pos = torch.arange(q_len, device=q_proj.device)
+                q = rope_llama(q_proj[sl].view(q_len, nh, hd).float(), pos, self.rope_theta).transpose(0, 1)
+                kk = rope_llama(kf[sl], pos, self.rope_theta).transpose(0, 1)
+                o = torch.nn.functional.scaled_dot_product_attention(q, kk, vf[sl].transpose(0, 1), is_causal=True)
+                outs.append(o.transpose(0, 1).reshape(q_len, self.hidden_size).to(q_proj.dtype))
+                beg += q_len
+        if blen.decode > 0:
+            assert decode_kv is not None
+            q = q_proj[blen.doff:].view(blen.decode, nh, hd)
+            ops.append_kv_i4(decode_kv, k_u4[blen.doff:].view(blen.decode, nh, hd // 2),
+                             v_u4[blen.doff:].view(blen.decode, nh, hd // 2), k_sz[blen.doff:].view(blen.decode, nh, 2),
+                             v_sz[blen.doff:].view(blen.decode, nh, 2), self.layer_idx)
+            o = ops.batch_decode_i4(q.contiguous(), decode_kv, self.layer_idx, rope_theta=self.rope_theta)
+            outs.append(o.view(blen.decode, self.hidden_size))
+        attn = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return self.o_proj(ops.reorder_fp16_i4(attn.contiguous(), self.reorder_index))
+
+
+class LlamaDecoderLayer(nn.Module):
+    """reference llama.py:247-292."""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = LlamaAttention(config=config, layer_idx=layer_idx)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
+        residual = hidden_states
+        hidden_states = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
+        hidden_states = residual + hidden_states
+        residual = hidden_states
+        hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
+        return residual + hidden_states

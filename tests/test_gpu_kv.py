@@ -87,6 +87,23 @@ def test_batch_decode_properties_and_errors():
     o = ops.batch_decode_i4(q, kv, 0)
     ref = O.batch_decode_i4(t2n(q), t2n(pool.buf), t2n(pool.param), *_np_tables(kv), 0)
     assert np.abs(t2n(o) - ref).max() <= 2e-3 * np.abs(ref).max()
+    # entries past a sequence's end are uninitialised memory in real use: NaN / Inf there must not leak into the output
+    from atom_amd.utils.kvcache import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    pool3 = KvPoolInt4(1, 4, 128, 8, 16, torch.device("cuda"))
+    pool3.buf.fill_(0xFF)
+    pool3.param.fill_(float("nan"))
+    c3 = [KvCacheInt4(pool3, 21), KvCacheInt4(pool3, 3)]
+    kv3 = BatchedKvCacheInt4(c3)
+    T = 24
+    ops.init_kv_i4(kv3, torch.randint(0, 256, (T, 4, 64), device="cuda", dtype=torch.uint8),
+                   torch.randint(0, 256, (T, 4, 64), device="cuda", dtype=torch.uint8),
+                   (torch.rand((T, 4, 2), device="cuda") + 0.1).half(), (torch.rand((T, 4, 2), device="cuda") + 0.1).half(),
+                   torch.tensor([0, 21, 24], dtype=torch.int32, device="cuda"), 0)
+    o3 = ops.batch_decode_i4(q, kv3, 0)
+    assert torch.isfinite(o3).all()
+    par = t2n(pool3.param)
+    ref3 = O.batch_decode_i4(t2n(q), t2n(pool3.buf), np.nan_to_num(par), *_np_tables(kv3), 0)
+    assert np.abs(t2n(o3) - ref3).max() <= 2e-3 * np.abs(ref3).max() + 1e-3
     data = t2n(pool.buf)
     with pytest.raises(AtomHipError):
         ops.batch_decode_i4(q.cpu(), kv, 0)
