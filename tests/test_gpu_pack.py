@@ -132,3 +132,48 @@ def test_qlinear_gptq_flow_runs_on_the_hip_gemm(golden_dir):
     layer.cpu()
     layer.to("cuda")
     assert layer.packed_weight() is not None and torch.equal(layer(xq), y1)
+
+
+def test_export_packed_loads_into_e2e_modules(tmp_path):
+    """quantise with the B1 modules, save, load into the real-kernel module tree (same parameter names
+    and shapes as the reference's LinearInt4 / LlamaRMSNormInt4) and get the same GEMM result."""
+    from atom_amd import ops
+    from atom_amd.e2e import LinearInt4, LlamaRMSNormInt4
+    from atom_amd.model import export
+    from atom_amd.model.qLinearLayer import QLinearLayer
+    args = types.SimpleNamespace(wbits=4, abits=4, a_sym=True, w_sym=True, act_group_size=128, weight_group_size=128,
+                                 weight_channel_group=2, keeper=128, keeper_precision=3, a_clip_ratio=0.9,
+                                 w_clip_ratio=0.85, kv_clip_ratio=1.0, tiling=0, exponential=False, quant_type="int",
+                                 static=False, reorder=True)
+    torch.manual_seed(0)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up_proj = QLinearLayer(torch.nn.Linear(512, 1408, bias=False).half(), args)
+            self.down_proj = QLinearLayer(torch.nn.Linear(1408, 512, bias=False).half(), args)
+
+    m = Tiny().cuda()
+    for l in (m.up_proj, m.down_proj):
+        l.to("cuda")
+        l.quant()
+    path = str(tmp_path / "tiny.safetensors")
+    export.save_packed(m, path)
+    sd = export.load_packed(path)
+    assert set(sd) == {f"{n}.{k}" for n in ("up_proj", "down_proj") for k in ("weight_int4", "weight_int8", "scale_int4", "scale_int8")}
+
+    class TinyE2E(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up_proj = LinearInt4(512, 1408, out_dtype="fp16")
+            self.down_proj = LinearInt4(1408, 512, out_dtype="fp16")
+
+    e = TinyE2E()
+    missing, unexpected = e.load_state_dict(sd, strict=True), None
+    e = e.cuda()
+    x = torch.randn(33, 512, device="cuda", dtype=torch.float16)
+    act = ops.reorder_fp16_i4(x, None)
+    y = e.up_proj(act)
+    b4, b8, sb, sb8 = m.up_proj.packed_weight()
+    want = ops.dense_layer_gemm_i4_fp16(act[1], b4, act[3], sb, act[0], b8, act[2], sb8)
+    assert torch.equal(y, want)

@@ -159,3 +159,43 @@ def test_pack_is_exact_on_rtn_weights_and_flags_off_grid(golden_dir):
     assert same or np.array_equal(_bits(_dequant_weight(r)), _bits(ref["wq"]))
     n, k = z["W"].shape
     assert O.pack_weight_fq(z["W"], 2)["bad"] == (n // 2) * ((k - 128) // 128) + n   # unquantised: every block off grid
+
+
+def test_kv_oracle_self_consistency():
+    """The INT4 paged-KV restatement (parity unpinned: the reference has no vectors) against an independent dense
+    evaluation: append through the page tables, then decode == plain softmax attention over the de-quantised, RoPE'd
+    rows gathered straight from the inputs."""
+    g = np.random.default_rng(0)
+    C, L, N, P, D = 12, 2, 4, 16, 128
+    data = np.zeros((C, L, 2, N, P, D // 2), np.uint8)
+    param = np.zeros((C, L, 2, N, P, 2), np.float16)
+    seqs = [37, 5, 16]
+    perm = list(g.permutation(C))
+    indptr, indices, lpo = [0], [], []
+    for s in seqs:
+        nb = -(-s // P)
+        indices += [perm.pop() for _ in range(nb)]
+        indptr.append(indptr[-1] + nb)
+        lpo.append((s - 1) % P + 1)
+    T = sum(seqs)
+    ai = np.cumsum([0] + seqs)
+    k = g.integers(0, 256, (T, N, D // 2), dtype=np.uint8)
+    v = g.integers(0, 256, (T, N, D // 2), dtype=np.uint8)
+    kp = (g.random((T, N, 2)) * 0.1 + 0.01).astype(np.float16)
+    vp = (g.random((T, N, 2)) * 0.1 + 0.01).astype(np.float16)
+    O.kv_append_i4(data, param, indptr, indices, lpo, k, v, kp, vp, 1, ai)
+    assert not data[:, 0].any()                                   # other layer untouched
+    q = g.standard_normal((3, N, D)).astype(np.float16)
+    o = O.batch_decode_i4(q, data, param, indptr, indices, lpo, 1)
+    for b, s in enumerate(seqs):
+        for h in range(N):
+            sl = slice(ai[b], ai[b + 1])
+            kf = O._rope_llama(O._dequant_u4_rows(k[sl, h], kp[sl, h]), np.arange(s))
+            vf = O._dequant_u4_rows(v[sl, h], vp[sl, h])
+            qf = O._rope_llama(q[b, h].astype(np.float64)[None], [s - 1])[0]
+            w = np.exp(kf @ qf / np.sqrt(D))
+            assert np.allclose(o[b, h], (w / w.sum()) @ vf, rtol=1e-10, atol=1e-12)
+    # RoPE is a rotation of the (i, i+64) pairs: norms are preserved, position 0 is the identity
+    x = g.standard_normal((5, D))
+    assert np.allclose(np.linalg.norm(O._rope_llama(x, np.arange(5)), axis=1), np.linalg.norm(x, axis=1))
+    assert np.allclose(O._rope_llama(x[:1], [0]), x[:1])
