@@ -38,6 +38,8 @@ SIGNATURES = {
     "atom_reorder_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_rmsnorm_reorder_quant_f16": (_int, [_vp, _vp, _f32, _vp, _i64, _int, _int, _f32, _int,
                                               _vp, _vp, _vp, _vp, _vp, _vp]),
+    "atom_add_rmsnorm_reorder_quant_f16": (_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _int, _int, _f32, _int,
+                                                  _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_silu_mul_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_quant_weight_w4": (_int, [_vp, _i64, _i64, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_pack_weight_w4": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -29,11 +29,13 @@
 
 namespace atom {
 
-enum ActOp { OP_REORDER = 0, OP_RMSNORM = 1, OP_SILU_MUL = 2 };
+enum ActOp { OP_REORDER = 0, OP_RMSNORM = 1, OP_SILU_MUL = 2, OP_ADD_RMSNORM = 3 };
 
 struct ActQuantParams {
   const half_t *x;        // reorder / rmsnorm: [M,H];  silu_mul: a [M,H]
   const half_t *b;        // rmsnorm: weight [H];       silu_mul: b [M,H]
+  const half_t *res;      // add_rmsnorm: residual [M,H]
+  half_t *res_out;        // add_rmsnorm: x + residual [M,H] (may alias res)
   const int16_t *idx;     // reorder index [H] (reorder / rmsnorm)
   int64_t M;
   int H;
@@ -184,8 +186,10 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   const int Gt = H >> 7;
   const int K4h = (H - kKeeper) >> 1;
   const int nchunks = H >> 3;                               // 16-byte chunks per row
+  constexpr bool ADD = OP == OP_ADD_RMSNORM, NORM = OP == OP_RMSNORM || ADD;
   const int bufbytes = ((H * 2 + 1023) & ~1023);            // DMA blocks are 1 KiB (64 lanes x 16 B)
-  double *red = reinterpret_cast<double *>(smem + 2 * bufbytes);   // [2][4] partial sums of squares
+  const int stage = ADD ? 2 * bufbytes : bufbytes;          // ADD stages two rows: x, then the residual
+  double *red = reinterpret_cast<double *>(smem + 2 * stage);      // [2][4] partial sums of squares
   const int j = tid & 7;
 
   // loop-invariant per-thread state: LDS byte offsets of my channels, gathered RMSNorm weights
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) off[ps][k] = (e0 + k) * 2;
     }
-    if constexpr (OP == OP_RMSNORM) {
+    if constexpr (NORM) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) wg[ps][k] = (float)p.b[off[ps][k] >> 1];
     }
@@ -214,12 +218,16 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 
   auto issue_row = [&](int64_t r, int b) {                  // DMA row r into buffer b
     const char *src = reinterpret_cast<const char *>(p.x + r * (int64_t)H);
+    const char *src2 = reinterpret_cast<const char *>(p.res + r * (int64_t)H);
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i) {
       const int blk = i * 4 + wave;                         // 1 KiB block
       if (blk * 64 < nchunks) {
         const int c = min(blk * 64 + lane, nchunks - 1);    // tail lanes re-read the last chunk into the padding
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 16), (lptr_t)(smem + b * bufbytes + blk * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 16), (lptr_t)(smem + b * stage + blk * 1024), 16, 0, 0);
+        if constexpr (ADD)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src2 + c * 16), (lptr_t)(smem + b * stage + bufbytes + blk * 1024),
+                                           16, 0, 0);
       }
     }
   };
@@ -232,7 +240,34 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
     __syncthreads();
     const int64_t rn = r + gridDim.x;
     if (rn < p.M) issue_row(rn, b ^ 1);
-    const char *row = smem + b * bufbytes;
+    char *row = smem + b * stage;
+
+    double ss = 0.0;
+    if constexpr (ADD) {
+      // x + residual (one fp16 add per element, as torch's half add), written back to the residual stream and kept in
+      // LDS for the gather; the sum of squares is taken here, on the linear data
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < 2 * NP; ++i) {
+        const int c = (i * 4 + wave) * 64 + lane;
+        if (c < nchunks) {
+          const h8 a = *reinterpret_cast<const h8 *>(row + c * 16);
+          const h8 rr = *reinterpret_cast<const h8 *>(row + bufbytes + c * 16);
+          const h8 sum = a + rr;
+          *reinterpret_cast<h8 *>(row + c * 16) = sum;
+          *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.res_out + r * (int64_t)H) + c * 16) = sum;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const double d = (double)(float)sum[k];
+            ss = __builtin_fma(d, d, ss);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      if (lane == 0) red[b * 4 + wave] = ss;
+      __syncthreads();                                      // sums visible to the gather, partial sums to everyone
+    }
 
     float x[NP][16];
 #pragma unroll
@@ -249,22 +284,23 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
         for (int k = 0; k < 16; ++k) x[ps][k] = (float)hv[k];
       }
     }
-    if constexpr (OP == OP_RMSNORM) {
-      // sum of squares in FP64 (fp16 squares are exact), rounded to FP32 once -> order-independent
-      double ss = 0.0;
+    if constexpr (NORM) {
+      if constexpr (!ADD) {
+        // sum of squares in FP64 (fp16 squares are exact), rounded to FP32 once -> order-independent
 #pragma unroll
-      for (int ps = 0; ps < NP; ++ps)
-        if (ps * 256 + tid < nslots) {
+        for (int ps = 0; ps < NP; ++ps)
+          if (ps * 256 + tid < nslots) {
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const double d = (double)x[ps][k];
-            ss = __builtin_fma(d, d, ss);                   // d*d is exact in FP64: same value as ss + d*d
+            for (int k = 0; k < 16; ++k) {
+              const double d = (double)x[ps][k];
+              ss = __builtin_fma(d, d, ss);                 // d*d is exact in FP64: same value as ss + d*d
+            }
           }
-        }
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-      if (lane == 0) red[b * 4 + wave] = ss;
-      __syncthreads();
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+        if (lane == 0) red[b * 4 + wave] = ss;
+        __syncthreads();
+      }
       const double tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
       const float var = (float)(tot / (double)H);
       const float rinv = 1.0f / sqrtf(var + p.eps);         // correctly rounded sqrt and divide
@@ -342,7 +378,7 @@ static int resident_blocks(K kernel, size_t lds) {           // persistent grid:
 
 template <int OP, bool SIM, bool DQ, int NP>
 static void launch_act_quant2_np(const ActQuantParams &p, hipStream_t s) {
-  const size_t lds = 2 * (size_t)((p.H * 2 + 1023) & ~1023) + 64;
+  const size_t lds = (OP == OP_ADD_RMSNORM ? 4 : 2) * (size_t)((p.H * 2 + 1023) & ~1023) + 64;
   // occupancy depends on the LDS size, i.e. on H; cache the last answer (benign race: same inputs, same value)
   static size_t cached_lds = 0;
   static int resident = 0;
@@ -372,6 +408,8 @@ static void launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
 static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_layout, void *stream) {
   if (!p.x || !p.o8 || !p.o4 || !p.s8 || !p.s4) return ATOM_ERR_INVALID_ARG;
   if (op != OP_REORDER && !p.b) return ATOM_ERR_INVALID_ARG;
+  if (op == OP_ADD_RMSNORM && (!p.res || !p.res_out)) return ATOM_ERR_INVALID_ARG;
+  if (op == OP_ADD_RMSNORM && (!aligned16(p.res) || !aligned16(p.res_out))) return ATOM_ERR_ALIGN;
   p.wide = (quant_mode & ATOM_QUANT_WIDE_CODES) != 0;
   quant_mode &= ~ATOM_QUANT_WIDE_CODES;
   if (quant_mode != ATOM_QUANT_KERNEL && quant_mode != ATOM_QUANT_SIM) return ATOM_ERR_INVALID_ARG;
@@ -393,6 +431,7 @@ static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_
   switch (op) {
     case OP_REORDER: ATOM_LAUNCH2(OP_REORDER) break;
     case OP_RMSNORM: ATOM_LAUNCH2(OP_RMSNORM) break;
+    case OP_ADD_RMSNORM: ATOM_LAUNCH2(OP_ADD_RMSNORM) break;
     default: ATOM_LAUNCH2(OP_SILU_MUL) break;
   }
 #undef ATOM_LAUNCH2
@@ -626,6 +665,19 @@ int atom_rmsnorm_reorder_quant_f16(const void *x, const void *weight, float eps,
   p.o8 = (int8_t *)o_outliers; p.o4 = (uint8_t *)o_norms; p.s8 = (half_t *)outlier_scales;
   p.s4 = (half_t *)norm_scales; p.xq = (half_t *)xq_f16;
   return launch_act_quant(OP_RMSNORM, p, quant_mode, scale_layout, stream);
+}
+
+int atom_add_rmsnorm_reorder_quant_f16(const void *x, const void *residual, void *residual_out, const void *weight,
+                                       float eps, const int16_t *reorder_index, int64_t M, int hidden, int quant_mode, float clip,
+                                       int scale_layout, void *o_outliers, void *o_norms, void *outlier_scales,
+                                       void *norm_scales, void *xq_f16, void *stream) {
+  ActQuantParams p{};
+  p.x = (const half_t *)x; p.res = (const half_t *)residual; p.res_out = (half_t *)residual_out;
+  p.b = (const half_t *)weight; p.eps = eps;
+  p.idx = reorder_index; p.M = M; p.H = hidden; p.clip = clip;
+  p.o8 = (int8_t *)o_outliers; p.o4 = (uint8_t *)o_norms; p.s8 = (half_t *)outlier_scales;
+  p.s4 = (half_t *)norm_scales; p.xq = (half_t *)xq_f16;
+  return launch_act_quant(OP_ADD_RMSNORM, p, quant_mode, scale_layout, stream);
 }
 
 int atom_silu_mul_quant_f16(const void *a, const void *b, int64_t M, int hidden, int quant_mode, float clip,

@@ -69,6 +69,11 @@ class LlamaRMSNormInt4(nn.Module):
     def forward(self, hidden_states):
         return ops.rmsnorm_fp16_i4(hidden_states, self.weight, self.reorder_index, self.variance_epsilon)
 
+    def forward_add(self, x, residual):
+        """(x + residual, quantised RMSNorm of it) in one kernel -- the residual add of reference llama.py:268-275 fused."""
+        out = ops.add_rmsnorm_fp16_i4(x, residual, self.weight, self.reorder_index, self.variance_epsilon)
+        return out[0], out[1:]
+
 
 class LlamaMLP(nn.Module):
     """reference llama.py:71-87: down( activate_fp16_i4( gate(x), up(x) ) )."""
@@ -179,9 +184,6 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
-        residual = hidden_states
-        hidden_states = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
-        hidden_states = residual + hidden_states
-        residual = hidden_states
-        hidden_states = self.mlp(self.post_attention_layernorm(hidden_states))
-        return residual + hidden_states
+        attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
+        residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
+        return residual + self.mlp(normed)

@@ -100,6 +100,28 @@ def rmsnorm_fp16_i4(hidden_states: torch.Tensor, weight: torch.Tensor, reorder_i
     return _ret(*outs)
 
 
+def add_rmsnorm_fp16_i4(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, reorder_index: torch.Tensor,
+                        eps: float, *, inplace=False, quant_mode="kernel", clip=1.0, scale_layout="ref",
+                        return_dequant=False, wide_codes=False):
+    """NEW (no reference op): s = x + residual (fp16), then rmsnorm_fp16_i4(s, ...) -- the residual add
+    of the decoder layer (llama.py:266-282) fused into the following RMSNorm-quant kernel.  Returns (s, *quant outputs);
+    ``inplace`` writes s over ``residual``."""
+    _require_cuda_half(x, "x")
+    _require_cuda_half(residual, "residual")
+    _require_cuda_half(weight, "weight")
+    assert x.shape == residual.shape and reorder_index.dtype == torch.int16 and reorder_index.is_cuda
+    bs, hidden_dim = x.shape
+    s = residual if inplace else torch.empty_like(residual)
+    outs = _alloc_act_outputs(bs, hidden_dim, x.device, scale_layout, return_dequant, wide_codes)
+    st = L.lib().atom_add_rmsnorm_reorder_quant_f16(x.data_ptr(), residual.data_ptr(), s.data_ptr(), weight.data_ptr(),
+                                                     float(eps), reorder_index.data_ptr(), bs, hidden_dim,
+                                                     _mode(quant_mode, wide_codes), clip, _LAYOUTS[scale_layout],
+                                                     outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                                     outs[3].data_ptr(), L.ptr(outs[4]), L.current_stream(x.device))
+    L.check(st, "atom_add_rmsnorm_reorder_quant_f16")
+    return (s,) + tuple(_ret(*outs))
+
+
 def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="kernel", clip=1.0,
                     scale_layout="ref", return_dequant=False, wide_codes=False):
     """quant(index_select(x, reorder_index)).  Reference: punica/ops/__init__.py:203-219 ->

@@ -194,3 +194,27 @@ def test_wide_codes_are_the_packed_codes_widened(M, H, mode, clip):
     sp = ops.activate_fp16_i4(xt, b, quant_mode=mode, clip=clip, scale_layout="plain")
     sw = ops.activate_fp16_i4(xt, b, quant_mode=mode, clip=clip, scale_layout="plain", wide_codes=True)
     assert np.array_equal(t2n(sw[1]), wide_codes(O.unpack_int4(t2n(sp[1]).view(np.uint8))))
+
+
+@pytest.mark.parametrize("M,H", [(1, 256), (9, 1024), (33, 4096), (5, 5120), (2, 16384), (600, 512)])
+@pytest.mark.parametrize("mode,clip", [("sim", 0.9), ("kernel", 1.0)])
+def test_add_rmsnorm_is_add_then_rmsnorm(M, H, mode, clip):
+    """atom_add_rmsnorm_reorder_quant_f16 == one fp16 add per element (torch half add) followed by exactly
+    atom_rmsnorm_reorder_quant_f16 (itself bit-exact against the oracle above); also in place."""
+    ops = _ops()
+    g = np.random.default_rng(M + H)
+    x = torch.from_numpy(rand_act(M, H, seed=M + H)).cuda()
+    res = torch.from_numpy((g.standard_normal((M, H)) * 3).astype(np.float16)).cuda()
+    w = torch.from_numpy((1 + 0.1 * g.standard_normal(H)).astype(np.float16)).cuda()
+    idx = torch.from_numpy(g.permutation(H).astype(np.int16)).cuda()
+    s_ref = x + res
+    want = ops.rmsnorm_fp16_i4(s_ref, w, idx, 1e-5, quant_mode=mode, clip=clip, scale_layout="plain", return_dequant=True)
+    got = ops.add_rmsnorm_fp16_i4(x, res, w, idx, 1e-5, quant_mode=mode, clip=clip, scale_layout="plain", return_dequant=True)
+    assert torch.equal(got[0], s_ref)
+    for a, b in zip(got[1:], want):
+        assert torch.equal(a, b)
+    oracle = O.rmsnorm_reorder_quant(t2n(s_ref), t2n(w), 1e-5, t2n(idx), mode, clip)
+    assert np.array_equal(O.unpack_int4(t2n(got[2]).view(np.uint8)), oracle["q4"])
+    res2 = res.clone()
+    got2 = ops.add_rmsnorm_fp16_i4(x, res2, w, idx, 1e-5, inplace=True, quant_mode=mode, clip=clip, scale_layout="plain")
+    assert got2[0] is res2 and torch.equal(res2, s_ref) and torch.equal(got2[2], want[1])
