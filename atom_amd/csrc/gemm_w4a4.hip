@@ -389,15 +389,18 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   return ATOM_OK;
 }
 
-// Split-K policy: shapes that yield fewer than 256 workgroups of the smallest tile are latency-bound (one pass over K per
+// Split-K policy: shapes that yield fewer than 512 workgroups of the smallest tile are latency-bound (one pass over K per
 // workgroup at ~1 us per K-group); split the K loop over up to 8 workgroups and reduce FP32 partials in a second launch.
 static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
   if (M <= gemv_max_m()) return 1;                         // decode kernel
   const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
-  if (tiles >= 256 || nsteps < 8) return 1;
-  int64_t s = 512 / tiles;
-  if (s > 8) s = 8;
+  static const int force = [] { const char *e = getenv("ATOM_SPLITS"); return e ? atoi(e) : 0; }();   // tuning only
+  if (force > 0) return force > nsteps / 2 ? (int)(nsteps / 2) : force;
+  if (tiles >= 512 || nsteps < 8) return 1;
+  int64_t s = 1024 / tiles;                                // measured (profiles/r01_gemm_sweeps.txt): 512x4096x4096 1 -> 4
+  if (s > 8) s = 8;                                        // splits: 38.4 -> 31.3 us; 256x13824x5120 1 -> 2: 51.3 -> 47.2 us
+  if (tiles >= 96 && s > 4) s = 4;
   if (s > nsteps / 4) s = nsteps / 4;
   return s < 2 ? 1 : (int)s;
 }
