@@ -43,6 +43,7 @@ SIGNATURES = {
     "atom_silu_mul_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_quant_weight_w4": (_int, [_vp, _i64, _i64, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_pack_weight_w4": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "atom_kv_fake_quant_f16": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "atom_kv_append_i4": (_int, [_vp] * 10 + [_i64] + [_int] * 6 + [_vp]),
     "atom_batch_decode_i4_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _int]),
     "atom_batch_decode_i4": (_int, [_vp] * 7 + [_int] * 6 + [_f32, _f32, _int, _vp, ctypes.c_size_t, _vp]),

@@ -634,6 +634,78 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(WeightPackParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// KV-cache fake quantisation of the simulated path: asymmetric n-bit per 128-d head vector, FP16 opmath
+//   reference: quantize_attn_k_wrapper / quantize_attn_v_wrapper (model/quant.py:233-257) -> quantize_tensor(sym=False)
+//   (model/quant.py:143-145,173-181).  8 lanes per vector (16 elements each), max / min by DPP, the same exact
+//   3-FMA quotient as the activation quantisers.  Input may be a strided [B, H, S, 128] view (the transposed projection
+//   output), output is contiguous -- what the reference's reshape(-1, 128) ... view(saved_shape) produces.
+struct KvFqParams {
+  const half_t *x;
+  half_t *y;
+  int64_t nvec;
+  int H, S;
+  int64_t sb, sh, ss;    // element strides of x over (batch, head, position); the last dim is contiguous
+  float qmax, clip;
+};
+
+__device__ __forceinline__ float min8(float a) {
+  a = fminf(a, dpp_f<0xB1>(a));
+  a = fminf(a, dpp_f<0x4E>(a));
+  a = fminf(a, dpp_f<0x141>(a));
+  return a;
+}
+
+__device__ __forceinline__ float exact_div_h(float n, float d, float rd) {   // RN_f32(n / d), rd = RN(1/d); fp16-valued n, d
+  const float q0 = n * rd;
+  return __builtin_fmaf(__builtin_fmaf(-q0, d, n), rd, q0);
+}
+
+__global__ __launch_bounds__(256) void kv_fake_quant_kernel(KvFqParams p) {
+  const int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int j = threadIdx.x & 7;
+  const int64_t vc = v < p.nvec ? v : p.nvec - 1;                 // keep all lanes alive for the DPP reductions
+  const int64_t b = vc / ((int64_t)p.H * p.S), h = (vc / p.S) % p.H, sq = vc % p.S;
+  const half_t *src = p.x + b * p.sb + h * p.sh + sq * p.ss + j * 16;
+  v4u raw[2];
+  raw[0] = *reinterpret_cast<const v4u *>(src);
+  raw[1] = *reinterpret_cast<const v4u *>(src + 8);
+  const half_t *hv = reinterpret_cast<const half_t *>(raw);
+  float x[16];
+  float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    x[i] = (float)hv[i];
+    mx = fmaxf(mx, x[i]);
+    mn = fminf(mn, x[i]);
+  }
+  mx = max8(mx);
+  mn = min8(mn);
+  if (p.clip < 1.0f) {                                            // quant.py:176-178 (in-place half multiplies)
+    mx = round_h(mx * p.clip);
+    mn = round_h(mn * p.clip);
+  }
+  const float range = fmaxf(round_h(mx - mn), (float)(half_t)1e-5f);          // (w_max - w_min).clamp(min=1e-5)
+  const float s = round_h(exact_div_h(opaque(range), p.qmax, 1.0f / p.qmax)); // / q_max (qmax = 2^n - 1 is an fp16 value)
+  const float so = opaque(s);
+  const float r0 = __builtin_amdgcn_rcpf(so);
+  const float rs = __builtin_fmaf(__builtin_fmaf(-r0, so, 1.0f), r0, r0);     // RN(1/s), round_probe.cpp
+  const float base = __builtin_amdgcn_fmed3f(rintf(round_h(exact_div_h(-mn, so, rs))), 0.f, p.qmax);   // :180
+  v4u o[2];
+  half_t *ov = reinterpret_cast<half_t *>(o);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    // clamp(round(w / scales) + base, 0, q_max) - base: the half additions are exact below 2048 and saturate above
+    const float c = __builtin_amdgcn_fmed3f(rintf(round_h(exact_div_h(x[i], so, rs))) + base, 0.f, p.qmax);
+    ov[i] = (half_t)__builtin_fmaf(c - base, s, 0.0f);           // exact product, one rounding
+  }
+  if (v < p.nvec) {
+    v4u *dst = reinterpret_cast<v4u *>(p.y + v * 128 + j * 16);
+    dst[0] = o[0];
+    dst[1] = o[1];
+  }
+}
+
 }  // namespace atom
 
 using namespace atom;
@@ -714,6 +786,20 @@ int atom_pack_weight_w4(const void *Wq_f16, int64_t N, int64_t K_total, int chan
   WeightPackParams p{(const half_t *)Wq_f16, N, (int)K_total, channel_group, (uint8_t *)B4,
                      (int8_t *)B8,           (half_t *)sB, (half_t *)sB8, (int *)bad_blocks};
   hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)(N / 2)), dim3(256), 0, s, p);
+  return check_launch();
+}
+
+int atom_kv_fake_quant_f16(const void *x, void *y, int64_t batch, int num_heads, int64_t seq_len, int64_t stride_b,
+                           int64_t stride_h, int64_t stride_s, int n_bits, float clip, void *stream) {
+  if (!x || !y) return ATOM_ERR_INVALID_ARG;
+  if (n_bits < 2 || n_bits > 8 || !(clip > 0.f)) return ATOM_ERR_INVALID_ARG;
+  if (batch < 1 || num_heads < 1 || seq_len < 1 || batch * num_heads * seq_len > (int64_t(1) << 40)) return ATOM_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(y) || (stride_b % 8) || (stride_h % 8) || (stride_s % 8)) return ATOM_ERR_ALIGN;
+  KvFqParams p{(const half_t *)x, (half_t *)y, batch * num_heads * seq_len, num_heads, (int)seq_len, stride_b, stride_h,
+               stride_s, (float)((1 << n_bits) - 1), clip};
+  if (seq_len > 0x7fffffff) return ATOM_ERR_SHAPE;
+  hipLaunchKernelGGL(kv_fake_quant_kernel, dim3((unsigned)((p.nvec + 31) / 32)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p);
   return check_launch();
 }
 

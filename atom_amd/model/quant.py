@@ -189,6 +189,9 @@ def quantize_activation_wrapper(x: torch.Tensor, args) -> torch.Tensor:
 @torch.no_grad()
 def _quantize_head_vectors(w: torch.Tensor, args) -> torch.Tensor:
     assert w.shape[-1] == 128, "KV cache quantization is per 128-d head vector"
+    if w.is_cuda and w.dtype == torch.float16 and w.dim() == 4 and w.stride(-1) == 1 and 2 <= args.abits <= 8 \
+            and all(st % 8 == 0 for st in w.stride()[:3]):
+        return _ops.kv_fake_quant(w, int(args.abits), float(args.kv_clip_ratio))      # one fused HIP kernel
     shape = w.shape
     out = quantize_tensor(w.reshape(-1, 128), n_bits=args.abits, group_size=0, tiling=0, sym=False,
                           clip_ratio=args.kv_clip_ratio)

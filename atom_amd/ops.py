@@ -293,3 +293,17 @@ def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 
                                   float(rope_scale), max_pages, L.ptr(ws), ws_bytes, L.current_stream(q.device))
     L.check(st, "atom_batch_decode_i4")
     return o
+
+
+def kv_fake_quant(x: torch.Tensor, n_bits: int = 4, clip: float = 1.0) -> torch.Tensor:
+    """Asymmetric per-head-vector fake quantisation of a [batch, heads, seq, 128] fp16 tensor (any strides over the first
+    three dims) -- quantize_attn_k_wrapper / quantize_attn_v_wrapper of the reference (model/quant.py:233-257)."""
+    if not x.is_cuda:
+        raise L.AtomHipError("kv_fake_quant needs a GPU tensor: no CPU fallback")
+    assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[-1] == 128 and x.stride(-1) == 1
+    b, h, s, _ = x.shape
+    y = torch.empty((b, h, s, 128), dtype=torch.float16, device=x.device)
+    st = L.lib().atom_kv_fake_quant_f16(x.data_ptr(), y.data_ptr(), b, h, s, x.stride(0), x.stride(1), x.stride(2),
+                                         int(n_bits), float(clip), L.current_stream(x.device))
+    L.check(st, "atom_kv_fake_quant_f16")
+    return y

@@ -217,6 +217,18 @@ int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void
                          int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
                          int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * KV-cache fake quantisation of the simulated path: every 128-d head vector of x is quantised
+ * asymmetrically to n_bits in FP16 opmath -- scale = ((max - min) * clip).clamp(1e-5) / (2^n - 1), base =
+ * round(-min / scale).clamp(0, 2^n - 1), y = (clamp(round(x / scale) + base, 0, 2^n - 1) - base) * scale -- and written
+ * back as fp16.  Replaces: quantize_attn_k_wrapper / quantize_attn_v_wrapper (model/quant.py:233-257 ->
+ * quantize_tensor(sym=False), :143-145,173-181).  x is a [batch, num_heads, seq_len, 128] view with the given ELEMENT
+ * strides (last dim contiguous; the reference feeds the transposed projection output), y is contiguous; y == x is
+ * allowed when x is contiguous.
+ */
+int atom_kv_fake_quant_f16(const void *x, void *y, int64_t batch, int num_heads, int64_t seq_len, int64_t stride_b,
+                           int64_t stride_h, int64_t stride_s, int n_bits, float clip, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -451,6 +451,29 @@ def sim_linear_torch(xq, wq):
     return torch.nn.functional.linear(xq, wq, None)
 
 
+def kv_fake_quant_sim(x16: np.ndarray, n_bits: int = 4, clip: float = 1.0) -> np.ndarray:
+    """quantize_attn_k_wrapper / quantize_attn_v_wrapper (model/quant.py:233-257): quantize_tensor(sym=False) per 128-d
+    head vector, every step in FP16 opmath (one FP32 op, rounded to half) as torch does on half tensors
+    (model/quant.py:143-145 max/min, :173-181 affine mapping).  x16 [..., 128] float16 -> same shape float16."""
+    x = np.asarray(x16, dtype=f16)
+    shape = x.shape
+    w = x.reshape(-1, shape[-1]).astype(np.float32)
+    h = lambda a: a.astype(f16).astype(np.float32)          # round an FP32 result to half
+    qmax = np.float32((1 << n_bits) - 1)
+    w_max = w.max(axis=1, keepdims=True)
+    w_min = w.min(axis=1, keepdims=True)
+    if clip < 1.0:
+        w_max = h(w_max * np.float32(clip))
+        w_min = h(w_min * np.float32(clip))
+    rng = np.maximum(h(w_max - w_min), np.float32(f16(1e-5)))
+    scales = h(rng / qmax)
+    with np.errstate(over="ignore", invalid="ignore"):
+        base = np.clip(_rne(h(-w_min / scales)), 0, qmax)
+        q = np.clip(h(_rne(h(w / scales)) + base), 0, qmax)
+        out = h(h(q - base) * scales)
+    return out.astype(f16).reshape(shape)
+
+
 # --------------------------------------------------------------------------- INT4 paged KV cache (SURVEY 8(f) N1 / N3)
 # Parity unpinned: the reference holds no golden vector for these (tests/test_batch_decode_int4.py only checks that the
 # CUDA kernel runs) and its kernels cannot run here; the restatement follows the CUDA sources line by line instead.

@@ -110,3 +110,32 @@ def test_batch_decode_properties_and_errors():
     with pytest.raises(AtomHipError):
         ops.batch_decode_i4(q, kv, 5)                        # layer out of range
     assert data.shape[1] == 2
+
+
+def test_kv_fake_quant_bit_exact(golden_dir):
+    """atom_kv_fake_quant_f16 against the reference-generated golden and the oracle, contiguous and transposed-view
+    inputs (the attention layer passes the transposed projection output, qLlamaLayer.py:238-249)."""
+    import os
+    from atom_amd import ops
+    from tests.helpers import bits16
+    z = np.load(os.path.join(golden_dir, "kv_fake_quant.npz"))
+    x = torch.from_numpy(z["x"]).cuda()
+    for key in z.files:
+        if key == "x":
+            continue
+        bits, clip = int(key.split("_b")[1].split("_")[0]), float(key.split("_c")[1])
+        y = ops.kv_fake_quant(x, bits, clip)
+        assert np.array_equal(bits16(t2n(y)), bits16(z[key])), key
+    xt = x.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    assert not xt.is_contiguous()
+    y = ops.kv_fake_quant(xt, 4, 1.0)
+    assert y.is_contiguous() and np.array_equal(bits16(t2n(y)), bits16(z["k_b4_c1.0"]))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    big = (torch.randn((3, 32, 257, 128), device="cuda", generator=g) * 2).half()
+    want = O.kv_fake_quant_sim(t2n(big), 4, 0.9)
+    assert np.array_equal(bits16(t2n(ops.kv_fake_quant(big, 4, 0.9))), bits16(want))
+    # through the drop-in wrapper
+    import types
+    from atom_amd.model import quant as Q
+    args = types.SimpleNamespace(abits=4, kv_clip_ratio=1.0)
+    assert np.array_equal(bits16(t2n(Q.quantize_attn_k_wrapper(xt, args))), bits16(z["k_b4_c1.0"]))

@@ -199,3 +199,14 @@ def test_kv_oracle_self_consistency():
     x = g.standard_normal((5, D))
     assert np.allclose(np.linalg.norm(O._rope_llama(x, np.arange(5)), axis=1), np.linalg.norm(x, axis=1))
     assert np.allclose(O._rope_llama(x[:1], [0]), x[:1])
+
+
+def test_kv_fake_quant_matches_reference(golden_dir):
+    """quantize_attn_k/v_wrapper (model/quant.py:233-257): the FP16-opmath restatement reproduces the unmodified reference
+    bit for bit (tests/golden/gen_golden_kv.py), clip and 8-bit variants included."""
+    z = _load(golden_dir, "kv_fake_quant.npz")
+    for key in z:
+        if key == "x":
+            continue
+        bits, clip = int(key.split("_b")[1].split("_")[0]), float(key.split("_c")[1])
+        assert np.array_equal(_bits(O.kv_fake_quant_sim(z["x"], bits, clip)), _bits(z[key])), key

@@ -1,0 +1,75 @@
+"""BASELINE config 4: one Llama-7B decoder block, W4A4 g128 keeper 128, KV fake-quant INT4, batch 32 x seq 2048, through the
+drop-in operator surface (atom_amd.model.qLlamaLayer.QLlamaDecoderLayer).  Reports the block time and the time inside the
+seven W4A4 GEMMs and the fused quantisers (CUDA events in forward hooks).  Run on the GPU box:  python tools/block_bench.py"""
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_golden_block as G  # noqa: E402  (pure-torch builders only)
+from atom_amd.model import qLlamaLayer, quant  # noqa: E402
+from atom_amd.model.qLinearLayer import QLinearLayer  # noqa: E402
+
+
+def main(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3):
+    args = types.SimpleNamespace(wbits=4, abits=4, a_sym=True, w_sym=True, act_group_size=128, weight_group_size=128,
+                                 weight_channel_group=2, keeper=128, keeper_precision=3, a_clip_ratio=0.9,
+                                 w_clip_ratio=0.85, kv_clip_ratio=1.0, tiling=0, exponential=False, quant_type="int",
+                                 static=False, reorder=True, kv_cache=True)
+    orig = G.build_original(hidden, heads, inter, seed=7)
+    idx, _, _, _ = G.make_inputs(hidden, inter, 1, 8, seed=8)
+    m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
+    G.prepare(m, args, {k: v.cuda() for k, v in idx.items()}, quant)
+    x = torch.randn(bsz, seq, hidden, device="cuda").half()
+    pos = torch.arange(seq, device="cuda")[None, :].expand(bsz, seq).contiguous()
+    mask = torch.full((seq, seq), torch.finfo(torch.float16).min, device="cuda").triu(1)[None, None].expand(bsz, 1, seq, seq).half().contiguous()
+
+    spans = {}
+
+    def timed(name, mod):
+        def pre(_m, _i):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            spans.setdefault(name, []).append([e, None])
+
+        def post(_m, _i, _o):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            spans[name][-1][1] = e
+        mod.register_forward_pre_hook(pre)
+        mod.register_forward_hook(post)
+
+    for name, mod in m.named_modules():
+        if type(mod) is QLinearLayer or name in ("input_layernorm", "post_attention_layernorm"):
+            timed(name, mod)
+    with torch.no_grad():
+        m(x, attention_mask=mask, position_ids=pos)            # warm-up (packs nothing: quant() already packed)
+        torch.cuda.synchronize()
+        spans.clear()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            m(x, attention_mask=mask, position_ids=pos)
+        e1.record()
+        torch.cuda.synchronize()
+    total = e0.elapsed_time(e1) / iters
+    print(f"BLOCK batch={bsz} seq={seq} hidden={hidden} inter={inter}: {total:.2f} ms per block forward", flush=True)
+    gemm = 0.0
+    for name, evs in spans.items():
+        ms = sum(a.elapsed_time(b) for a, b in evs) / iters
+        print(f"  {name:28s} {ms:8.3f} ms")
+        if "proj" in name:
+            gemm += ms
+    M = bsz * seq
+    ops = 2.0 * M * (4 * hidden * hidden + 3 * hidden * inter)
+    print(f"  seven W4A4 GEMMs: {gemm:.2f} ms = {ops / gemm / 1e9:.0f} TOPS; rest (attention in torch, KV fake-quant, RoPE, "
+          f"residuals): {total - gemm:.2f} ms")
+
+
+if __name__ == "__main__":
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    main(bsz=b)
