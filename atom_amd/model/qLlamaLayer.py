@@ -13,6 +13,7 @@ reference's pin) and 5.x module layouts alike.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -22,6 +23,9 @@ from .. import ops as _ops
 from .qLinearLayer import QLinearLayer
 from .quant import (ActCodes, Quantizer, _reorder_index_i16, attach_codes, hip_act_quant,  # noqa: F401
                     want_wide_codes)
+
+
+_USE_SDPA = os.environ.get("ATOM_ATTN_SDPA", "0") == "1"
 
 
 def rotate_half(x):
@@ -205,6 +209,14 @@ class QLlamaAttention(nn.Module):
         k = repeat_kv(k, self.num_key_value_groups)
         v = repeat_kv(v, self.num_key_value_groups)
 
+        if self.q_kv_cache:
+            v = self.v_quant(v)
+        if _USE_SDPA and not output_attentions:
+            # opt-in (ATOM_ATTN_SDPA=1): fused attention instead of the reference's materialised score matrix
+            # (qLlamaLayer.py:262-290).  Same mathematics, FP32 softmax inside the kernel; not bit-identical.
+            attn_output = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask)
+            attn_weights = None
+            return self._finish(attn_output, bsz, q_len, attn_weights, past_key_value, output_attentions)
         attn_weights = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.head_dim)
         if tuple(attn_weights.shape) != (bsz, self.num_heads, q_len, kv_seq_len):
             raise ValueError(f"score tensor has shape {tuple(attn_weights.shape)}, expected "
@@ -214,9 +226,10 @@ class QLlamaAttention(nn.Module):
                 raise ValueError(f"mask has shape {tuple(attention_mask.shape)}, expected {(bsz, 1, q_len, kv_seq_len)}")
             attn_weights = attn_weights + attention_mask
         attn_weights = nn.functional.softmax(attn_weights, dim=-1, dtype=torch.float32).to(q.dtype)
-        if self.q_kv_cache:
-            v = self.v_quant(v)
         attn_output = torch.matmul(attn_weights, v)
+        return self._finish(attn_output, bsz, q_len, attn_weights, past_key_value, output_attentions)
+
+    def _finish(self, attn_output, bsz, q_len, attn_weights, past_key_value, output_attentions):
         assert tuple(attn_output.shape) == (bsz, self.num_heads, q_len, self.head_dim)
         attn_output = attn_output.transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
 
