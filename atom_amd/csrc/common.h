@@ -57,12 +57,14 @@ struct GemmParams {
   int ref_layout;
   int a_wide;       // A4 is the wide activation format: int8 [M, K4] = code*16, even/odd de-interleaved per 32 channels
   int64_t ldA;      // halves between groups of sA
+  int64_t f6_rows_a, f6_rows_b;   // F6 operand format: padded rows per group of A4 / B4 (gemm_w4a4_f6.hip)
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
 int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s);         // gemm_w4a4_v2.hip, u4 epilogue
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_v3.hip (templated geometry)
 int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
+int launch_gemm_f6(const GemmParams &p, hipStream_t s);            // gemm_w4a4_f6.hip (BF6 operands, 256x256 tiles)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -313,6 +313,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int variant = [] { const char *e = getenv("ATOM_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
   if (p.a_wide && variant != 0 && !(variant >= 320 && variant <= 330)) return ATOM_ERR_INVALID_ARG;
+  if (p.f6_rows_a && variant != 0) return ATOM_ERR_INVALID_ARG;
   switch (variant) {   // tuning / ablation variants; 0 is the product path
     case 320: case 324: case 325: return launch_gemm_v3(p, variant - 300, hs);
     case 101: return launch_gemm<GemmCfg<128, 256, 2, 4>, 1>(p, hs);
@@ -337,6 +338,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       return launch_gemm_v3(p, variant - 300, hs);
     }
     default:                                                        // product path
+      if (p.f6_rows_a) return launch_gemm_f6(p, hs);           // BF6 operands: block-scaled MFMA kernel, 256x256 tiles
       if (p.a_wide) {   // activations pre-widened by the quant kernels: 256x256 tiles once they fill half the chip
         const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
         const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
@@ -366,7 +368,9 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
                        int keeper, int scale_layout) {
   if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8) return ATOM_ERR_INVALID_ARG;
   const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
-  scale_layout &= ~ATOM_A_WIDE;
+  const int f6 = (scale_layout & ATOM_AB_F6) != 0;
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6);
+  if (a_wide && f6) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
   if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return ATOM_ERR_SHAPE;
@@ -385,6 +389,8 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.G = (int)((K_total - kKeeper) / kGroup);
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
   p.a_wide = a_wide;
+  p.f6_rows_a = f6 ? (M + 255) / 256 * 256 : 0;              // == atom_f6_rows(): rows per group, padded to the tile
+  p.f6_rows_b = f6 ? (N + 255) / 256 * 256 : 0;
   p.ldA = (int64_t)atom_scale_size(M, scale_layout);
   return ATOM_OK;
 }
@@ -414,7 +420,7 @@ size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
                           const void *sA8, const void *sB8, void *D, int64_t M, int64_t N, int64_t K_total, int group,
                           int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream) {
-  const size_t need = atom_gemm_w4a4_workspace_bytes(M, N, K_total);
+  const size_t need = (scale_layout & ATOM_AB_F6) ? 0 : atom_gemm_w4a4_workspace_bytes(M, N, K_total);
   if (need == 0 || !workspace || workspace_bytes < need)
     return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
   if (!D) return ATOM_ERR_INVALID_ARG;
@@ -436,7 +442,7 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
   const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
   if (st != ATOM_OK) return st;
   if ((N % 128) != 0) return ATOM_ERR_SHAPE;
-  if (p.a_wide) return ATOM_ERR_INVALID_ARG;                 // the u4 epilogue kernel takes packed activations only
+  if (p.a_wide || p.f6_rows_a) return ATOM_ERR_INVALID_ARG;  // the u4 epilogue kernel takes packed activations only
   if (!aligned16(D_u4)) return ATOM_ERR_ALIGN;
   p.D4 = (uint8_t *)D_u4;
   p.Dsz = (half_t *)D_scale_zero;

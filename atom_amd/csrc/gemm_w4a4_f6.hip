@@ -1,0 +1,297 @@
+// W4A4 GEMM, prefill kernel on the block-scaled MFMA of gfx950 with BF6 operands ("F6" native format).
+//
+// gfx950 has no INT4 MFMA; the INT8 path (gemm_w4a4_v3.hip) spends 4 x v_mfma_i32_32x32x32_i8 per 128-channel group and
+// 4.5 VALU per MFMA widening nibbles.  But every INT4 code in [-8, 7] IS a BF6 (E3M2) number, products of two codes and
+// sums of 128 of them are exact in FP32, and v_mfma_scale_f32_32x32x64_f8f6f4 runs BF6 at the FP4 rate: with unit block
+// scales (E8M0 127) it is an exact integer dot product of 64 channels at 21.7 ns per instruction where the INT8
+// 32x32x32 takes 17.6 ns for 32 channels (tools/probes/bf6_probe.cpp: 0 mismatches, 6.19 vs 3.81 Pop/s) -- 38 % less
+// matrix time per group, and no widening at all when both operands arrive as BF6.
+//
+// Operand format "F6" (produced by the activation quantisers with ATOM_QUANT_F6_CODES and by atom_repack_weight_f6):
+//   [G][rows_pad][104 bytes]   group-major; 96 bytes = the group's 128 codes as a little-endian stream of 6-bit BF6
+//                              fields, byte 96..97 = the fp16 scale of (row, group), 98..103 zero
+// Group-major makes the 256 rows a tile needs for one K step ONE contiguous 26 KiB block: the LDS-DMA is base + 16*lane
+// with no per-row address, rows_pad (a multiple of 256) keeps tail tiles in bounds, and the 104-byte pitch (26 dwords =
+// 2 x odd) makes the 32 rows of an MFMA fragment read (3 x ds_read_b64 of 24 bytes) hit 32 distinct bank pairs with no
+// swizzle.  The token scale is read from the row itself (no scale DMA, no scale region); weight scales keep their dense
+// fp16 array.  The INT8 keeper runs as the two 64-column half-steps of the INT8 kernel in the same stage buffer.
+// Arithmetic is the same contract: t = round_f32(idot * sA), c = fma(t, sB, c) per group in order, keeper last --
+// results are bit-identical to the INT8 kernels.
+#include "common.h"
+
+namespace atom {
+namespace f6 {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 256, BN = 256, NS = 3, TM = 4, TN = 2, NW = 8, NT = 512;
+constexpr int PITCH = 104;                               // bytes per row and group
+constexpr int W_BYTES = BN * PITCH, A_OFF = W_BYTES;     // 26,624 = 26 DMA blocks each
+constexpr int DATA_BYTES = (BN + BM) * PITCH;            // 53,248
+constexpr int SB_OFF = DATA_BYTES;                       // BN fp16 weight scales (int4 steps and keeper)
+constexpr int STAGE_BYTES = DATA_BYTES + BN * 2;         // 53,760; x3 = 161,280 <= 160 KiB
+constexpr int KP_SA_OFF = (BN + BM) * 64;                // keeper half-steps: rows of 64 bytes, then BM dwords of sA8
+constexpr int GLDS = 7;                                  // DMA instructions per wave and stage: 52 data blocks + 2 scale
+                                                         // pieces (+ 2 repeats) = 56
+constexpr int EP_BYTES = NW * 64 * 144;
+constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
+constexpr float kMagic = 12582912.0f;
+constexpr int kMagicBits = 0x4B400000;
+static_assert(W_BYTES % 1024 == 0 && NS * STAGE_BYTES <= 160 * 1024, "stage geometry");
+
+__device__ __forceinline__ void issue_int4(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0) {
+  const uint8_t *wsrc = p.B4 + ((int64_t)g * p.f6_rows_b + n0) * PITCH;
+  const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - W_BYTES;   // so that block j >= 26 is asrc + j*1024
+  // block j = 8*i + wave: i <= 2 is always weights, i = 4, 5 always activations -- compile-time; i = 3 straddles the
+  // boundary (one uniform pointer select), i = 6 carries the last 4 activation blocks and the 2 scale pieces
+#pragma unroll
+  for (int i = 0; i < GLDS - 1; ++i) {
+    const int j = 8 * i + wave;
+    const uint8_t *base = (i < 3 || (i == 3 && j < 26)) ? wsrc : asrc;
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+  }
+  if (wave < 4) {
+    const int j = 48 + wave;
+    __builtin_amdgcn_global_load_lds((gptr_t)(asrc + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+  } else {                                               // 128 weight scales per piece, a dword (2 channels) per lane;
+    const int part = wave & 1;                           // waves 6, 7 repeat the pieces of waves 4, 5
+    const half_t *sBb = p.sB + (int64_t)g * p.N;
+    const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
+    __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + SB_OFF + part * 256), 4, 0, 0);
+  }
+}
+
+// keeper half-step `half` (0 / 1): the INT8 kernel's layout -- 16 rows x 64 B per DMA block, XOR-swizzled chunks
+__device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char *slot, int wave, int lane, int m0, int n0) {
+  // only two of these per tile: addresses are computed here instead of living in registers through the int4 loop
+  const unsigned kj = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+#pragma unroll
+  for (int i = 0; i < GLDS; ++i) {
+    if (i < 4) {
+      const int gidx = wave * 4 + i;                     // 32 blocks: 16 weight, 16 activation
+      const int row = gidx * 16 + (lane >> 2);
+      const unsigned idx = (unsigned)(gidx < 16 ? min(n0 + row, p.N - 1) : min(m0 + row - BN, p.M - 1));
+      const uint8_t *base = (gidx < 16 ? p.B8 : p.A8) + half * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + idx * kKeeper + kj), (lptr_t)(slot + gidx * 1024), 16, 0, 0);
+    } else if (i == 4 && wave < 4) {                     // sA8 of 64 tokens: one fp16 per lane -> zero-extended dword
+      const int idx = min(m0 + wave * 64 + lane, p.M - 1);
+      const unsigned ksa = (unsigned)(p.ref_layout ? ref_scale_index(idx) : idx);
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.sA8 + ksa), (lptr_t)(slot + KP_SA_OFF + wave * 256), 2, 0, 0);
+    } else {                                             // sB8 (two pieces; the other waves repeat one of them)
+      const int part = wave & 1;
+      const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.sB8 + n), (lptr_t)(slot + SB_OFF + part * 256), 4, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ v8i frag24(const char *p) {    // 24 bytes = 32 BF6 fields -> MFMA operand (6 of 8 VGPRs)
+  const v2u a = *reinterpret_cast<const v2u *>(p);
+  const v2u b = *reinterpret_cast<const v2u *>(p + 8);
+  const v2u c = *reinterpret_cast<const v2u *>(p + 16);
+  return v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
+}
+
+__device__ __forceinline__ void dequant16(const float (&acc)[16], float sa, const char *psb, float (&c)[16]) {
+  v2u sbp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + 16 * q);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+    const float t = acc[r] * sa;                         // == round_f32(idot * sA): acc is the exact integer dot
+    c[r] = __builtin_fmaf(t, (float)hv[r & 3], c[r]);
+    asm volatile("" : "+v"(c[r]));
+  }
+}
+
+// one int4 group out of LDS: 2 BF6 MFMAs per 32x32 tile
+__device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const char *pw = slot + (wn * 64 + l31) * PITCH + h * 24;             // + tn*32*PITCH + s*48
+  const char *pa = slot + A_OFF + (wm * 128 + l31) * PITCH + h * 24;    // + tm*32*PITCH + s*48
+  const char *psb = slot + SB_OFF + (wn * 64 + 4 * h) * 2;              // + tn*64 + 16*q
+  v8i af[TN][2];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) af[tn][s] = frag24(pw + tn * 32 * PITCH + s * 48);
+  v8i bf[2];
+  bf[0] = frag24(pa);
+  bf[1] = frag24(pa + 48);
+  half_t sah = *reinterpret_cast<const half_t *>(pa - h * 24 + 96);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_sched_barrier(0);
+    const float sa = (float)sah;
+    if (tm + 1 < TM) sah = *reinterpret_cast<const half_t *>(pa - h * 24 + 96 + (tm + 1) * 32 * PITCH);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      __builtin_amdgcn_sched_barrier(0);
+      v16f acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        // cbsz = blgp = 3: BF6 (E3M2) x BF6; block scales E8M0 127 = 2^0
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[tn][s], bf[s], acc, 3, 3, 0, 127, 0, 127);
+        if (tn == TN - 1 && tm + 1 < TM) {
+          __builtin_amdgcn_sched_barrier(0);             // refill the slice behind its last reader
+          bf[s] = frag24(pa + (tm + 1) * 32 * PITCH + s * 48);
+        }
+      }
+      float a16[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a16[i] = acc[i];
+      dequant16(a16, sa, psb + tn * 64, c[tn][tm]);
+    }
+  }
+}
+
+// keeper half-step out of LDS (INT8 MFMA, magic-biased accumulator), de-quantised per half
+__device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int sw = (l31 >> 2) & 3;
+  const char *pw0 = slot + (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4);
+  const char *pw1 = slot + (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
+  const char *pa0 = slot + (BN + wm * 128 + l31) * 64 + (((0 + h) ^ sw) << 4);
+  const char *pa1 = slot + (BN + wm * 128 + l31) * 64 + (((2 + h) ^ sw) << 4);
+  const char *psa = slot + KP_SA_OFF + (wm * 128 + l31) * 4;
+  const char *psb = slot + SB_OFF + (wn * 64 + 4 * h) * 2;
+  v4i af[TN][2];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    af[tn][0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw0 + tn * 2048));
+    af[tn][1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw1 + tn * 2048));
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const v4i b0 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa0 + tm * 2048));
+    const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa1 + tm * 2048));
+    const float sa = (float)*reinterpret_cast<const half_t *>(psa + tm * 128);
+    const float nms = -kMagic * sa;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      __builtin_amdgcn_sched_barrier(0);
+      // each 64-column half is de-quantised on its own (the contract of include/atom_hip.h): t = round_f32(idot * sA8)
+      v16i magic;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
+      v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], b0, magic, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][1], b1, a, 0, 0, 0);
+      v2u sbp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
+        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        asm volatile("" : "+v"(c[tn][tm][r]));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / 4, wn = wave % 4;
+
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  float c[TN][TM][16];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
+
+  const int nsteps = p.G + 2;
+  auto issue = [&](int step) {
+    char *slot = lds + (step % NS) * STAGE_BYTES;
+    const int s = min(step, nsteps - 1);
+    if (s < p.G) issue_int4(p, s, slot, wave, lane, m0, n0);
+    else issue_keeper(p, s - p.G, slot, wave, lane, m0, n0);
+  };
+  issue(0);
+  issue(1);
+#define ATOM_F6_STEP(COMPUTE)                                                            \
+  {                                                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS * (NS - 2)) : "memory");               \
+    __builtin_amdgcn_s_barrier();                                                        \
+    issue(step + NS - 1);                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    COMPUTE(lds + (step % NS) * STAGE_BYTES, wm, wn, lane, c);                           \
+  }
+  int step = 0;
+  for (; step < p.G; ++step) ATOM_F6_STEP(compute_int4)
+  for (; step < nsteps; ++step) ATOM_F6_STEP(compute_keeper)
+#undef ATOM_F6_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int EP_STRIDE = 144;
+  char *ep = lds + wave * (64 * EP_STRIDE);
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < TM / 2; ++half) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int tm = half * 2 + t2;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v2u o;
+          half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ov[k] = f2h(c[tn][tm][4 * q + k]);
+          *reinterpret_cast<v2u *>(ep + (t2 * 32 + l31) * EP_STRIDE + (tn * 32 + 8 * q + 4 * h) * 2) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = i * 8 + (lane >> 3);
+      const int ch = lane & 7;
+      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
+      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int n = n0 + wn * 64 + ch * 8;
+      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+    }
+  }
+}
+
+}  // namespace f6
+
+int launch_gemm_f6(const GemmParams &p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f6::gemm_w4a4_f6_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, f6::LDS_BYTES) != hipSuccess)
+      return ATOM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nbm = (p.M + f6::BM - 1) / f6::BM, nbn = (p.N + f6::BN - 1) / f6::BN;
+  hipLaunchKernelGGL(f6::gemm_w4a4_f6_kernel, dim3((unsigned)(nbm * nbn)), dim3(f6::NT), f6::LDS_BYTES, s, p);
+  return check_launch();
+}
+
+}  // namespace atom

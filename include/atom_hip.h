@@ -64,6 +64,22 @@ extern "C" {
 #define ATOM_QUANT_WIDE_CODES 0x100
 #define ATOM_A_WIDE 0x100
 
+/*
+ * Native "F6" operand format of the block-scaled-MFMA prefill kernel (gemm_w4a4_f6.hip; no reference counterpart): every
+ * INT4 code is a BF6 (E3M2) number, and v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales multiplies them exactly
+ * at the FP4 rate.  OR ATOM_AB_F6 into `scale_layout` of atom_gemm_w4a4_f16: BOTH A4 and B4 are then
+ *   uint8 [G][atom_f6_rows(rows)][104]   group-major; bytes 0..95 = the 128 codes of (row, group) as a little-endian
+ *                                         stream of 6-bit BF6 fields, bytes 96..97 = the fp16 scale of (row, group) (A4
+ *                                         only: the GEMM reads token scales from here, `sA` is ignored), 98..103 zero
+ * with atom_f6_rows(rows) = rows rounded up to 256 (pad rows: any bytes).  sB / keeper operands and scales as before.
+ * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
+ * still written).  Weights: atom_repack_weight_f6.  Results are bit-identical to the INT8 kernels.  M, N >= 1 as usual;
+ * meant for prefill (one 256x256 tile per workgroup, no split-K).
+ */
+#define ATOM_QUANT_F6_CODES 0x200
+#define ATOM_AB_F6 0x200
+#define ATOM_F6_PITCH 104
+
 const char *atom_version(void);
 const char *atom_strerror(int code);
 

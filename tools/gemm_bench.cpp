@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -72,11 +73,41 @@ int main(int argc, char **argv) {
         }
     up(&Ain, hw.data(), hw.size());
   }
+  // ATOM_F6=1: feed the GEMM the BF6 group-major format (both operands)
+  void *Bin = B4;
+  int layout2 = layout;
+  if (getenv("ATOM_F6")) {
+    static const uint8_t mag[9] = {0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18};
+    auto code6 = [&](int v) { return (uint8_t)((v < 0 ? 0x20 : 0) | mag[v < 0 ? -v : v]); };
+    auto conv = [&](const std::vector<uint8_t> &packed, int rows, const half_t *scales /* [G][rows] or null */) {
+      const int rp = (rows + 255) / 256 * 256;
+      std::vector<uint8_t> out((size_t)G * rp * 104, 0);
+      for (int g = 0; g < G; ++g)
+        for (int r = 0; r < rows; ++r) {
+          uint8_t *dst = &out[((size_t)g * rp + r) * 104];
+          for (int e = 0; e < 128; ++e) {
+            const int kk = g * 128 + e;
+            const uint8_t pb = packed[(size_t)r * (K4 / 2) + kk / 2];
+            const int nv = (kk & 1) ? (int8_t)(pb & 0xF0) >> 4 : (int8_t)(pb << 4) >> 4;
+            const unsigned c = code6(nv);
+            const int bit = 6 * e;
+            dst[bit / 8] |= (uint8_t)(c << (bit % 8));
+            if (bit % 8 > 2) dst[bit / 8 + 1] |= (uint8_t)(c >> (8 - bit % 8));
+          }
+          if (scales) memcpy(dst + 96, &scales[(size_t)g * rows + r], 2);
+        }
+      return out;
+    };
+    std::vector<uint8_t> ha = conv(hA4, M, hsA.data()), hb = conv(hB4, N, nullptr);
+    up(&Ain, ha.data(), ha.size());
+    up(&Bin, hb.data(), hb.size());
+    layout2 = ATOM_SCALE_LAYOUT_PLAIN | ATOM_AB_F6;
+  }
   size_t wsb = getenv("ATOM_WS") ? atom_gemm_w4a4_workspace_bytes(M, N, K) : 0;
   void *ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
   printf("workspace bytes %zu\n", wsb);
 #define atom_gemm_w4a4_f16(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p) atom_gemm_w4a4_f16_ws(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, ws, wsb, p)
-  int st = atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
+  int st = atom_gemm_w4a4_f16(Ain, Bin, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout2, nullptr);
   if (st) { printf("atom_gemm_w4a4_f16: %s\n", atom_strerror(st)); return 1; }
   CK(hipDeviceSynchronize());
 
@@ -103,12 +134,12 @@ int main(int argc, char **argv) {
   }
 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
+  for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(Ain, Bin, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout2, nullptr);
   CK(hipDeviceSynchronize());
   float best = 1e30f, tot = 0;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) atom_gemm_w4a4_f16(Ain, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr);
+    for (int i = 0; i < iters; ++i) atom_gemm_w4a4_f16(Ain, Bin, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout2, nullptr);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters; tot += ms; if (ms < best) best = ms;
   }
