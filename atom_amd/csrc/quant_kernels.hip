@@ -41,6 +41,7 @@ struct ActQuantParams {
   int H;
   int sim;                // 1 = ATOM_QUANT_SIM
   int wide;               // 1 = ATOM_QUANT_WIDE_CODES: o4 is int8 [M, H-128] (code*16, even/odd de-interleaved per 32)
+  int64_t f6_rows;        // > 0 = ATOM_QUANT_F6_CODES: o4 is uint8 [G][f6_rows][104] (BF6 stream + scale, atom_hip.h)
   float clip;
   float eps;
   int ref_layout;         // 1 = ATOM_SCALE_LAYOUT_REF
@@ -142,7 +143,28 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
       hi = __builtin_fmaf(tr[8 * k + 7], 4096.f, hi);
       w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x88888888u;
     }
-    if (p.wide) {
+    if (p.f6_rows) {
+      // BF6 (E3M2) holds every INT4 code exactly; v_cvt_scalef32_2xpk16_bf6_f32 converts AND packs 32 floats into 6-bit
+      // fields, interleaving its two sources (field 2i = a[i], 2i+1 = b[i]; tools/probes): my 16 codes are fields 0..15
+      typedef float v16f __attribute__((ext_vector_type(16)));
+      typedef unsigned v6u __attribute__((ext_vector_type(6)));
+      typedef unsigned v3u __attribute__((ext_vector_type(3)));
+      v16f ea, eb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ea[i] = tr[2 * i];
+        eb[i] = tr[2 * i + 1];
+        ea[8 + i] = 0.f;
+        eb[8 + i] = 0.f;
+      }
+      const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+      uint8_t *dst = p.o4 + ((int64_t)g * p.f6_rows + r) * 104;
+      *reinterpret_cast<v3u *>(dst + 12 * j) = v3u{f[0], f[1], f[2]};
+      if (j == 0) {                                       // the GEMM reads the token scale from the row itself
+        const unsigned sh = (unsigned)__builtin_bit_cast(unsigned short, f2h(s_store));
+        *reinterpret_cast<v2u *>(dst + 96) = v2u{sh, 0u};
+      }
+    } else if (p.wide) {
       // my 16 channels are half `j & 1` of 32-channel block g*4 + j/2: even channels -> chunk 0, odd -> chunk 1
       uint8_t *dst = p.o4 + r * (int64_t)(2 * K4h) + g * 128 + (j >> 1) * 32 + (j & 1) * 8;
       *reinterpret_cast<v2u *>(dst) = v2u{(w[0] << 4) & 0xF0F0F0F0u, (w[1] << 4) & 0xF0F0F0F0u};
@@ -411,7 +433,9 @@ static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_
   if (op == OP_ADD_RMSNORM && (!p.res || !p.res_out)) return ATOM_ERR_INVALID_ARG;
   if (op == OP_ADD_RMSNORM && (!aligned16(p.res) || !aligned16(p.res_out))) return ATOM_ERR_ALIGN;
   p.wide = (quant_mode & ATOM_QUANT_WIDE_CODES) != 0;
-  quant_mode &= ~ATOM_QUANT_WIDE_CODES;
+  p.f6_rows = (quant_mode & ATOM_QUANT_F6_CODES) ? (p.M + 255) / 256 * 256 : 0;
+  if (p.wide && p.f6_rows) return ATOM_ERR_INVALID_ARG;
+  quant_mode &= ~(ATOM_QUANT_WIDE_CODES | ATOM_QUANT_F6_CODES);
   if (quant_mode != ATOM_QUANT_KERNEL && quant_mode != ATOM_QUANT_SIM) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN)
     return ATOM_ERR_INVALID_ARG;
@@ -706,6 +730,45 @@ __global__ __launch_bounds__(256) void kv_fake_quant_kernel(KvFqParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed INT4 weights -> the F6 operand format of gemm_w4a4_f6.hip ([G][rows_pad][104] BF6 streams).  Offline.
+struct RepackF6Params {
+  const uint8_t *B4;
+  uint8_t *out;
+  int64_t N, rows_pad;
+  int K4h, G;
+};
+
+__global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Params p) {
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  typedef unsigned v6u __attribute__((ext_vector_type(6)));
+  typedef unsigned v3u __attribute__((ext_vector_type(3)));
+  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (row, group, j): 16 codes each
+  const int j = (int)(unit & 7);
+  const int64_t rg = unit >> 3;
+  const int g = (int)(rg % p.G);
+  const int64_t n = rg / p.G;
+  if (n >= p.rows_pad) return;
+  uint8_t *dst = p.out + ((int64_t)g * p.rows_pad + n) * 104;
+  v3u o = v3u{0u, 0u, 0u};
+  if (n < p.N) {
+    const v2u raw = *reinterpret_cast<const v2u *>(p.B4 + n * p.K4h + g * 64 + j * 8);
+    v16f ea, eb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned byte = (raw[i >> 2] >> (8 * (i & 3))) & 0xFF;
+      ea[i] = (float)((int)(byte << 28) >> 28);                        // element 2i: low nibble, sign-extended
+      eb[i] = (float)((int)(byte << 24) >> 28);                        // element 2i+1: high nibble
+      ea[8 + i] = 0.f;
+      eb[8 + i] = 0.f;
+    }
+    const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+    o = v3u{f[0], f[1], f[2]};
+  }
+  *reinterpret_cast<v3u *>(dst + 12 * j) = o;
+  if (j == 0) *reinterpret_cast<v2u *>(dst + 96) = v2u{0u, 0u};
+}
+
 }  // namespace atom
 
 using namespace atom;
@@ -799,6 +862,20 @@ int atom_kv_fake_quant_f16(const void *x, void *y, int64_t batch, int num_heads,
                stride_s, (float)((1 << n_bits) - 1), clip};
   if (seq_len > 0x7fffffff) return ATOM_ERR_SHAPE;
   hipLaunchKernelGGL(kv_fake_quant_kernel, dim3((unsigned)((p.nvec + 31) / 32)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+size_t atom_f6_rows(int64_t rows) { return rows < 0 ? 0 : (size_t)((rows + 255) / 256 * 256); }
+
+int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6, void *stream) {
+  if (!B4 || !B_f6) return ATOM_ERR_INVALID_ARG;
+  if (N < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if (!aligned16(B4) || !aligned16(B_f6)) return ATOM_ERR_ALIGN;
+  RepackF6Params p{(const uint8_t *)B4, (uint8_t *)B_f6, N, (int64_t)atom_f6_rows(N), (int)((K_total - kKeeper) / 2),
+                   (int)((K_total - kKeeper) / kGroup)};
+  const int64_t units = p.rows_pad * p.G * 8;
+  hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), p);
   return check_launch();
 }

@@ -52,6 +52,7 @@ class QLinearLayer(nn.Module):
         self._packed = None          # (B4, B8, sB, sB8)
         self._packed_key = None      # identity of the fp16 weight the packed form was made from
         self._unpackable_key = None  # identity of a weight that pack_weight_w4 found to be off the grid
+        self._f6 = None              # (packed B4 it was made from, BF6 repack) for the block-scaled-MFMA kernel
 
     # ------------------------------------------------------------------------------------------------ forward
     def _weight_key(self):
@@ -87,6 +88,10 @@ class QLinearLayer(nn.Module):
         packed = self.packed_weight() if codes is not None else None
         if packed is not None and codes.hidden == self.weight.shape[1] and x.is_cuda:
             b4, b8, sb, sb8 = packed
+            if codes.wide == "f6":                        # BF6 operands: the weight is repacked once per packed form
+                if self._f6 is None or self._f6[0] is not b4:
+                    self._f6 = (b4, _ops.repack_weight_f6(b4))
+                b4 = self._f6[1]
             y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
                                               scale_layout=codes.layout, a_wide=codes.wide)
             y = y.view(*x.shape[:-1], self.weight.shape[0])

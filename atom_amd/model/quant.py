@@ -37,9 +37,14 @@ class ActCodes:
         self.wide = wide          # o4 is the native int8 (code*16, de-interleaved) format instead of packed nibbles
 
 
-def want_wide_codes(rows: int) -> bool:
-    """Prefill-sized batches feed the MFMA tile kernel, which is faster on pre-widened activation codes; decode-sized
-    ones (rows <= 7) run the weight-streaming dot-product kernel, which consumes the packed nibbles."""
+def want_wide_codes(rows: int):
+    """Which activation-code format the fused quantisers should emit for a batch of ``rows`` tokens:
+    "f6"   rows >= 3072: the BF6 group-major format of the block-scaled-MFMA prefill kernel (256x256 tiles only: it needs
+           about 200 tiles to fill the chip, i.e. 3072 rows against the 4096-wide projections of a 7B model);
+    True   8 <= rows: pre-widened int8 codes for the INT8 MFMA tile kernels;
+    False  rows <= 7: packed nibbles, which the weight-streaming decode kernel consumes."""
+    if rows >= 3072:
+        return "f6"
     return rows >= 8
 
 

@@ -10,7 +10,9 @@ Keyword-only extras (defaults reproduce the reference CUDA kernels exactly):
   return_dequant  also return the de-quantised FP16 tensor (what quantize_activation_wrapper returns)
   wide_codes   (activation ops) / a_wide (GEMM): the native activation format of include/atom_hip.h -- o_norms is
                int8 [bs, H-128] = code*16 with the even/odd channels of every 32-channel block de-interleaved, i.e.
-               already the INT8 MFMA operand; the prefill GEMM then skips 2/3 of its widening instructions
+               already the INT8 MFMA operand; the prefill GEMM then skips 2/3 of its widening instructions.
+               wide_codes="f6" / a_wide="f6": the BF6 group-major format [G][f6_rows(bs)][104] of the block-scaled-MFMA
+               prefill kernel; the GEMM then also wants the weight from repack_weight_f6
 """
 from __future__ import annotations
 
@@ -42,11 +44,19 @@ def _require_cuda_half(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be contiguous")
 
 
+def f6_rows(rows: int) -> int:
+    """Rows per group of an F6 operand buffer (include/atom_hip.h, ATOM_AB_F6): rows rounded up to 256."""
+    return (rows + 255) // 256 * 256
+
+
 def _alloc_act_outputs(bs, hidden_dim, device, layout, return_dequant, wide=False):
     # zeros, not empty, for the replicated layout: it has slots no row ever writes
     alloc = torch.zeros if layout == "ref" else torch.empty
     o_outlier = torch.empty((bs, GROUP_SIZE), dtype=torch.int8, device=device)
-    o_norms = torch.empty((bs, (hidden_dim - GROUP_SIZE) // (1 if wide else 2)), dtype=torch.int8, device=device)
+    if wide == "f6":        # [G][rows_pad][104] BF6 streams + in-row scales; pad rows are never read into a result
+        o_norms = torch.empty((hidden_dim // GROUP_SIZE - 1, f6_rows(bs), L.F6_PITCH), dtype=torch.uint8, device=device)
+    else:
+        o_norms = torch.empty((bs, (hidden_dim - GROUP_SIZE) // (1 if wide else 2)), dtype=torch.int8, device=device)
     outlier_scales = alloc((_ld(bs, layout),), dtype=torch.float16, device=device)
     norm_scales = alloc((hidden_dim // GROUP_SIZE - 1, _ld(bs, layout)), dtype=torch.float16, device=device)
     xq = torch.empty((bs, hidden_dim), dtype=torch.float16, device=device) if return_dequant else None
@@ -60,7 +70,9 @@ def _ret(o_outlier, o_norms, outlier_scales, norm_scales, xq):
 
 
 def _mode(quant_mode, wide_codes):
-    return _MODES[quant_mode] | (L.QUANT_WIDE_CODES if wide_codes else 0)
+    """wide_codes: False (packed nibbles, the reference format) | True (int8 code*16) | "f6" (BF6 group-major)."""
+    flag = L.QUANT_F6_CODES if wide_codes == "f6" else (L.QUANT_WIDE_CODES if wide_codes else 0)
+    return _MODES[quant_mode] | flag
 
 
 def activate_fp16_i4(a: torch.Tensor, b: torch.Tensor, *, quant_mode="kernel", clip=1.0, scale_layout="ref",
@@ -152,7 +164,9 @@ def _workspace(device, nbytes):
     return t
 
 
-def _gemm_dims(a, b, a_keeper, a_wide=False):
+def _gemm_dims(a, b, a_keeper, a_wide=False, b_keeper=None):
+    if a_wide == "f6":                                             # [G][rows_pad][104]: sizes come from the keepers
+        return a_keeper.size(0), b_keeper.size(0), a.size(0) * GROUP_SIZE + a_keeper.size(1)
     m = a.size(0)
     n = b.size(0)
     k = a.size(1) * (1 if a_wide else 2) + a_keeper.size(1)       # punica_ops.cc:228-241
@@ -167,7 +181,9 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     for t in (a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale):
         if not t.is_cuda:
             raise L.AtomHipError("all GEMM operands must live on the GPU: no CPU fallback")
-    m, n, k = _gemm_dims(a, b, a_keeper, a_wide)
+    m, n, k = _gemm_dims(a, b, a_keeper, a_wide, b_keeper)
+    if a_wide == "f6":
+        assert a.shape == (k // GROUP_SIZE - 1, f6_rows(m), L.F6_PITCH) and b.shape == (a.shape[0], f6_rows(n), L.F6_PITCH)
     d = torch.empty((m, n), dtype=torch.float16, device=a.device)
     lib = L.lib()
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k)     # > 0 only for skinny shapes that gain from split-K
@@ -175,7 +191,8 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
-                                   _LAYOUTS[scale_layout] | (L.A_WIDE if a_wide else 0), L.ptr(ws), ws_bytes,
+                                   _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0)),
+                                   L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
     return d
@@ -307,3 +324,16 @@ def kv_fake_quant(x: torch.Tensor, n_bits: int = 4, clip: float = 1.0) -> torch.
                                          int(n_bits), float(clip), L.current_stream(x.device))
     L.check(st, "atom_kv_fake_quant_f16")
     return y
+
+
+def repack_weight_f6(b4: torch.Tensor) -> torch.Tensor:
+    """Packed INT4 weights uint8 [N, K4/2] -> the F6 operand format uint8 [G][f6_rows(N)][104] (atom_repack_weight_f6)."""
+    if not b4.is_cuda:
+        raise L.AtomHipError("repack_weight_f6 needs a GPU tensor: no CPU fallback")
+    n, k4h = b4.shape
+    g = k4h // 64
+    out = torch.empty((g, f6_rows(n), L.F6_PITCH), dtype=torch.uint8, device=b4.device)
+    st = L.lib().atom_repack_weight_f6(b4.contiguous().data_ptr(), n, k4h * 2 + GROUP_SIZE, out.data_ptr(),
+                                        L.current_stream(b4.device))
+    L.check(st, "atom_repack_weight_f6")
+    return out

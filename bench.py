@@ -5,7 +5,11 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 (configs[2]: M=N=K=4096, group 128, 128 INT8 outlier columns), operands resident in HBM, synthetic uniform random
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
+
+The headline runs the operand format the drop-in modules use for prefill batches (F6: both operands BF6-coded, block-scaled
+MFMA); at N=1 the reference's packed-nibble format and the wide-activation format are timed beside it (same codes, same
+scales, outputs compared bit for bit) and reported under "other_operand_formats".
 
 N > 1: one process per GPU (torch.distributed.run), every rank runs an independent replica (the path is a
 single-device per-layer GEMM: "replicas only", no collective on the data path); value = all ranks' ops / max time.
@@ -87,18 +91,42 @@ def aggregate(world, steps, wall_s, kern_ms, M, N, K):
             "achieved": ops_per_step / (kern_ms * 1e-3) / 1e12}
 
 
-def measured_traffic(M, N, K):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/bench_hbm_traffic.json), or None."""
+def measured_traffic(M, N, K, fmt):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/bench_hbm_traffic*.json), or None."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
         for d in sorted(os.listdir(pdir)):
-            f = os.path.join(pdir, d, "bench_hbm_traffic.json")
-            if os.path.isfile(f):
-                t = json.load(open(f))
-                if t.get("algorithmic_bytes_per_launch") == algorithmic_bytes(M, N, K):
-                    best = int(t["traffic_bytes_per_launch"])
+            for name in ("bench_hbm_traffic.json", f"bench_hbm_traffic_{fmt}.json"):
+                f = os.path.join(pdir, d, name)
+                if os.path.isfile(f):
+                    t = json.load(open(f))
+                    if t.get("algorithmic_bytes_per_launch") == algorithmic_bytes(M, N, K) and \
+                            t.get("operand_format", "packed") == fmt:
+                        best = int(t["traffic_bytes_per_launch"])
     return best
+
+
+def build_f6_operands(ops_, M, N, K, dev):
+    """The headline operands in the native F6 format (include/atom_hip.h, ATOM_AB_F6): activations as the fused quantisers
+    emit them with ATOM_QUANT_F6_CODES (built here with torch from the same packed codes and scales), weights through
+    atom_repack_weight_f6 (offline, once per weight)."""
+    from atom_amd import ops as aops
+    K4 = K - 128
+    G = K4 // 128
+    a4 = ops_[0].view(torch.uint8)
+    nib = torch.stack([a4 & 0xF, a4 >> 4], dim=-1).reshape(M, K4).to(torch.int64)          # element 2j in the low nibble
+    lut = torch.tensor([0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x38, 0x37, 0x36, 0x35, 0x34, 0x32, 0x30, 0x2C],
+                       dtype=torch.int64, device=dev)                                      # BF6 (E3M2) code of nibble n
+    c6 = lut[nib].reshape(M, G, 32, 4)
+    w24 = c6[..., 0] | (c6[..., 1] << 6) | (c6[..., 2] << 12) | (c6[..., 3] << 18)
+    by = torch.stack([(w24 >> (8 * i)) & 0xFF for i in range(3)], dim=-1).to(torch.uint8).reshape(M, G, 96)
+    a6 = torch.zeros((G, aops.f6_rows(M), 104), dtype=torch.uint8, device=dev)
+    a6[:, :M, :96] = by.permute(1, 0, 2)
+    a6[:, :M, 96:98] = ops_[2].reshape(G, M, 1).view(torch.uint8).reshape(G, M, 2)         # sA[g, m] rides in the row
+    b6 = aops.repack_weight_f6(ops_[1].view(torch.uint8))
+    return a6, b6
 
 
 def main():
@@ -109,6 +137,8 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--format", choices=["f6", "packed", "wide"], default="f6",
+                    help="operand format of the headline measurement (the other two are reported beside it at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -132,11 +162,30 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     ptrs = [t.data_ptr() for t in ops_]
 
-    def step():
-        st = lib.atom_gemm_w4a4_f16(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN, stream)
-        if st != 0:
-            L.check(st, "atom_gemm_w4a4_f16")
+    # the three operand formats of the same GEMM (same codes, same scales, bit-identical results)
+    a4 = ops_[0].view(torch.uint8).view(M, (K - 128) // 32, 16)
+    wide = torch.stack([(a4 << 4) & 0xF0, a4 & 0xF0], dim=2).reshape(M, K - 128).contiguous()
+    a6, b6 = build_f6_operands(ops_, M, N, K, dev)
+    variants = {
+        "packed": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+                   "reference format: packed INT4 nibbles (punica.ops ABI), INT8 MFMA after in-kernel widening"),
+        "wide": ([wide.data_ptr()] + ptrs[1:], L.SCALE_LAYOUT_PLAIN | L.A_WIDE,
+                 "activations int8 = code*16 (ATOM_A_WIDE), weights packed INT4, INT8 MFMA"),
+        "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6,
+               "both operands BF6 group-major (ATOM_AB_F6): v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, "
+               "exact integer dot products; the format the fused quantisers emit for prefill batches"),
+    }
 
+    def make_step(name):
+        vp, layout, _ = variants[name]
+
+        def step():
+            st = lib.atom_gemm_w4a4_f16(*vp, D.data_ptr(), M, N, K, 128, 128, layout, stream)
+            if st != 0:
+                L.check(st, "atom_gemm_w4a4_f16")
+        return step
+
+    step = make_step(args.format)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -156,32 +205,28 @@ def main():
     kern_ms = e0.elapsed_time(e1) / args.steps                  # HIP events on the launch stream
     wall, kern_ms = max_over_ranks([wall, kern_ms], dist, dev)
 
-    # Second line of evidence (N=1 only, reported beside the headline, never as `value`): the same GEMM fed the native
-    # activation format the fused quant kernels can emit (int8 code*16, ATOM_A_WIDE) instead of the reference's packed
-    # nibbles -- the format the B1 modules use for prefill-sized batches.
-    native = None
+    # N=1 only: the other operand formats beside the headline, and a bit-for-bit comparison of the outputs
+    others = {}
     if world == 1:
-        a4 = ops_[0].view(torch.uint8).view(M, (K - 128) // 32, 16)
-        wide = torch.stack([(a4 << 4) & 0xF0, a4 & 0xF0], dim=2).reshape(M, K - 128).contiguous()
-        wptrs = [wide.data_ptr()] + ptrs[1:]
-
-        def step_w():
-            st = lib.atom_gemm_w4a4_f16(*wptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.A_WIDE, stream)
-            if st != 0:
-                L.check(st, "atom_gemm_w4a4_f16")
-
-        for _ in range(args.warmup):
-            step_w()
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(args.steps):
-            step_w()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        wms = e0.elapsed_time(e1) / args.steps
-        native = {"value": round(2.0 * M * N * K / (wms * 1e-3) / 1e12, 2), "unit": "TOPS", "kernel_us": round(wms * 1e3, 2),
-                  "frac": round(2.0 * M * N * K / (wms * 1e-3) / 1e12 / PEAK_I8_TOPS, 4),
-                  "format": "activations int8 = code*16 (ATOM_A_WIDE), weights packed INT4"}
+        D_head = D.clone()
+        for name in variants:
+            if name == args.format:
+                continue
+            st2 = make_step(name)
+            for _ in range(args.warmup):
+                st2()
+            torch.cuda.synchronize(dev)
+            same = bool(torch.equal(D, D_head))
+            e0.record()
+            for _ in range(args.steps):
+                st2()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / args.steps
+            tops = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+            others[name] = {"value": round(tops, 2), "unit": "TOPS", "kernel_us": round(ms * 1e3, 2),
+                            "frac": round(tops / PEAK_I8_TOPS, 4), "bit_identical_to_headline_output": same,
+                            "format": variants[name][2]}
 
     if rank == 0:
         agg = aggregate(world, args.steps, wall, kern_ms, M, N, K)
@@ -191,17 +236,22 @@ def main():
             "metric": "effective TOPS, W4A4 group-128 GEMM + 128 INT8 outlier cols, fp16 out",
             "value": round(tops, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(agg["ms_per_step"], 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int4xint4->int32 (i8 MFMA), fp32 dequant, fp16 out", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "int4xint4 exact integer dot (BF6-coded on the block-scaled MFMA; INT8 MFMA for the keeper), fp32 dequant, fp16 out"
+                     if args.format == "f6" else "int4xint4->int32 (i8 MFMA), fp32 dequant, fp16 out",
+            "data": "synthetic",
             "config": {"workload": f"W4A4 GEMM M={M} N={N} K={K} group=128 keeper=128 (BASELINE configs[2])",
-                       "M": M, "N": N, "K": K, "parallelism": f"replicas x{world}"},
+                       "M": M, "N": N, "K": K, "parallelism": f"replicas x{world}", "operand_format": args.format,
+                       "operand_format_note": variants[args.format][2]},
             "gbps": round(agg["gbps"], 1),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_I8_TOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": measured_traffic(M, N, K),
+                         "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": measured_traffic(M, N, K, args.format),
                          "kernel_us": round(kern_ms * 1e3, 2),
-                         "algorithmic_bytes": algorithmic_bytes(M, N, K), "algorithmic_ops": int(ops_per_step)},
+                         "algorithmic_bytes": algorithmic_bytes(M, N, K), "algorithmic_ops": int(ops_per_step),
+                         "peak_note": "dense INT8 MFMA peak (BASELINE.md); the BF6 MFMA this format runs on peaks at ~10 POPS"},
         }
-        if native is not None:
-            out["native_wide_activations"] = native
+        if others:
+            out["other_operand_formats"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N, K)
         print(json.dumps(out), flush=True)

@@ -245,6 +245,13 @@ int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void
 int atom_kv_fake_quant_f16(const void *x, void *y, int64_t batch, int num_heads, int64_t seq_len, int64_t stride_b,
                            int64_t stride_h, int64_t stride_s, int n_bits, float clip, void *stream);
 
+/* Rows per group of an F6 operand buffer: `rows` rounded up to 256 (buffer bytes = G * atom_f6_rows(rows) * 104). */
+size_t atom_f6_rows(int64_t rows);
+
+/* Packed INT4 weights B4 [N, K4/2] -> the F6 format (see ATOM_AB_F6): B_f6 uint8 [G][atom_f6_rows(N)][104], pad rows and
+ * bytes 96..103 zeroed.  Offline, once per weight. */
+int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,34 @@ def wide_codes(q4):
     blk = q.reshape(M, K4 // 32, 16, 2)                      # [.., j, p]
     out = np.transpose(blk, (0, 1, 3, 2)).reshape(M, K4)     # [.., p, j]
     return (out.astype(np.int16) * 16).astype(np.int8)
+
+
+_BF6_MAG = [0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18]
+
+
+def f6_codes(q4, scales=None):
+    """int8 codes [M, K4] (+ fp16 scales [M, G]) -> the F6 operand buffer uint8 [G][round_up(M,256)][104]
+    (include/atom_hip.h, ATOM_AB_F6): 6-bit BF6 (E3M2) fields, little-endian, scale at byte 96; pad rows zero."""
+    q = np.asarray(q4, dtype=np.int64)
+    M, K4 = q.shape
+    G = K4 // 128
+    rp = (M + 255) // 256 * 256
+    lut = np.array([(0x20 if v < 0 else 0) | _BF6_MAG[abs(v)] for v in range(-8, 8)], dtype=np.uint64)
+    c = lut[q + 8].reshape(M, G, 32, 4)                                   # 4 fields = 24 bits = 3 bytes
+    w = c[..., 0] | (c[..., 1] << 6) | (c[..., 2] << 12) | (c[..., 3] << 18)
+    b = np.stack([(w >> (8 * i)) & 0xFF for i in range(3)], axis=-1).astype(np.uint8).reshape(M, G, 96)
+    out = np.zeros((G, rp, 104), dtype=np.uint8)
+    out[:, :M, :96] = np.transpose(b, (1, 0, 2))
+    if scales is not None:
+        sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float16).T).view(np.uint8).reshape(G, M, 2)
+        out[:, :M, 96:98] = sc
+    return out
+
+
+def f6_fields(buf):
+    """F6 buffer [G, rows, 104] -> the 6-bit fields [G, rows, 128] with the code of -0 (0x20) folded onto +0."""
+    b = np.asarray(buf, dtype=np.uint64)[..., :96].reshape(*buf.shape[:2], 32, 3)
+    w = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    f = np.stack([(w >> (6 * i)) & 0x3F for i in range(4)], axis=-1).reshape(*buf.shape[:2], 128).astype(np.uint8)
+    f[f == 0x20] = 0
+    return f

@@ -225,3 +225,46 @@ def test_gemm_wide_full_size_and_errors():
         st = ops.L.lib().atom_gemm_w4a4_o4(aw.data_ptr(), *[x.data_ptr() for x in t[1:]], t[0].data_ptr(),
                                            t[2].data_ptr(), 4096, 4096, 4096, 128, 128, 1 | ops.L.A_WIDE, None)
         ops.L.check(st, "atom_gemm_w4a4_o4")
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 512, 512), (257, 1024, 1152), (300, 64, 1280), (1024, 1024, 2176), (5, 256, 640)])
+def test_gemm_f6_operands_bit_identical(M, N, K):
+    """ATOM_AB_F6: both operands as BF6 streams on the block-scaled MFMA (gemm_w4a4_f6.hip).  Integer dot products are
+    exact there too and the FP32 de-quantisation order is the same: equal to the packed call bit for bit where that one
+    runs the MFMA tile kernel without split-K, and to the exact oracle everywhere.  The weight comes from
+    atom_repack_weight_f6, the activation buffer is built on the host here (the quantiser path is tested below)."""
+    from tests.helpers import f6_codes
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M * 11 + N + K)
+    t = to_device(d, "plain")
+    a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+    b6 = ops.repack_weight_f6(t[1])
+    assert np.array_equal(t2n(b6), f6_codes(d["qb4"]))
+    out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
+    assert_gemm_close(t2n(out), _exact(d), f"f6 {M}x{N}x{K}")
+    if M >= 8 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+        assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"))
+
+
+def test_gemm_f6_full_size_from_the_quantiser():
+    """Headline shape end to end in the native format: activation quantiser (ATOM_QUANT_F6_CODES) -> F6 GEMM equals
+    activation quantiser (packed) -> INT8 GEMM, bit for bit."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M = N = K = 4096
+    x = (torch.randn((M, K), device="cuda", generator=g) * 1.5).half()
+    W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).half()
+    b4, b8, sb, sb8 = ops.quant_weight_w4(W, 0.85, 2)
+    p = ops.reorder_fp16_i4(x, None, quant_mode="sim", clip=0.9, scale_layout="plain")
+    f = ops.reorder_fp16_i4(x, None, quant_mode="sim", clip=0.9, scale_layout="plain", wide_codes="f6")
+    assert torch.equal(p[0], f[0]) and torch.equal(p[2], f[2]) and torch.equal(p[3], f[3])
+    from tests.helpers import f6_codes, f6_fields
+    want6 = f6_codes(O.unpack_int4(t2n(p[1]).view(np.uint8)), t2n(p[3]).T)
+    got6 = t2n(f[1])
+    # same codes (a value that rounded to zero from below is stored as BF6 -0: same number) and same in-row scales
+    assert np.array_equal(f6_fields(got6[:, :M]), f6_fields(want6[:, :M]))
+    assert np.array_equal(got6[:, :M, 96:], want6[:, :M, 96:])
+    ref = ops.dense_layer_gemm_i4_fp16(p[1], b4, p[3], sb, p[0], b8, p[2], sb8, scale_layout="plain")
+    out = ops.dense_layer_gemm_i4_fp16(f[1], ops.repack_weight_f6(b4), f[3], sb, f[0], b8, f[2], sb8,
+                                       scale_layout="plain", a_wide="f6")
+    assert torch.equal(out, ref)

@@ -218,3 +218,30 @@ def test_add_rmsnorm_is_add_then_rmsnorm(M, H, mode, clip):
     res2 = res.clone()
     got2 = ops.add_rmsnorm_fp16_i4(x, res2, w, idx, 1e-5, inplace=True, quant_mode=mode, clip=clip, scale_layout="plain")
     assert got2[0] is res2 and torch.equal(res2, s_ref) and torch.equal(got2[2], want[1])
+
+
+def test_f6_codes_from_all_three_quantisers():
+    """ATOM_QUANT_F6_CODES: the BF6 group-major buffer holds the same codes as the packed call (decoded field by field;
+    -0 and +0 are the same code value) and the scale of every (row, group) at byte 96 of its row."""
+    from tests.helpers import f6_codes, f6_fields
+    ops = _ops()
+    M, H = 300, 1024
+    x = torch.from_numpy(rand_act(M, H, seed=5)).cuda()
+    b = torch.from_numpy(rand_act(M, H, seed=6, outliers=False)).cuda()
+    w = torch.from_numpy((1 + 0.1 * np.random.default_rng(2).standard_normal(H)).astype(np.float16)).cuda()
+    idx = torch.from_numpy(np.random.default_rng(3).permutation(H).astype(np.int16)).cuda()
+    calls = [lambda **k: ops.reorder_fp16_i4(x, idx, scale_layout="plain", **k),
+             lambda **k: ops.rmsnorm_fp16_i4(x, w, idx, 1e-5, scale_layout="plain", **k),
+             lambda **k: ops.activate_fp16_i4(x, b, scale_layout="plain", **k),
+             lambda **k: ops.add_rmsnorm_fp16_i4(x, b, w, idx, 1e-5, scale_layout="plain", **k)[1:]]
+    for mode, clip in (("sim", 0.9), ("kernel", 1.0)):
+        for call in calls:
+            p = call(quant_mode=mode, clip=clip)
+            f = call(quant_mode=mode, clip=clip, wide_codes="f6")
+            assert f[1].shape == (H // 128 - 1, 512, 104) and f[1].dtype == torch.uint8
+            want = f6_codes(O.unpack_int4(t2n(p[1]).view(np.uint8)), t2n(p[3]).T)
+            got = t2n(f[1])
+            assert np.array_equal(f6_fields(got[:, :M]), f6_fields(want[:, :M]))
+            assert np.array_equal(got[:, :M, 96:], want[:, :M, 96:])
+            for a, c in zip((p[0], p[2], p[3]), (f[0], f[2], f[3])):
+                assert torch.equal(a, c)
