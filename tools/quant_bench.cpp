@@ -21,18 +21,19 @@ int main(int argc, char **argv) {
   hipMalloc(&x, hx.size() * 2); hipMalloc(&b, hx.size() * 2); hipMalloc(&w, H * 2); hipMalloc(&idx, H * 2);
   hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(b, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(w, hw.data(), H * 2, hipMemcpyHostToDevice); hipMemcpy(idx, hidx.data(), H * 2, hipMemcpyHostToDevice);
-  hipMalloc(&o8, (size_t)M * 128); hipMalloc(&o4, (size_t)M * (H - 128) / 2); hipMalloc(&s8, (size_t)M * 8 + 256); hipMalloc(&s4, (size_t)(H / 128) * (M * 8 + 256));
+  hipMalloc(&o8, (size_t)M * 128); hipMalloc(&o4, (size_t)(H / 128) * ((size_t)(M + 255) / 256 * 256) * 104 + (size_t)M * H);  /* large enough for every code format */ hipMalloc(&s8, (size_t)M * 8 + 256); hipMalloc(&s4, (size_t)(H / 128) * (M * 8 + 256));
   hipMalloc(&xq, hx.size() * 2);
+  const int fmt = getenv("ATOM_QB_FMT") ? atoi(getenv("ATOM_QB_FMT")) : 0;   // 0 packed, 0x100 wide, 0x200 F6
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double out_bytes = (double)M * ((H - 128) / 2 + 128 + 2.0 * (H / 128));
   for (int op = 0; op < 3; ++op) for (int mode = 0; mode < 2; ++mode) for (int dq = 0; dq < 2; ++dq) {
     auto run = [&]() {
       void *xo = dq ? xq : nullptr;
-      if (op == 0) return atom_reorder_quant_f16(x, noidx ? nullptr : (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
-      if (op == 1) return atom_rmsnorm_reorder_quant_f16(x, w, 1e-5f, (const int16_t *)idx, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
-      return atom_silu_mul_quant_f16(x, b, M, H, mode, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      if (op == 0) return atom_reorder_quant_f16(x, noidx ? nullptr : (const int16_t *)idx, M, H, mode | fmt, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      if (op == 1) return atom_rmsnorm_reorder_quant_f16(x, w, 1e-5f, (const int16_t *)idx, M, H, mode | fmt, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
+      return atom_silu_mul_quant_f16(x, b, M, H, mode | fmt, mode ? 0.9f : 1.0f, 1, o8, o4, s8, s4, xo, nullptr);
     };
-    for (int i = 0; i < 10; ++i) if (run()) { printf("error\n"); return 1; }
+    for (int i = 0; i < 10; ++i) { int st = run(); if (st) { printf("error %d (%s) op=%d mode=%d dq=%d\n", st, atom_strerror(st), op, mode, dq); return 1; } }
     hipEventRecord(e0);
     for (int i = 0; i < iters; ++i) run();
     hipEventRecord(e1); hipEventSynchronize(e1);
