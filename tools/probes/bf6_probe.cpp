@@ -56,6 +56,24 @@ __global__ void rate_kernel(float *out, int iters) {
   }
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ void rate16(float *out, int iters) {
+  v8i a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 7 + i; b[i] = threadIdx.x * 3 + i; }
+  v4f c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c0, 3, 3, 0, 127, 0, 127);
+    c1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c1, 3, 3, 0, 127, 0, 127);
+    c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c2, 3, 3, 0, 127, 0, 127);
+    c3 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c3, 3, 3, 0, 127, 0, 127);
+    c4 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c4, 3, 3, 0, 127, 0, 127);
+    c5 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c5, 3, 3, 0, 127, 0, 127);
+    c6 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c6, 3, 3, 0, 127, 0, 127);
+    c7 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c7, 3, 3, 0, 127, 0, 127);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+}
+
 int main() {
   std::mt19937 rng(1);
   std::vector<int> Am(32 * 64), Bm(32 * 64);            // A[i][k], B[j][k], values -8..7 (and 8 for coverage)
@@ -119,6 +137,17 @@ int main() {
     const double ns_per = ms * 1e6 / mfmas;
     const double ops = 256.0 * 4 * mfmas * 2.0 * 32 * 32 * (mode == 0 ? 64 : 32);
     printf("PROBE rate %s: %.2f ns per MFMA per SIMD, %.0f Tops/s chip\n", mode == 0 ? "bf6 32x32x64 scaled" : "i8 32x32x32", ns_per, ops / (ms * 1e-3) / 1e12);
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    rate16<<<256, 256>>>(dout, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+  }
+  {
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mfmas = 8.0 * iters;
+    printf("PROBE rate bf6 16x16x128 scaled: %.2f ns per MFMA per SIMD, %.0f Tops/s chip\n", ms * 1e6 / mfmas,
+           256.0 * 4 * mfmas * 2.0 * 16 * 16 * 128 / (ms * 1e-3) / 1e12);
   }
   return 0;
 }
