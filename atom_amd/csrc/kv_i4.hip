@@ -131,19 +131,25 @@ struct TileRegs {     // one 16-token tile's operands of this lane, as loaded
   unsigned kq, vq;    // (scale, zero) half2 of my token
 };
 
-__device__ __forceinline__ TileRegs load_tile(const DecodeParams &p, int pg0, int tile, int tpp, int t, int u, int h) {
-  const int N = p.kv.N, P = p.kv.P;
-  const int64_t page = p.kv.indices[pg0 + tile / tpp];
-  const int e = (tile % tpp) * 16 + t;                  // entry inside the page
-  const int64_t base = ((page * p.kv.L + p.kv.layer) * 2 * N + h) * P;             // K block of (page, layer, head)
-  const uint8_t *kp = p.kv.data + (base + e) * 64;
-  const uint8_t *vp = kp + (int64_t)N * P * 64;
+// Everything about a tile's addresses except the page number is loop-invariant: per wave (layer, head) and per lane
+// (token slot, quarter).  Per tile that leaves one 64-bit scalar multiply-add per region instead of the ~130 SALU + 36
+// VALU of the straightforward indexing.
+struct TileBase {
+  const uint8_t *k;          // data  + (layer, K, head) offset;  V is + vdelta
+  const half_t *kq;          // param + (layer, K, head) offset;  V is + vqdelta
+  int64_t page_bytes, page_halves, vdelta, vqdelta;
+  int lk, lv, lq;            // per-lane byte / half offsets inside a 16-token tile
+};
+
+__device__ __forceinline__ TileRegs load_tile(const TileBase &tb, int64_t page, int sub) {
+  const uint8_t *kp = tb.k + page * tb.page_bytes + sub * (16 * 64);
+  const half_t *qp = tb.kq + page * tb.page_halves + sub * (16 * 2);
   TileRegs r;
-  r.k1 = *reinterpret_cast<const v2u *>(kp + 8 * u);
-  r.k2 = *reinterpret_cast<const v2u *>(kp + 32 + 8 * u);
-  r.v = *reinterpret_cast<const v4u *>(vp + 16 * u);
-  r.kq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + e) * 2);
-  r.vq = *reinterpret_cast<const unsigned *>(p.kv.param + (base + (int64_t)N * P + e) * 2);
+  r.k1 = *reinterpret_cast<const v2u *>(kp + tb.lk);
+  r.k2 = *reinterpret_cast<const v2u *>(kp + tb.lk + 32);
+  r.v = *reinterpret_cast<const v4u *>(kp + tb.vdelta + tb.lv);
+  r.kq = *reinterpret_cast<const unsigned *>(qp + tb.lq);
+  r.vq = *reinterpret_cast<const unsigned *>(qp + tb.vqdelta + tb.lq);
   return r;
 }
 
@@ -159,9 +165,26 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
   const int tpp = P >> 4;                               // 16-token tiles per page
 
-  TileRegs cur, nxt;                                    // two tiles in flight ahead of the one being computed
-  if (tile0 < tile1) cur = load_tile(p, pg0, tile0, tpp, t, u, h);
-  if (tile0 + 1 < tile1) nxt = load_tile(p, pg0, tile0 + 1, tpp, t, u, h);
+  // two tiles in flight ahead of the one being computed, and the page index (a dependent scalar load) one tile ahead of
+  // that: otherwise every iteration waits for the page table before it can issue its vector loads
+  TileBase tb;
+  {
+    const int64_t blk = (int64_t)N * P;                  // tokens x heads of one (page, layer, K|V) block
+    tb.k = p.kv.data + ((int64_t)p.kv.layer * 2 * N + h) * P * 64;
+    tb.kq = p.kv.param + ((int64_t)p.kv.layer * 2 * N + h) * P * 2;
+    tb.page_bytes = (int64_t)p.kv.L * 2 * blk * 64;
+    tb.page_halves = (int64_t)p.kv.L * 2 * blk * 2;
+    tb.vdelta = blk * 64;
+    tb.vqdelta = blk * 2;
+    tb.lk = t * 64 + 8 * u;
+    tb.lv = t * 64 + 16 * u;
+    tb.lq = t * 2;
+  }
+  auto page_of = [&](int tile) { return (int64_t)p.kv.indices[pg0 + min(tile, ntiles - 1) / tpp]; };
+  TileRegs cur, nxt;
+  if (tile0 < tile1) cur = load_tile(tb, page_of(tile0), tile0 % tpp);
+  if (tile0 + 1 < tile1) nxt = load_tile(tb, page_of(tile0 + 1), (tile0 + 1) % tpp);
+  int64_t page2 = page_of(tile0 + 2);
 
   // q rotated to the relative position of MY token of the first tile: A = R((len-1 - j) f) q, pairs (i, i+64)
   float A1[16], A2[16], C16[16], S16[16];
@@ -197,7 +220,8 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   for (int tile = tile0; tile < tile1; ++tile) {
     const TileRegs r = cur;
     cur = nxt;
-    if (tile + 2 < tile1) nxt = load_tile(p, pg0, tile + 2, tpp, t, u, h);
+    if (tile + 2 < tile1) nxt = load_tile(tb, page2, (tile + 2) % tpp);
+    page2 = page_of(tile + 3);
     const bool valid = tile * 16 + t < seq_len;
 
     // score = sum over my 16 pairs of (u1*ks - kz) * A1 + (u2*ks - kz) * A2 = ks * sum((1024+u) . A) - (kz + 1024 ks) * sum(A)
@@ -248,6 +272,8 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
       for (int k = 0; k < 4; ++k) {
         o[8 * w + k] = __builtin_fmaf(ps, (float)mv[k].x, o[8 * w + k]);
         o[8 * w + 4 + k] = __builtin_fmaf(ps, (float)mv[k].y, o[8 * w + 4 + k]);
+        // one v_fma_mix_f32 each: without the anchors hipcc converts the halves first and SLP-packs (cvt + pk_fma + moves)
+        asm volatile("" : "+v"(o[8 * w + k]), "+v"(o[8 * w + 4 + k]));
       }
     }
     // my token of the next tile is 16 positions later: A <- R(-16 f) A = (A1 C + A2 S, A2 C - A1 S)
