@@ -74,7 +74,12 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       return launch_gemm_v3(p, variant - 300, hs);
     }
     default:                                                        // product path
-      if (p.f6_rows_a) return launch_gemm_f6(p, hs);           // BF6 operands: block-scaled MFMA kernel, 256x256 tiles
+      if (p.f6_rows_a) {                                      // BF6 operands: block-scaled MFMA kernels
+        static const int force = [] { const char *e = getenv("ATOM_F6_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+        const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, cn128 = (N + 127) / 128;
+        const int cfg = force >= 0 ? force : (cm256 * cn256 >= 192 ? 0 : (cm256 * cn128 >= 256 ? 1 : 2));
+        return launch_gemm_f6(p, cfg, hs);
+      }
       if (p.a_wide) {   // activations pre-widened by the quant kernels: 256x256 tiles once they fill half the chip
         const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
         const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
@@ -156,7 +161,7 @@ size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
                           const void *sA8, const void *sB8, void *D, int64_t M, int64_t N, int64_t K_total, int group,
                           int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream) {
-  const size_t need = (scale_layout & ATOM_AB_F6) ? 0 : atom_gemm_w4a4_workspace_bytes(M, N, K_total);
+  const size_t need = atom_gemm_w4a4_workspace_bytes(M, N, K_total);
   if (need == 0 || !workspace || workspace_bytes < need)
     return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
   if (!D) return ATOM_ERR_INVALID_ARG;
@@ -167,6 +172,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.D = (half_t *)D;
   p.ws = (float *)workspace;
   p.splits = choose_splits(M, N, K_total);
+  if (p.f6_rows_a) return launch_gemm_f6(p, 2, reinterpret_cast<hipStream_t>(stream));
   return launch_gemm_v3(p, p.a_wide ? 25 : 5, reinterpret_cast<hipStream_t>(stream));
 }
 

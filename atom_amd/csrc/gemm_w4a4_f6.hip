@@ -20,6 +20,9 @@
 #include "common.h"
 
 namespace atom {
+
+__global__ void splitk_reduce_kernel(const float *ws, half_t *D, int64_t MN, int splits);   // gemm_w4a4_v3.hip
+
 namespace f6 {
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -27,63 +30,85 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 256, BN = 256, NS = 3, TM = 4, TN = 2, NW = 8, NT = 512;
+constexpr int TN = 2;                                    // a wave covers 32*TM tokens x 64 features
 constexpr int PITCH = 104;                               // bytes per row and group
-constexpr int W_BYTES = BN * PITCH, A_OFF = W_BYTES;     // 26,624 = 26 DMA blocks each
-constexpr int DATA_BYTES = (BN + BM) * PITCH;            // 53,248
-constexpr int SB_OFF = DATA_BYTES;                       // BN fp16 weight scales (int4 steps and keeper)
-constexpr int STAGE_BYTES = DATA_BYTES + BN * 2;         // 53,760; x3 = 161,280 <= 160 KiB
-constexpr int KP_SA_OFF = (BN + BM) * 64;                // keeper half-steps: rows of 64 bytes, then BM dwords of sA8
-constexpr int GLDS = 7;                                  // DMA instructions per wave and stage: 52 data blocks + 2 scale
-                                                         // pieces (+ 2 repeats) = 56
-constexpr int EP_BYTES = NW * 64 * 144;
-constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
 constexpr float kMagic = 12582912.0f;
 constexpr int kMagicBits = 0x4B400000;
-static_assert(W_BYTES % 1024 == 0 && NS * STAGE_BYTES <= 160 * 1024, "stage geometry");
 
+// Tile geometry.  Three instances: 256x256 (8 waves, one workgroup per CU) once the shape yields ~200 of them,
+// 256x128 (4 waves, two workgroups per CU, two stages), and 64x128 (2 waves, several workgroups per CU, split-K) for
+// skinny M.
+template <int BM_, int BN_, int TM_, int NS_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, TM = TM_, NS = NS_;
+  static constexpr int WM = 32 * TM, WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
+  static constexpr int W_BYTES = BN * PITCH, A_BYTES = BM * PITCH;
+  static constexpr int NBW = W_BYTES / 1024;                           // whole 1 KiB DMA blocks of the weight rows
+  static constexpr int NBA = (A_BYTES + 1023) / 1024;                  // activation rows: the last block may be partial
+  static constexpr int A_TAIL = (A_BYTES % 1024) / 16;                 // lanes of that partial block (0 = it is whole)
+  static constexpr int NSB = BN / 128;                                 // weight-scale pieces (128 fp16 = 64 dwords each)
+  static constexpr int A_OFF = W_BYTES;
+  static constexpr int SB_OFF = W_BYTES + NBA * 1024;                  // BN fp16 weight scales (int4 steps and keeper)
+  static constexpr int STAGE_BYTES = SB_OFF + BN * 2;
+  static constexpr int KP_SA_OFF = (BN + BM) * 64;                     // keeper half-steps: rows of 64 B, then BM dwords sA8
+  static constexpr int NPIECE = NBW + NBA + NSB;                       // DMA instructions per int4 stage
+  static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB;           // ... per keeper half-step
+  static constexpr int GLDS = ((NPIECE > NKP ? NPIECE : NKP) + NW - 1) / NW;   // per wave, padded with repeats
+  static constexpr int EP_BYTES = NW * 64 * 144;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
+  static_assert(BN % 128 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4) && NS >= 2, "geometry");
+  static_assert(KP_SA_OFF + BM * 4 <= SB_OFF && LDS_BYTES <= 160 * 1024, "stage layout");
+};
+
+template <class C>
 __device__ __forceinline__ void issue_int4(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0) {
   const uint8_t *wsrc = p.B4 + ((int64_t)g * p.f6_rows_b + n0) * PITCH;
-  const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - W_BYTES;   // so that block j >= 26 is asrc + j*1024
-  // block j = 8*i + wave: i <= 2 is always weights, i = 4, 5 always activations -- compile-time; i = 3 straddles the
-  // boundary (one uniform pointer select), i = 6 carries the last 4 activation blocks and the 2 scale pieces
+  const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - C::W_BYTES;   // block j >= NBW is asrc + j*1024
 #pragma unroll
-  for (int i = 0; i < GLDS - 1; ++i) {
-    const int j = 8 * i + wave;
-    const uint8_t *base = (i < 3 || (i == 3 && j < 26)) ? wsrc : asrc;
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
-  }
-  if (wave < 4) {
-    const int j = 48 + wave;
-    __builtin_amdgcn_global_load_lds((gptr_t)(asrc + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
-  } else {                                               // 128 weight scales per piece, a dword (2 channels) per lane;
-    const int part = wave & 1;                           // waves 6, 7 repeat the pieces of waves 4, 5
-    const half_t *sBb = p.sB + (int64_t)g * p.N;
-    const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-    __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + SB_OFF + part * 256), 4, 0, 0);
+  for (int i = 0; i < C::GLDS; ++i) {
+    int j = i * C::NW + wave;                              // piece j: NBW weight blocks, NBA activation blocks, NSB scales
+    j = j < C::NPIECE ? j : j - C::NSB;                    // padding repeats a scale piece (same bytes, same place)
+    if (i * C::NW + C::NW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {            // compile time: whole data blocks only
+      const uint8_t *base = (i * C::NW + C::NW <= C::NBW || j < C::NBW) ? wsrc : asrc;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+    } else if (j < C::NBW + C::NBA) {
+      const uint8_t *base = j < C::NBW ? wsrc : asrc;
+      // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
+      if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+    } else {                                               // 128 weight scales per piece, a dword (2 channels) per lane
+      const int part = j - (C::NBW + C::NBA);
+      const half_t *sBb = p.sB + (int64_t)g * p.N;
+      const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
+      __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
+    }
   }
 }
 
 // keeper half-step `half` (0 / 1): the INT8 kernel's layout -- 16 rows x 64 B per DMA block, XOR-swizzled chunks
+template <class C>
 __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char *slot, int wave, int lane, int m0, int n0) {
   // only two of these per tile: addresses are computed here instead of living in registers through the int4 loop
   const unsigned kj = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  constexpr int ND = (C::BN + C::BM) / 16, NSA = C::BM / 64;
 #pragma unroll
-  for (int i = 0; i < GLDS; ++i) {
-    if (i < 4) {
-      const int gidx = wave * 4 + i;                     // 32 blocks: 16 weight, 16 activation
-      const int row = gidx * 16 + (lane >> 2);
-      const unsigned idx = (unsigned)(gidx < 16 ? min(n0 + row, p.N - 1) : min(m0 + row - BN, p.M - 1));
-      const uint8_t *base = (gidx < 16 ? p.B8 : p.A8) + half * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + idx * kKeeper + kj), (lptr_t)(slot + gidx * 1024), 16, 0, 0);
-    } else if (i == 4 && wave < 4) {                     // sA8 of 64 tokens: one fp16 per lane -> zero-extended dword
-      const int idx = min(m0 + wave * 64 + lane, p.M - 1);
+  for (int i = 0; i < C::GLDS; ++i) {
+    int j = i * C::NW + wave;
+    j = j < C::NKP ? j : ND + NSA + (j % C::NSB);          // padding repeats a weight-scale piece
+    if (i * C::NW + C::NW <= ND || j < ND) {               // (first half: known at compile time)
+      const int row = j * 16 + (lane >> 2);
+      const unsigned idx = (unsigned)(j < C::BN / 16 ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
+      const uint8_t *base = (j < C::BN / 16 ? p.B8 : p.A8) + half * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + idx * kKeeper + kj), (lptr_t)(slot + j * 1024), 16, 0, 0);
+    } else if (j < ND + NSA) {                             // sA8 of 64 tokens: one fp16 per lane -> zero-extended dword
+      const int pc = j - ND;
+      const int idx = min(m0 + pc * 64 + lane, p.M - 1);
       const unsigned ksa = (unsigned)(p.ref_layout ? ref_scale_index(idx) : idx);
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.sA8 + ksa), (lptr_t)(slot + KP_SA_OFF + wave * 256), 2, 0, 0);
-    } else {                                             // sB8 (two pieces; the other waves repeat one of them)
-      const int part = wave & 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.sA8 + ksa), (lptr_t)(slot + C::KP_SA_OFF + pc * 256), 2, 0, 0);
+    } else {
+      const int part = j - ND - NSA;
       const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.sB8 + n), (lptr_t)(slot + SB_OFF + part * 256), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.sB8 + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
     }
   }
 }
@@ -109,11 +134,13 @@ __device__ __forceinline__ void dequant16(const float (&acc)[16], float sa, cons
 }
 
 // one int4 group out of LDS: 2 BF6 MFMAs per 32x32 tile
-__device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+template <class C>
+__device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+  constexpr int TM = C::TM;
   const int l31 = lane & 31, h = lane >> 5;
-  const char *pw = slot + (wn * 64 + l31) * PITCH + h * 24;             // + tn*32*PITCH + s*48
-  const char *pa = slot + A_OFF + (wm * 128 + l31) * PITCH + h * 24;    // + tm*32*PITCH + s*48
-  const char *psb = slot + SB_OFF + (wn * 64 + 4 * h) * 2;              // + tn*64 + 16*q
+  const char *pw = slot + (wn * 64 + l31) * PITCH + h * 24;                   // + tn*32*PITCH + s*48
+  const char *pa = slot + C::A_OFF + (wm * C::WM + l31) * PITCH + h * 24;     // + tm*32*PITCH + s*48
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * h) * 2;                 // + tn*64 + 16*q
   v8i af[TN][2];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
@@ -152,15 +179,17 @@ __device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, i
 }
 
 // keeper half-step out of LDS (INT8 MFMA, magic-biased accumulator), de-quantised per half
-__device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+template <class C>
+__device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+  constexpr int TM = C::TM;
   const int l31 = lane & 31, h = lane >> 5;
   const int sw = (l31 >> 2) & 3;
   const char *pw0 = slot + (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4);
   const char *pw1 = slot + (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
-  const char *pa0 = slot + (BN + wm * 128 + l31) * 64 + (((0 + h) ^ sw) << 4);
-  const char *pa1 = slot + (BN + wm * 128 + l31) * 64 + (((2 + h) ^ sw) << 4);
-  const char *psa = slot + KP_SA_OFF + (wm * 128 + l31) * 4;
-  const char *psb = slot + SB_OFF + (wn * 64 + 4 * h) * 2;
+  const char *pa0 = slot + (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4);
+  const char *pa1 = slot + (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
+  const char *psa = slot + C::KP_SA_OFF + (wm * C::WM + l31) * 4;
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * h) * 2;
   v4i af[TN][2];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -196,14 +225,17 @@ __device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn,
   }
 }
 
-__global__ __launch_bounds__(NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
+template <class C, bool SK>
+__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int TM = C::TM, NS = C::NS;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / 4, wn = wave % 4;
+  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
 
-  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
   const int nwg = nbm * nbn;
   int id = blockIdx.x;
   {
@@ -214,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
   const int band = id / (GM * nbn), inband = id % (GM * nbn);
   const int rows_in_band = min(GM, nbm - band * GM);
   const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
-  const int m0 = bm * BM, n0 = bn * BN;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
 
   float c[TN][TM][16];
 #pragma unroll
@@ -224,33 +256,55 @@ __global__ __launch_bounds__(NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
 
-  const int nsteps = p.G + 2;
+  // split-K (SK): blockIdx.y owns the K steps [s_begin, nsteps) and writes FP32 partial sums to p.ws
+  const int total_steps = p.G + 2;
+  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
+  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;
   auto issue = [&](int step) {
-    char *slot = lds + (step % NS) * STAGE_BYTES;
+    char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
-    if (s < p.G) issue_int4(p, s, slot, wave, lane, m0, n0);
-    else issue_keeper(p, s - p.G, slot, wave, lane, m0, n0);
+    if (s < p.G) issue_int4<C>(p, s, slot, wave, lane, m0, n0);
+    else issue_keeper<C>(p, s - p.G, slot, wave, lane, m0, n0);
   };
-  issue(0);
-  issue(1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s_begin + s);
 #define ATOM_F6_STEP(COMPUTE)                                                            \
   {                                                                                      \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS * (NS - 2)) : "memory");               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");            \
     __builtin_amdgcn_s_barrier();                                                        \
     issue(step + NS - 1);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    COMPUTE(lds + (step % NS) * STAGE_BYTES, wm, wn, lane, c);                           \
+    COMPUTE<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);                     \
   }
-  int step = 0;
-  for (; step < p.G; ++step) ATOM_F6_STEP(compute_int4)
+  int step = s_begin;
+  for (; step < min(p.G, nsteps); ++step) ATOM_F6_STEP(compute_int4)
   for (; step < nsteps; ++step) ATOM_F6_STEP(compute_keeper)
 #undef ATOM_F6_STEP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  const int l31 = lane & 31, h = lane >> 5;
+  if constexpr (SK) {
+    // FP32 partial tile: lane owns token m and 4 consecutive features per (tile, q) -> one 16-byte store each
+    float *wsp = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * C::WM + tm * 32 + l31;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + tn * 32 + 8 * q + 4 * h;
+          if (n >= p.N) continue;
+          *reinterpret_cast<v4f *>(wsp + (int64_t)m * p.N + n) =
+              v4f{c[tn][tm][4 * q], c[tn][tm][4 * q + 1], c[tn][tm][4 * q + 2], c[tn][tm][4 * q + 3]};
+        }
+    }
+    return;
+  }
   constexpr int EP_STRIDE = 144;
   char *ep = lds + wave * (64 * EP_STRIDE);
-  const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
@@ -272,26 +326,43 @@ __global__ __launch_bounds__(NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
       const int rl = i * 8 + (lane >> 3);
       const int ch = lane & 7;
       const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
-      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int m = m0 + wm * C::WM + half * 64 + rl;
       const int n = n0 + wn * 64 + ch * 8;
       if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
     }
   }
 }
 
-}  // namespace f6
-
-int launch_gemm_f6(const GemmParams &p, hipStream_t s) {
+template <class C, bool SK>
+static int launch(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f6::gemm_w4a4_f6_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, f6::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6_kernel<C, SK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
-  const int nbm = (p.M + f6::BM - 1) / f6::BM, nbn = (p.N + f6::BN - 1) / f6::BN;
-  hipLaunchKernelGGL(f6::gemm_w4a4_f6_kernel, dim3((unsigned)(nbm * nbn)), dim3(f6::NT), f6::LDS_BYTES, s, p);
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6_kernel<C, SK>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
+                     C::LDS_BYTES, s, p);
+  if (SK) {
+    const int64_t MN = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.ws, p.D, MN, p.splits);
+  }
   return check_launch();
+}
+
+}  // namespace f6
+
+// cfg: 0 = 256x256 (8 waves), 1 = 256x128 (4 waves, 2 stages, two workgroups per CU), 2 = 64x128 (2 waves; split-K when
+// p.splits > 1 and p.ws is set)
+int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
+  if (cfg == 2) {
+    if (p.splits > 1 && p.ws) return f6::launch<f6::Cfg<64, 128, 2, 3>, true>(p, s);
+    return f6::launch<f6::Cfg<64, 128, 2, 3>, false>(p, s);
+  }
+  if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
+  return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);
 }
 
 }  // namespace atom

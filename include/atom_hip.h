@@ -74,7 +74,8 @@ extern "C" {
  * with atom_f6_rows(rows) = rows rounded up to 256 (pad rows: any bytes).  sB / keeper operands and scales as before.
  * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
  * still written).  Weights: atom_repack_weight_f6.  Results are bit-identical to the INT8 kernels.  M, N >= 1 as usual;
- * meant for prefill (one 256x256 tile per workgroup, no split-K).
+ * three tile geometries (256x256, 256x128, 64x128 + split-K through atom_gemm_w4a4_f16_ws) picked by tile count; it pays
+ * off for prefill-sized M (>= ~2-3k rows), below that the INT8 kernels are as fast.
  */
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
