@@ -31,6 +31,18 @@ static int gemv_max_m() {
   return v;
 }
 
+// Tile geometry of the F6 kernels by shape (measured: profiles/r01_f6_dispatch.txt).  256x256 (one workgroup per CU) when
+// the tiles fill whole rounds of the 256 CUs; else 128x128 (three workgroups per CU) while that yields >= 256 tiles (>= 128
+// for short K); else 64x128, which splits K when the caller passes a workspace.
+static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
+  static const int force = [] { const char *e = getenv("ATOM_F6_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+  if (force >= 0) return force;
+  const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (t256 >= 256 && 5 * t256 >= 4 * ((t256 + 255) / 256) * 256) return 0;
+  if (t128 >= 256 || (t128 >= 128 && K_total <= 6144)) return 3;
+  return 2;
+}
+
 extern "C" {
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }
@@ -74,12 +86,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       return launch_gemm_v3(p, variant - 300, hs);
     }
     default:                                                        // product path
-      if (p.f6_rows_a) {                                      // BF6 operands: block-scaled MFMA kernels
-        static const int force = [] { const char *e = getenv("ATOM_F6_CFG"); return e ? atoi(e) : -1; }();   // tuning only
-        const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, cn128 = (N + 127) / 128;
-        const int cfg = force >= 0 ? force : (cm256 * cn256 >= 192 ? 0 : (cm256 * cn128 >= 256 ? 1 : 2));
-        return launch_gemm_f6(p, cfg, hs);
-      }
+      if (p.f6_rows_a) return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);   // BF6 operands: block-scaled MFMA kernels
       if (p.a_wide) {   // activations pre-widened by the quant kernels: 256x256 tiles once they fill half the chip
         const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
         const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
@@ -172,7 +179,11 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.D = (half_t *)D;
   p.ws = (float *)workspace;
   p.splits = choose_splits(M, N, K_total);
-  if (p.f6_rows_a) return launch_gemm_f6(p, 2, reinterpret_cast<hipStream_t>(stream));
+  if (p.f6_rows_a) {
+    const int cfg = f6_pick_cfg(M, N, K_total);
+    if (cfg != 2) { p.ws = nullptr; p.splits = 1; }
+    return launch_gemm_f6(p, cfg, reinterpret_cast<hipStream_t>(stream));
+  }
   return launch_gemm_v3(p, p.a_wide ? 25 : 5, reinterpret_cast<hipStream_t>(stream));
 }
 

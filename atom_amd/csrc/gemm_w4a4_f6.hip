@@ -17,6 +17,7 @@
 // fp16 array.  The INT8 keeper runs as the two 64-column half-steps of the INT8 kernel in the same stage buffer.
 // Arithmetic is the same contract: t = round_f32(idot * sA), c = fma(t, sB, c) per group in order, keeper last --
 // results are bit-identical to the INT8 kernels.
+#include <cstdlib>
 #include "common.h"
 
 namespace atom {
@@ -38,8 +39,9 @@ constexpr int kMagicBits = 0x4B400000;
 // Tile geometry.  Three instances: 256x256 (8 waves, one workgroup per CU) once the shape yields ~200 of them,
 // 256x128 (4 waves, two workgroups per CU, two stages), and 64x128 (2 waves, several workgroups per CU, split-K) for
 // skinny M.
-template <int BM_, int BN_, int TM_, int NS_>
+template <int BM_, int BN_, int TM_, int NS_, int OCC_ = 2>
 struct Cfg {
+  static constexpr int OCC = OCC_;                                     // waves per SIMD the register budget is set for
   static constexpr int BM = BM_, BN = BN_, TM = TM_, NS = NS_;
   static constexpr int WM = 32 * TM, WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
   static constexpr int W_BYTES = BN * PITCH, A_BYTES = BM * PITCH;
@@ -53,36 +55,42 @@ struct Cfg {
   static constexpr int KP_SA_OFF = (BN + BM) * 64;                     // keeper half-steps: rows of 64 B, then BM dwords sA8
   static constexpr int NPIECE = NBW + NBA + NSB;                       // DMA instructions per int4 stage
   static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB;           // ... per keeper half-step
-  static constexpr int GLDS = ((NPIECE > NKP ? NPIECE : NKP) + NW - 1) / NW;   // per wave, padded with repeats
+  // The LDS-DMA instructions are issued by the first NDW waves.
+  static constexpr int NDW = NW;   // (measured: NW / 2 -- only the older wave of each SIMD issuing -- is 6 % slower)
+  static constexpr int GLDS = ((NPIECE > NKP ? NPIECE : NKP) + NDW - 1) / NDW;  // per issuing wave, padded with repeats
   static constexpr int EP_BYTES = NW * 64 * 144;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
   static_assert(BN % 128 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4) && NS >= 2, "geometry");
   static_assert(KP_SA_OFF + BM * 4 <= SB_OFF && LDS_BYTES <= 160 * 1024, "stage layout");
 };
 
+// DMA instruction i (of C::GLDS) of this wave for int4 group g
 template <class C>
-__device__ __forceinline__ void issue_int4(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0) {
+__device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0, int i) {
   const uint8_t *wsrc = p.B4 + ((int64_t)g * p.f6_rows_b + n0) * PITCH;
   const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - C::W_BYTES;   // block j >= NBW is asrc + j*1024
-#pragma unroll
-  for (int i = 0; i < C::GLDS; ++i) {
-    int j = i * C::NW + wave;                              // piece j: NBW weight blocks, NBA activation blocks, NSB scales
-    j = j < C::NPIECE ? j : j - C::NSB;                    // padding repeats a scale piece (same bytes, same place)
-    if (i * C::NW + C::NW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {            // compile time: whole data blocks only
-      const uint8_t *base = (i * C::NW + C::NW <= C::NBW || j < C::NBW) ? wsrc : asrc;
+  int j = i * C::NDW + wave;                               // piece j: NBW weight blocks, NBA activation blocks, NSB scales
+  j = j < C::NPIECE ? j : j - C::NSB;                      // padding repeats a scale piece (same bytes, same place)
+  if (i * C::NDW + C::NDW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {              // compile time: whole data blocks only
+    const uint8_t *base = (i * C::NDW + C::NDW <= C::NBW || j < C::NBW) ? wsrc : asrc;
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+  } else if (j < C::NBW + C::NBA) {
+    const uint8_t *base = j < C::NBW ? wsrc : asrc;
+    // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
+    if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
       __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
-    } else if (j < C::NBW + C::NBA) {
-      const uint8_t *base = j < C::NBW ? wsrc : asrc;
-      // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
-      if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
-    } else {                                               // 128 weight scales per piece, a dword (2 channels) per lane
-      const int part = j - (C::NBW + C::NBA);
-      const half_t *sBb = p.sB + (int64_t)g * p.N;
-      const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
-    }
+  } else {                                                 // 128 weight scales per piece, a dword (2 channels) per lane
+    const int part = j - (C::NBW + C::NBA);
+    const half_t *sBb = p.sB + (int64_t)g * p.N;
+    const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
+    __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
   }
+}
+
+template <class C>
+__device__ __forceinline__ void issue_int4(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0) {
+#pragma unroll
+  for (int i = 0; i < C::GLDS; ++i) issue_int4_piece<C>(p, g, slot, wave, lane, m0, n0, i);
 }
 
 // keeper half-step `half` (0 / 1): the INT8 kernel's layout -- 16 rows x 64 B per DMA block, XOR-swizzled chunks
@@ -93,9 +101,9 @@ __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char
   constexpr int ND = (C::BN + C::BM) / 16, NSA = C::BM / 64;
 #pragma unroll
   for (int i = 0; i < C::GLDS; ++i) {
-    int j = i * C::NW + wave;
+    int j = i * C::NDW + wave;
     j = j < C::NKP ? j : ND + NSA + (j % C::NSB);          // padding repeats a weight-scale piece
-    if (i * C::NW + C::NW <= ND || j < ND) {               // (first half: known at compile time)
+    if (i * C::NDW + C::NDW <= ND || j < ND) {               // (first half: known at compile time)
       const int row = j * 16 + (lane >> 2);
       const unsigned idx = (unsigned)(j < C::BN / 16 ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
       const uint8_t *base = (j < C::BN / 16 ? p.B8 : p.A8) + half * 64;
@@ -120,35 +128,56 @@ __device__ __forceinline__ v8i frag24(const char *p) {    // 24 bytes = 32 BF6 f
   return v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
 }
 
-__device__ __forceinline__ void dequant16(const float (&acc)[16], float sa, const char *psb, float (&c)[16]) {
+__device__ __forceinline__ void dequant16(float (&acc)[16], float sa, const char *psb, float (&c)[16]) {
+  // (the 16 weight scales are re-read per tile: holding a step's 32 in registers puts them into the LDS burst behind the
+  // barrier and measures 3 % slower)
   v2u sbp[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + 16 * q);
+  // t = round_f32(idot * sA) for all 16 elements FIRST (in place, one block): a multiply followed directly by the FMA that
+  // reads it costs 3.2 cycles per instruction instead of 2 (dependent issue), which was 9 us of the 4096^3 launch
+#define M1(i) "v_mul_f32 %" #i ", %" #i ", %16\n"
+  // element 0 through the compiler: its hazard recogniser then places the MFMA->VALU wait states the asm block relies on
+  acc[0] *= sa;
+  asm volatile("" : "+v"(acc[0]));
+  asm volatile(M1(1) M1(2) M1(3) M1(4) M1(5) M1(6) M1(7) M1(8) M1(9) M1(10) M1(11) M1(12) M1(13) M1(14) M1(15)
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                 "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+               : "v"(sa));
+#undef M1
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-    const float t = acc[r] * sa;                         // == round_f32(idot * sA): acc is the exact integer dot
-    c[r] = __builtin_fmaf(t, (float)hv[r & 3], c[r]);
+    c[r] = __builtin_fmaf(acc[r], (float)hv[r & 3], c[r]);
     asm volatile("" : "+v"(c[r]));
   }
 }
 
 // one int4 group out of LDS: 2 BF6 MFMAs per 32x32 tile
-template <class C>
-__device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+// ABL (tools only, -DATOM_F6_ABLATE): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment refills
+struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
+
+// `dma(i)`, i < C::GLDS: the wave's LDS-DMA instructions for a later stage, spread over the tiles -- each is issued behind a
+// tile's MFMA pair, where the wave would wait for the matrix pipe anyway (issuing them in a block at the top of the step
+// stalls both waves of a SIMD on the address path at the same time)
+template <class C, int ABL = 0, class F = NoDma>
+__device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16], F dma = F(),
+                                             unsigned long long *tp = nullptr) {
   constexpr int TM = C::TM;
   const int l31 = lane & 31, h = lane >> 5;
   const char *pw = slot + (wn * 64 + l31) * PITCH + h * 24;                   // + tn*32*PITCH + s*48
   const char *pa = slot + C::A_OFF + (wm * C::WM + l31) * PITCH + h * 24;     // + tm*32*PITCH + s*48
   const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * h) * 2;                 // + tn*64 + 16*q
+  // only what the first tile needs is loaded ahead of its MFMAs (all 8 waves hit the LDS at once behind the barrier); the
+  // second feature fragment pair follows behind the first MFMA pair
   v8i af[TN][2];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) af[tn][s] = frag24(pw + tn * 32 * PITCH + s * 48);
-  v8i bf[2];
-  bf[0] = frag24(pa);
-  bf[1] = frag24(pa + 48);
+  constexpr bool DB = C::OCC <= 2;                 // token fragments double-buffered across tm when the register budget allows
+  constexpr int NB = DB ? 2 : 1;
+  v8i bf[NB][2];
+  af[0][0] = frag24(pw);
+  bf[0][0] = frag24(pa);
+  af[0][1] = frag24(pw + 48);
+  bf[0][1] = frag24(pa + 48);
   half_t sah = *reinterpret_cast<const half_t *>(pa - h * 24 + 96);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -161,19 +190,48 @@ __device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, i
       v16f acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      if constexpr ((ABL & 16) != 0)
+        if (tp && tm == 0 && tn == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp[3] = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         // cbsz = blgp = 3: BF6 (E3M2) x BF6; block scales E8M0 127 = 2^0
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[tn][s], bf[s], acc, 3, 3, 0, 127, 0, 127);
-        if (tn == TN - 1 && tm + 1 < TM) {
-          __builtin_amdgcn_sched_barrier(0);             // refill the slice behind its last reader
-          bf[s] = frag24(pa + (tm + 1) * 32 * PITCH + s * 48);
+        if constexpr (!(ABL & 4)) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[tn][s], bf[tm % NB][s], acc, 3, 3, 0, 127, 0, 127);
+        else asm volatile("" : "+v"(acc) : "v"(af[tn][s]), "v"(bf[tm % NB][s]));
+      }
+      if (tn == (DB ? 0 : TN - 1) && tm + 1 < TM) {       // next token fragments: behind this tm's first MFMA pair, or (single
+        __builtin_amdgcn_sched_barrier(0);                // buffer) in place behind its last one
+        if (!(ABL & 8)) {
+          bf[(tm + 1) % NB][0] = frag24(pa + (tm + 1) * 32 * PITCH);
+          bf[(tm + 1) % NB][1] = frag24(pa + (tm + 1) * 32 * PITCH + 48);
+        } else if (DB) {
+          bf[(tm + 1) % NB][0] = bf[tm % NB][0];
+          bf[(tm + 1) % NB][1] = bf[tm % NB][1];
         }
+      }
+      if (tm == 0 && tn == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 1; t2 < TN; ++t2)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) af[t2][s] = frag24(pw + t2 * 32 * PITCH + s * 48);
+      }
+      {
+        constexpr int NTILE = TM * TN;
+        const int t = tm * TN + tn;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = (t * C::GLDS + NTILE - 1) / NTILE; i < ((t + 1) * C::GLDS + NTILE - 1) / NTILE; ++i) dma(i);   // front-loaded
+        __builtin_amdgcn_sched_barrier(0);
       }
       float a16[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) a16[i] = acc[i];
-      dequant16(a16, sa, psb + tn * 64, c[tn][tm]);
+      if constexpr (!(ABL & 2)) dequant16(a16, sa, psb + tn * 64, c[tn][tm]);
+      else { c[tn][tm][0] += a16[0] + a16[15]; asm volatile("" ::"v"(acc)); }
+      if constexpr ((ABL & 16) != 0) {                     // tools only: s_memtime after tiles 1, 3, 5, 7
+        const int t = tm * TN + tn;
+        if (tp && (t & 1)) { __builtin_amdgcn_sched_barrier(0); tp[4 + (t >> 1)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+      }
     }
   }
 }
@@ -225,8 +283,8 @@ __device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn,
   }
 }
 
-template <class C, bool SK>
-__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
+template <class C, bool SK, int ABL = 0>
+__global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int TM = C::TM, NS = C::NS;
   const int tid = threadIdx.x;
@@ -263,23 +321,41 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
   auto issue = [&](int step) {
     char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
+    if (wave >= C::NDW) return;
     if (s < p.G) issue_int4<C>(p, s, slot, wave, lane, m0, n0);
     else issue_keeper<C>(p, s - p.G, slot, wave, lane, m0, n0);
   };
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s_begin + s);
-#define ATOM_F6_STEP(COMPUTE)                                                            \
+  unsigned long long *tbase = nullptr;                   // tools only (ABL & 16): u64 [wave][64 steps][8] stamps of workgroup 0
+  if constexpr ((ABL & 16) != 0)
+    if (blockIdx.x == 0 && lane == 0) tbase = reinterpret_cast<unsigned long long *>(p.Dsz) + wave * 64 * 8;
+#define ATOM_F6_STAMP(k) if constexpr ((ABL & 16) != 0) { if (tbase) tbase[step * 8 + k] = __builtin_amdgcn_s_memtime(); }
+#define ATOM_F6_STEP(ISSUE, COMPUTE)                                                     \
   {                                                                                      \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");            \
+    ATOM_F6_STAMP(0)                                                                     \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 1) ? 0 : C::GLDS * (NS - 2)) : "memory"); \
+    ATOM_F6_STAMP(1)                                                                     \
     __builtin_amdgcn_s_barrier();                                                        \
-    issue(step + NS - 1);                                                                \
+    ATOM_F6_STAMP(2)                                                                     \
+    ISSUE;                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    COMPUTE<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);                     \
+    COMPUTE;                                                                             \
   }
   int step = s_begin;
-  for (; step < min(p.G, nsteps); ++step) ATOM_F6_STEP(compute_int4)
-  for (; step < nsteps; ++step) ATOM_F6_STEP(compute_keeper)
+  // int4 steps whose prefetch (step + NS - 1) is an int4 group too: DMA instructions interleaved with the tiles
+  for (; step + NS - 1 < min(p.G, nsteps); ++step) {
+    char *nslot = lds + ((step + NS - 1) % NS) * C::STAGE_BYTES;
+    const int g = step + NS - 1;
+    auto dma = [&](int i) { if (!(ABL & 1) && wave < C::NDW) issue_int4_piece<C>(p, g, nslot, wave, lane, m0, n0, i); };
+    ATOM_F6_STEP((void)0, (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, tbase ? tbase + step * 8 : nullptr)))
+  }
+  for (; step < min(p.G, nsteps); ++step)
+    ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c)))
+  for (; step < nsteps; ++step)
+    ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_keeper<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c)))
 #undef ATOM_F6_STEP
+  { ATOM_F6_STAMP(0) }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -333,17 +409,17 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6_kernel(GemmParams p) {
   }
 }
 
-template <class C, bool SK>
+template <class C, bool SK, int ABL = 0>
 static int launch(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6_kernel<C, SK>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6_kernel<C, SK, ABL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6_kernel<C, SK>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
+  hipLaunchKernelGGL((gemm_w4a4_f6_kernel<C, SK, ABL>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
                      C::LDS_BYTES, s, p);
   if (SK) {
     const int64_t MN = (int64_t)p.M * p.N;
@@ -357,11 +433,26 @@ static int launch(const GemmParams &p, hipStream_t s) {
 // cfg: 0 = 256x256 (8 waves), 1 = 256x128 (4 waves, 2 stages, two workgroups per CU), 2 = 64x128 (2 waves; split-K when
 // p.splits > 1 and p.ws is set)
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
+#ifdef ATOM_F6_ABLATE
+  if (cfg == 116) {   // traced run (tools/trace_f6.cpp): the stamp buffer arrives in ATOM_TRACE_PTR
+    const char *e = getenv("ATOM_TRACE_PTR");
+    if (!e) return ATOM_ERR_INVALID_ARG;
+    GemmParams q = p;
+    q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+    return f6::launch<f6::Cfg<256, 256, 4, 3>, false, 16>(q, s);
+  }
+  switch (cfg) {   // tools/gemm_bench only: 100 + ablation mask on the 256x256 geometry
+#define ATOM_ABL(a) case 100 + a: return f6::launch<f6::Cfg<256, 256, 4, 3>, false, a>(p, s);
+    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15)
+#undef ATOM_ABL
+  }
+#endif
   if (cfg == 2) {
     if (p.splits > 1 && p.ws) return f6::launch<f6::Cfg<64, 128, 2, 3>, true>(p, s);
     return f6::launch<f6::Cfg<64, 128, 2, 3>, false>(p, s);
   }
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
+  if (cfg == 3) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);   // 4 waves, three workgroups per CU
   return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);
 }
 

@@ -39,11 +39,12 @@ class ActCodes:
 
 def want_wide_codes(rows: int):
     """Which activation-code format the fused quantisers should emit for a batch of ``rows`` tokens:
-    "f6"   rows >= 3072: the BF6 group-major format of the block-scaled-MFMA prefill kernel (256x256 tiles only: it needs
-           about 200 tiles to fill the chip, i.e. 3072 rows against the 4096-wide projections of a 7B model);
+    "f6"   rows >= 256: the BF6 group-major format of the block-scaled-MFMA kernels (three tile geometries, picked by
+           shape; measured against the INT8 kernels over Llama projection shapes in profiles/r01_f6_dispatch.txt: ahead
+           from 256 rows up, 1.3-1.4x at 1k-2k rows);
     True   8 <= rows: pre-widened int8 codes for the INT8 MFMA tile kernels;
     False  rows <= 7: packed nibbles, which the weight-streaming decode kernel consumes."""
-    if rows >= 3072:
+    if rows >= 256:
         return "f6"
     return rows >= 8
 
