@@ -154,7 +154,8 @@ __device__ __forceinline__ void dequant16(float (&acc)[16], float sa, const char
 }
 
 // one int4 group out of LDS: 2 BF6 MFMAs per 32x32 tile
-// ABL (tools only, -DATOM_F6_ABLATE): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment refills
+// ABL (tools only, -DATOM_F6_ABLATE): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment refills, 16 = s_memtime
+// stamps, 32 = no priority swap
 struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 
 // `dma(i)`, i < C::GLDS: the wave's LDS-DMA instructions for a later stage, spread over the tiles -- each is issued behind a
@@ -162,7 +163,7 @@ struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 // stalls both waves of a SIMD on the address path at the same time)
 template <class C, int ABL = 0, class F = NoDma>
 __device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16], F dma = F(),
-                                             unsigned long long *tp = nullptr) {
+                                             unsigned long long *tp = nullptr, bool older = false) {
   constexpr int TM = C::TM;
   const int l31 = lane & 31, h = lane >> 5;
   const char *pw = slot + (wn * 64 + l31) * PITCH + h * 24;                   // + tn*32*PITCH + s*48
@@ -190,6 +191,14 @@ __device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, i
       v16f acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      if constexpr (C::NW >= 8 && TM == 4 && !(ABL & 32)) {
+        // two waves of the workgroup per SIMD: they swap priority mid-step.  The arbiter otherwise always serves the older
+        // wave first; it then idles ~1k cycles at every barrier while the younger one finishes the step alone at the
+        // single-wave issue rate (s_memtime trace: barrier wait 1050 -> 400 cycles, step 4750 -> 4500; every-two-tiles
+        // swapping measures slower than no swapping)
+        if (tm * TN + tn == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+        if (tm * TN + tn == TM * TN / 2) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+      }
       if constexpr ((ABL & 16) != 0)
         if (tp && tm == 0 && tn == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp[3] = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
@@ -348,10 +357,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
     char *nslot = lds + ((step + NS - 1) % NS) * C::STAGE_BYTES;
     const int g = step + NS - 1;
     auto dma = [&](int i) { if (!(ABL & 1) && wave < C::NDW) issue_int4_piece<C>(p, g, nslot, wave, lane, m0, n0, i); };
-    ATOM_F6_STEP((void)0, (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, tbase ? tbase + step * 8 : nullptr)))
+    ATOM_F6_STEP((void)0, (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, tbase ? tbase + step * 8 : nullptr, wave < C::NW / 2)))
   }
   for (; step < min(p.G, nsteps); ++step)
-    ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c)))
+    ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), nullptr, wave < C::NW / 2)))
+  __builtin_amdgcn_s_setprio(0);
   for (; step < nsteps; ++step)
     ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_keeper<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c)))
 #undef ATOM_F6_STEP
@@ -443,7 +453,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   }
   switch (cfg) {   // tools/gemm_bench only: 100 + ablation mask on the 256x256 geometry
 #define ATOM_ABL(a) case 100 + a: return f6::launch<f6::Cfg<256, 256, 4, 3>, false, a>(p, s);
-    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15)
+    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15) ATOM_ABL(32)
 #undef ATOM_ABL
   }
 #endif

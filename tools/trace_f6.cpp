@@ -33,7 +33,7 @@ int main() {
              (long long)(e[0] - t00), (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]),
              (long long)(e[5] - e[4]), (long long)(e[6] - e[5]), (long long)(e[7] - e[6]), (long long)(n[0] - e[7]), (long long)(n[0] - e[0]));
     }
-    printf("  loop end t=%lld\n", (long long)(h[(w * 64 + 33) * 8] - t00));
+    printf("  last int4 step starts t=%lld\n", (long long)(h[(w * 64 + 30) * 8] - t00));
   }
   return 0;
 }
