@@ -31,6 +31,21 @@ static int gemv_max_m() {
   return v;
 }
 
+// Decode batches go to the register-resident weight-streaming MFMA kernel (gemm_w4a4_skinny.hip) where it measures
+// faster than the tile kernels + split-K (profiles/r01_skinny.txt): always up to 16 tokens, up to 32 unless K is very
+// long, up to 64 while the shape is small enough that its one-workgroup-per-16-features grid is not the bottleneck.
+static int skinny_max_m() {
+  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 64; }();   // tuning only
+  return v;
+}
+static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
+  const int64_t items = (K_total - kKeeper) / kGroup + 1;
+  if (M > skinny_max_m() || items > 8 * 14) return false;
+  if (M <= 16) return true;
+  if (M <= 32) return items <= 96;
+  return N * items <= 420000;
+}
+
 // Tile geometry of the F6 kernels by shape (measured: profiles/r01_f6_dispatch.txt).  256x256 (one workgroup per CU) when
 // the tiles fill whole rounds of the 256 CUs; else 128x128 (three workgroups per CU) while that yields >= 256 tiles (>= 128
 // for short K); else 64x128, which splits K when the caller passes a workspace.
@@ -92,8 +107,12 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
         const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
         return launch_gemm_v3(p, cfg, hs);
       }
-      if (M <= gemv_max_m()) {                                      // decode: weight-streaming dot-product kernel
-        const int st = launch_gemv(p, hs);
+      if (M > 1 && skinny_fits(M, N, K_total)) {                    // decode batches: weight streaming on the MFMA
+        const int st = launch_gemm_skinny(p, hs);
+        if (st != ATOM_ERR_SHAPE) return st;
+      }
+      if (M <= gemv_max_m()) {                                      // M = 1 (and 2..7 with K too long for the above):
+        const int st = launch_gemv(p, hs);                          // weight-streaming dot-product kernel
         if (st != ATOM_ERR_SHAPE) return st;
       }
       {   // prefill: LDS-DMA MFMA tile kernel (gemm_w4a4_v3.hip); tile geometry by how many workgroups the shape yields
@@ -146,7 +165,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 // Split-K policy: shapes that yield fewer than 512 workgroups of the smallest tile are latency-bound (one pass over K per
 // workgroup at ~1 us per K-group); split the K loop over up to 8 workgroups and reduce FP32 partials in a second launch.
 static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
-  if (M <= gemv_max_m()) return 1;                         // decode kernel
+  if (M <= gemv_max_m() || skinny_fits(M, N, K_total)) return 1;   // decode kernels
   const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
   static const int force = [] { const char *e = getenv("ATOM_SPLITS"); return e ? atoi(e) : 0; }();   // tuning only

@@ -1,0 +1,200 @@
+// W4A4 GEMM, decode batches (8 <= M <= 64) for gfx950: weight streaming on the INT8 MFMA, latency-bound.
+//
+// A serving step multiplies a handful of tokens by the whole weight matrix: 8.4 MB of packed weights at N=K=4096 against
+// 0.1-2 GFLOP.  The tile kernels need 64-row tiles and a K loop with a barrier per group (12-15 us through split-K and a
+// second launch); the dot-product decode kernel (gemv_w4a4.hip) pays VALU and a cross-lane reduction per token.  Here:
+//   * one workgroup owns 16 output features; its 8 waves split K (groups in order, keeper last), so a shape yields N/16
+//     workgroups (256 at N=4096) and every wave has its whole weight slice in flight from its first instruction:
+//     lane (feature l%16, chunk l/16) loads the 16-byte chunk of each of its <= 14 groups straight into VGPRs
+//     (8 MB in flight over the chip; no LDS round trip, every weight byte is read exactly once);
+//   * v_mfma_i32_16x16x64_i8: A = 16 features x 64 channels, B = 64 channels x 16 tokens.  A packed 16-byte chunk holds 32
+//     codes: the even ones (low nibbles) as (x << 4) & 0xF0F0F0F0 and the odd ones as x & 0xF0F0F0F0 are int8 = 16*code;
+//     the same permutation of k on both operands, so two MFMAs give 256 * (the group's integer dot), exactly;
+//   * token blocks of 16 (up to 4) re-use the weight registers; a block's activation chunks come from L2 and are
+//     re-filled in place for the next block as soon as they have been widened;
+//   * per group and 16x16 tile: t = round_f32(idot * sA[m,g]), c = fma(t, sB[g,n], c) -- the contract of
+//     include/atom_hip.h; the partial sums of the NW waves are added in wave order through LDS (the FP32 summation ORDER
+//     therefore differs from the prefill kernels, like the decode kernel's; all are within 1 fp16 ulp of the exact value).
+// Replaces the M = 16..64 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
+// which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
+#include <cstdlib>
+#include "common.h"
+
+namespace atom {
+namespace skinny {
+
+constexpr int CNT_MAX = 14;                              // items (int4 groups, or the keeper) per wave, at most
+
+__device__ __forceinline__ v4i even_codes(v4u x) {       // low nibbles  -> int8 16*code
+  return v4i{(int)((x.x << 4) & 0xF0F0F0F0u), (int)((x.y << 4) & 0xF0F0F0F0u), (int)((x.z << 4) & 0xF0F0F0F0u),
+             (int)((x.w << 4) & 0xF0F0F0F0u)};
+}
+__device__ __forceinline__ v4i odd_codes(v4u x) {        // high nibbles -> int8 16*code
+  return v4i{(int)(x.x & 0xF0F0F0F0u), (int)(x.y & 0xF0F0F0F0u), (int)(x.z & 0xF0F0F0F0u), (int)(x.w & 0xF0F0F0F0u)};
+}
+
+// c[r] += round_f32(idot[r] * sa) * sb[r], r = the lane's 4 features
+__device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb, float (&c)[4]) {
+  const half_t *hv = reinterpret_cast<const half_t *>(&sb);
+  float t[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = (float)acc[r] * sa;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], (float)hv[r], c[r]);
+}
+
+// NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
+template <int NW, int MBLK, int CNT>
+__global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
+  __shared__ float part[NW][MBLK][64][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane & 15, kb = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int K4h = p.K4h, G = p.G;
+
+  // this wave's items: int4 groups [i0, min(i1, G)), and the keeper if i1 == G + 1
+  const int per = (G + 1 + NW - 1) / NW;
+  const int i0 = wave * per, i1 = min(i0 + per, G + 1);
+  const bool keeper = i1 == G + 1 && i0 <= G;
+  const int ng = min(i1, G) - i0;                          // int4 groups of this wave (<= CNT; may be <= 0)
+
+  // addresses = wave-uniform base (SGPRs) + 32-bit lane offset (one VGPR) + compile-time j * 64 where the stride is known:
+  // 64-bit per-lane pointers for 4 x 14 loads would cost more registers than the data
+  const char *wbase = reinterpret_cast<const char *>(p.B4) + (int64_t)n0 * K4h + i0 * 64;
+  const unsigned woff = (unsigned)(row * K4h + kb * 16);
+  const char *sbbase = reinterpret_cast<const char *>(p.sB + (int64_t)i0 * p.N + n0);
+  const char *abase = reinterpret_cast<const char *>(p.A4) + i0 * 64;
+  const char *sabase = reinterpret_cast<const char *>(p.sA + (int64_t)i0 * p.ldA);
+  unsigned aoff[MBLK], soff[MBLK], koff[MBLK];
+#pragma unroll
+  for (int tb = 0; tb < MBLK; ++tb) {
+    const int m = min(tb * 16 + row, p.M - 1);
+    aoff[tb] = (unsigned)(m * K4h + kb * 16);
+    soff[tb] = (unsigned)(p.ref_layout ? ref_scale_index(m) : m) * 2u;
+    koff[tb] = (unsigned)(m * kKeeper + kb * 16);
+  }
+
+  // ---- everything this wave will ever read of the weights, in flight at once
+  v4u w[CNT];
+  v2u sb[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    if (j < ng) {
+      w[j] = *reinterpret_cast<const v4u *>(wbase + j * 64 + woff);
+      sb[j] = *reinterpret_cast<const v2u *>(sbbase + (int64_t)j * p.N * 2 + 8 * kb);
+    }
+  }
+  v4u wk[2] = {};
+  v2u sbk = {};
+  if (keeper) {
+    const char *kp = reinterpret_cast<const char *>(p.B8) + (int64_t)n0 * kKeeper + (unsigned)(row * kKeeper + kb * 16);
+    wk[0] = *reinterpret_cast<const v4u *>(kp);
+    wk[1] = *reinterpret_cast<const v4u *>(kp + 64);
+    sbk = *reinterpret_cast<const v2u *>(reinterpret_cast<const char *>(p.sB8 + n0) + 8 * kb);
+  }
+  // ---- token block 0
+  v4u a[CNT];
+  half_t sa[CNT];
+  auto load_act = [&](int tb, int j) { a[j] = *reinterpret_cast<const v4u *>(abase + j * 64 + aoff[tb]); };
+  auto load_sa = [&](int tb, int j) { sa[j] = *reinterpret_cast<const half_t *>(sabase + (int64_t)j * p.ldA * 2 + soff[tb]); };
+#pragma unroll
+  for (int j = 0; j < CNT; ++j)
+    if (j < ng) { load_act(0, j); load_sa(0, j); }
+  v4u ak[2] = {};
+  half_t sak = (half_t)0;
+  auto load_keeper_act = [&](int tb) {
+    const char *kp = reinterpret_cast<const char *>(p.A8) + koff[tb];
+    ak[0] = *reinterpret_cast<const v4u *>(kp);
+    ak[1] = *reinterpret_cast<const v4u *>(kp + 64);
+    sak = *reinterpret_cast<const half_t *>(reinterpret_cast<const char *>(p.sA8) + soff[tb]);
+  };
+  if (keeper) load_keeper_act(0);
+
+  float c[MBLK][4];
+#pragma unroll
+  for (int tb = 0; tb < MBLK; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[tb][r] = 0.f;
+
+#pragma unroll
+  for (int tb = 0; tb < MBLK; ++tb) {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+      __builtin_amdgcn_sched_barrier(0);                   // keep the refills where they are written (register pressure)
+      if (j < ng) {                                        // wave-uniform
+        const v4i be = even_codes(a[j]), bo = odd_codes(a[j]);
+        if (tb + 1 < MBLK) load_act(tb + 1, j);            // in place: the next block's chunk is on its way during this block
+        const v4i ae = even_codes(w[j]), ao = odd_codes(w[j]);
+        v4i acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, be, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bo, acc, 0, 0, 0);
+        dequant4(acc, (float)sa[j] * (1.0f / 256.0f), sb[j], c[tb]);
+        if (tb + 1 < MBLK) load_sa(tb + 1, j);
+      }
+    }
+    if (keeper) {                                          // INT8 keeper, last, as two 64-column halves (the contract)
+      const float sa8 = (float)sak;
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        v4i acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(v4i, wk[hlf]), __builtin_bit_cast(v4i, ak[hlf]), acc, 0, 0, 0);
+        dequant4(acc, sa8, sbk, c[tb]);
+      }
+      if (tb + 1 < MBLK) load_keeper_act(tb + 1);
+    }
+  }
+
+  // ---- partial sums of the NW waves, added in wave order
+#pragma unroll
+  for (int tb = 0; tb < MBLK; ++tb)
+    *reinterpret_cast<v4f *>(&part[wave][tb][lane][0]) = v4f{c[tb][0], c[tb][1], c[tb][2], c[tb][3]};
+  __syncthreads();
+  for (int tb = wave; tb < MBLK; tb += NW) {
+    v4f s = *reinterpret_cast<const v4f *>(&part[0][tb][lane][0]);
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) {
+      const v4f q = *reinterpret_cast<const v4f *>(&part[w2][tb][lane][0]);
+      s = v4f{s[0] + q[0], s[1] + q[1], s[2] + q[2], s[3] + q[3]};
+    }
+    const int m = tb * 16 + row;
+    if (m < p.M) {
+      v2u o;
+      half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = f2h(s[r]);
+      *reinterpret_cast<v2u *>(p.D + (int64_t)m * p.N + n0 + 4 * kb) = o;
+    }
+  }
+}
+
+template <int NW, int MBLK, int CNT>
+static int launch(const GemmParams &p, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), 0, s, p);
+  return check_launch();
+}
+
+template <int NW, int CNT>
+static int launch_m(const GemmParams &p, hipStream_t s) {
+  const int mblk = (p.M + 15) / 16;
+  if (mblk <= 1) return launch<NW, 1, CNT>(p, s);
+  if (mblk <= 2 && !(NW == 8 && CNT == 14)) return launch<NW, 2, CNT>(p, s);   // (that one instance spills; 4 blocks do not)
+  return launch<NW, 4, CNT>(p, s);
+}
+
+}  // namespace skinny
+
+// 1 <= M <= 64, reference packed format, K <= 14336.  ATOM_ERR_SHAPE when K is too long for the register-resident weight slice
+// (caller falls back to the tile kernels).
+int launch_gemm_skinny(const GemmParams &p, hipStream_t s) {
+  if (p.M > 64 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0) return ATOM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p.D) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 ||
+      (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0)
+    return ATOM_ERR_SHAPE;                                 // 8-byte scale loads / stores: the tile kernels take these
+  const int per = (p.G + 1 + 7) / 8;                      // 8 waves split K (measured: 4 waves with twice the slice are slower)
+  if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
+  if (per <= 4) return skinny::launch_m<8, 4>(p, s);
+  return per <= 8 ? skinny::launch_m<8, 8>(p, s) : skinny::launch_m<8, 14>(p, s);
+}
+
+}  // namespace atom

@@ -191,13 +191,35 @@ def test_gemm_split_k_path(M, N, K):
         assert np.array_equal(bits16(t2n(out)), bits16(t2n(plain)))
 
 
+# decode batches: gemm_w4a4_skinny.hip (2 <= M <= 64; 8 waves split K: 1..14 groups per wave incl. waves with no work,
+# keeper on the last working wave, 1 / 2 / 4 token blocks, ragged M, N = 64 .. 13824)
+SKINNY = [(2, 256, 256), (7, 4096, 4096), (8, 64, 384), (16, 512, 512), (17, 1408, 2176), (31, 320, 1152), (33, 5120, 5120),
+          (48, 11008, 4096), (64, 4096, 11008), (16, 5120, 13824), (64, 1024, 1280)]
+
+
+@pytest.mark.parametrize("M,N,K", SKINNY)
+@pytest.mark.parametrize("layout", ["ref", "plain"])
+def test_gemm_decode_batches(M, N, K, layout):
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M * 13 + N + K)
+    t = to_device(d, layout)
+    out = ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout)
+    exact = gemm_ref_torch_f64(d).cpu().numpy() if N * K > (1 << 24) else _exact(d)
+    assert_gemm_close(t2n(out), exact, f"decode batch {M}x{N}x{K} {layout}")
+    assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout))          # deterministic summation order
+    if M <= 16:                                              # rows are independent: a batch equals its rows one by one
+        one = to_device({k: (v[M - 1:M] if k in ("qa4", "qa8", "sA", "sA8") else v) for k, v in d.items()}, layout)
+        row = ops.dense_layer_gemm_i4_fp16(*one, scale_layout=layout)
+        assert_gemm_close(t2n(row), exact[M - 1:M], "last row alone")
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 512, 512), (129, 320, 384), (257, 1024, 1152), (300, 64, 1280), (8, 4096, 4096),
                                    (64, 5120, 5120), (1024, 1024, 2176), (5, 256, 640)])
 @pytest.mark.parametrize("layout", ["ref", "plain"])
 def test_gemm_wide_activations_bit_identical(M, N, K, layout):
     """ATOM_A_WIDE: the activation operand pre-widened to int8 (x16, even/odd de-interleaved) is the same arithmetic in
     the same order: results equal the packed call bit for bit wherever both run the same kernel family (MFMA tiles:
-    M >= 8), and match the exact oracle everywhere (ragged M / N tails, split-K shapes, M <= 7 on the tile kernel)."""
+    M > 64), and match the exact oracle everywhere (ragged M / N tails, split-K shapes, M <= 7 on the tile kernel)."""
     from tests.helpers import wide_codes
     ops = _ops()
     d = rand_gemm_operands(M, N, K, seed=M * 5 + N + K)
@@ -205,7 +227,7 @@ def test_gemm_wide_activations_bit_identical(M, N, K, layout):
     aw = torch.from_numpy(wide_codes(d["qa4"])).cuda()
     out_w = ops.dense_layer_gemm_i4_fp16(aw, *t[1:], scale_layout=layout, a_wide=True)
     assert_gemm_close(t2n(out_w), _exact(d), f"wide {M}x{N}x{K} {layout}")
-    if M >= 8 and not (M == 64 and N == 5120):          # same tile family and no split-K regrouping of partial sums
+    if M > 64:                                          # same tile family (M <= 64: the decode kernels sum in wave order)
         out_p = ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout)
         if ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
             assert torch.equal(out_w, out_p)
@@ -242,7 +264,7 @@ def test_gemm_f6_operands_bit_identical(M, N, K):
     assert np.array_equal(t2n(b6), f6_codes(d["qb4"]))
     out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
     assert_gemm_close(t2n(out), _exact(d), f"f6 {M}x{N}x{K}")
-    if M >= 8 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+    if M > 64 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
         assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"))
 
 
