@@ -35,7 +35,7 @@ static int gemv_max_m() {
 // faster than the tile kernels + split-K (profiles/r01_skinny.txt): always up to 16 tokens, up to 32 unless K is very
 // long, up to 64 while the shape is small enough that its one-workgroup-per-16-features grid is not the bottleneck.
 static int skinny_max_m() {
-  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 64; }();   // tuning only
+  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 128; }();   // tuning only
   return v;
 }
 static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
@@ -43,6 +43,7 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   if (M > skinny_max_m() || items > 8 * 14) return false;
   if (M <= 16) return true;
   if (M <= 32) return items <= 96;
+  if (M > 64 && items > 64) return false;                  // 8 token blocks: the 4- and 8-slot instances only
   return N * items <= 420000;
 }
 
