@@ -33,9 +33,10 @@ static int gemv_max_m() {
 
 // Decode batches go to the register-resident weight-streaming MFMA kernel (gemm_w4a4_skinny.hip) where it measures
 // faster than the tile kernels + split-K (profiles/r01_skinny.txt): always up to 16 tokens, up to 32 unless K is very
-// long, up to 64 while the shape is small enough that its one-workgroup-per-16-features grid is not the bottleneck.
+// long, up to 128 (256 for K <= 4096) while the shape is small enough that its one-workgroup-per-16-features grid and
+// the per-workgroup re-widening of the activations are not the bottleneck.
 static int skinny_max_m() {
-  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 128; }();   // tuning only
+  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 256; }();   // tuning only
   return v;
 }
 static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
@@ -43,7 +44,8 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   if (M > skinny_max_m() || items > 8 * 14) return false;
   if (M <= 16) return true;
   if (M <= 32) return items <= 96;
-  if (M > 64 && items > 64) return false;                  // 8 token blocks: the 4- and 8-slot instances only
+  if (M > 64 && items > 64) return false;                  // 8 / 16 token blocks: the 4- and 8-slot instances only
+  if (M > 128) return items <= 32 && N * items <= 200000;   // 16 blocks: K <= 4096 (256x4096x4096: 16.1 vs 25.2 us)
   return N * items <= 420000;
 }
 

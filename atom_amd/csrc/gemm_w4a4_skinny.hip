@@ -1,4 +1,4 @@
-// W4A4 GEMM, decode batches (2 <= M <= 128) for gfx950: weight streaming on the INT8 MFMA, latency-bound.
+// W4A4 GEMM, decode batches (2 <= M <= 256) for gfx950: weight streaming on the INT8 MFMA, latency-bound.
 //
 // A serving step multiplies a handful of tokens by the whole weight matrix: 8.4 MB of packed weights at N=K=4096 against
 // 0.1-2 GFLOP.  The tile kernels need 64-row tiles and a K loop with a barrier per group (12-15 us through split-K and a
@@ -10,7 +10,7 @@
 //   * v_mfma_i32_16x16x64_i8: A = 16 features x 64 channels, B = 64 channels x 16 tokens.  A packed 16-byte chunk holds 32
 //     codes: the even ones (low nibbles) as (x << 4) & 0xF0F0F0F0 and the odd ones as x & 0xF0F0F0F0 are int8 = 16*code;
 //     the same permutation of k on both operands, so two MFMAs give 256 * (the group's integer dot), exactly;
-//   * token blocks of 16 (up to 8) re-use the weight registers; a block's activation chunks come from L2 and are
+//   * token blocks of 16 (up to 16) re-use the weight registers; a block's activation chunks come from L2 and are
 //     re-filled in place for the next block as soon as they have been widened;
 //   * per group and 16x16 tile: t = round_f32(idot * sA[m,g]), c = fma(t, sB[g,n], c) -- the contract of
 //     include/atom_hip.h; the partial sums of the NW waves are added in wave order through LDS (the FP32 summation ORDER
@@ -46,7 +46,8 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
 template <int NW, int MBLK, int CNT>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
-  __shared__ float part[NW][MBLK][64][4];
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]
+  float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row = lane & 15, kb = lane >> 4;
@@ -170,7 +171,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
 
 template <int NW, int MBLK, int CNT>
 static int launch(const GemmParams &p, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), 0, s, p);
+  constexpr size_t lds = (size_t)NW * MBLK * 64 * 16;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ATOM_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
 
@@ -180,16 +191,19 @@ static int launch_m(const GemmParams &p, hipStream_t s) {
   if (mblk <= 1) return launch<NW, 1, CNT>(p, s);
   if (mblk <= 2 && !(NW == 8 && CNT == 14)) return launch<NW, 2, CNT>(p, s);   // (that one instance spills; 4 blocks do not)
   if (mblk <= 4) return launch<NW, 4, CNT>(p, s);
-  if constexpr (CNT <= 8) return launch<NW, 8, CNT>(p, s);
+  if constexpr (CNT <= 8) {
+    if (mblk <= 8) return launch<NW, 8, CNT>(p, s);
+    if (mblk <= 16) return launch<NW, 16, CNT>(p, s);
+  }
   return ATOM_ERR_SHAPE;
 }
 
 }  // namespace skinny
 
-// 1 <= M <= 128 (<= 64 when K > 8192), reference packed format, K <= 14336.  ATOM_ERR_SHAPE when K is too long for the register-resident weight slice
+// 1 <= M <= 256 (<= 64 when K > 8192), reference packed format, K <= 14336.  ATOM_ERR_SHAPE when K is too long for the register-resident weight slice
 // (caller falls back to the tile kernels).
 int launch_gemm_skinny(const GemmParams &p, hipStream_t s) {
-  if (p.M > 128 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0) return ATOM_ERR_SHAPE;
+  if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0) return ATOM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(p.D) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 ||
       (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0)
     return ATOM_ERR_SHAPE;                                 // 8-byte scale loads / stores: the tile kernels take these

@@ -59,7 +59,7 @@ extern "C" {
  * packed operands) with the even / odd channels of every 32-channel block de-interleaved -- exactly the two operands the
  * GEMM otherwise makes from one packed 16-byte chunk with 3 VALU instructions per MFMA.  Costs K4/2 more bytes per
  * token in HBM, transient.  Same results bit for bit.  Not accepted by atom_gemm_w4a4_o4; always runs the tile
- * kernels (use the packed format for decode batches, M <= 128: they have their own kernels).
+ * kernels (use the packed format for decode batches, M <= 256: they have their own kernels).
  */
 #define ATOM_QUANT_WIDE_CODES 0x100
 #define ATOM_A_WIDE 0x100
@@ -94,7 +94,7 @@ size_t atom_scale_size(int64_t rows, int scale_layout);
  *           DenseLayerGEMM_i4<nv_half> (e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4.cu:722-791).
  * Integer dot products are exact (INT8 MFMA); per group c = fma(round_f32(idot*sA), sB, c) in FP32, groups in
  * order, then the keeper as two 64-column halves (each dequantised the same way); D = half(c).  The decode kernels
- * (M = 1: dot products along K; 2 <= M <= 128 in the packed format: eight waves own an eighth of the groups each) apply
+ * (M = 1: dot products along K; 2 <= M <= 256 in the packed format: eight waves own an eighth of the groups each) apply
  * the same per-group arithmetic and add their per-lane / per-wave partial sums in a fixed order: deterministic, within
  * 1 fp16 ulp of the exact value like the tile kernels, but not the same FP32 summation order.
  * Constraints: (K_total-128) % 128 == 0, K_total >= 256, N % 64 == 0, M >= 1, all pointers 16-byte aligned.
