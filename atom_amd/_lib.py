@@ -38,6 +38,8 @@ SIGNATURES = {
     "atom_gemm_w4a4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_o4": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
+    "atom_gemm_w4a4_o4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
+    "atom_gemm_w4a4_o4_ws": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_reorder_quant_f16": (_int, [_vp, _vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_rmsnorm_reorder_quant_f16": (_int, [_vp, _vp, _f32, _vp, _i64, _int, _int, _f32, _int,
                                               _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -64,7 +64,8 @@ int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v
 int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s);         // gemm_w4a4_v2.hip, u4 epilogue
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_v3.hip (templated geometry)
 int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
-int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_skinny.hip (decode batches, M <= 64)
+int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_skinny.hip (decode batches, M <= 256)
+int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... with the u4 epilogue (FP32 sums through p.ws)
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

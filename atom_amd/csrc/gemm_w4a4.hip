@@ -224,4 +224,31 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
   return launch_gemm_v2_o4(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t atom_gemm_w4a4_o4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
+  if (M < 1 || N < 128 || (N % 128) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  return skinny_fits(M, N, K_total) ? (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int atom_gemm_w4a4_o4_ws(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                         const void *sA8, const void *sB8, void *D_u4, void *D_scale_zero, int64_t M, int64_t N,
+                         int64_t K_total, int group, int keeper, int scale_layout, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  const size_t need = atom_gemm_w4a4_o4_workspace_bytes(M, N, K_total);
+  if (need == 0 || !workspace || workspace_bytes < need || (scale_layout & (ATOM_A_WIDE | ATOM_AB_F6)))
+    return atom_gemm_w4a4_o4(A4, B4, sA, sB, A8, B8, sA8, sB8, D_u4, D_scale_zero, M, N, K_total, group, keeper, scale_layout,
+                             stream);
+  if (!D_u4 || !D_scale_zero) return ATOM_ERR_INVALID_ARG;
+  GemmParams p;
+  const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+  if (st != ATOM_OK) return st;
+  if (!aligned16(D_u4) || !aligned16(workspace)) return ATOM_ERR_ALIGN;
+  p.D4 = (uint8_t *)D_u4;
+  p.Dsz = (half_t *)D_scale_zero;
+  p.ws = (float *)workspace;
+  const int s2 = launch_gemm_skinny_o4(p, reinterpret_cast<hipStream_t>(stream));
+  if (s2 != ATOM_ERR_SHAPE) return s2;
+  return atom_gemm_w4a4_o4(A4, B4, sA, sB, A8, B8, sA8, sB8, D_u4, D_scale_zero, M, N, K_total, group, keeper, scale_layout,
+                           stream);
+}
+
 }  // extern "C"

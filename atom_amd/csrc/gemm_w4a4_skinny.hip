@@ -44,7 +44,7 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 }
 
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
-template <int NW, int MBLK, int CNT>
+template <int NW, int MBLK, int CNT, bool OUT32 = false>   // OUT32: FP32 sums to p.ws [M, N] (the u4-epilogue path)
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]
   float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw);
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       s = v4f{s[0] + q[0], s[1] + q[1], s[2] + q[2], s[3] + q[3]};
     }
     const int m = tb * 16 + row;
-    if (m < p.M) {
+    if (m < p.M && OUT32) {
+      *reinterpret_cast<v4f *>(p.ws + (int64_t)m * p.N + n0 + 4 * kb) = s;
+    } else if (m < p.M) {
       v2u o;
       half_t *ov = reinterpret_cast<half_t *>(&o);
 #pragma unroll
@@ -169,33 +171,71 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   }
 }
 
-template <int NW, int MBLK, int CNT>
+template <int NW, int MBLK, int CNT, bool OUT32 = false>
 static int launch(const GemmParams &p, hipStream_t s) {
   constexpr size_t lds = (size_t)NW * MBLK * 64 * 16;
   if constexpr (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ATOM_ERR_LAUNCH;
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
 
-template <int NW, int CNT>
+template <int NW, int CNT, bool OUT32 = false>
 static int launch_m(const GemmParams &p, hipStream_t s) {
   const int mblk = (p.M + 15) / 16;
-  if (mblk <= 1) return launch<NW, 1, CNT>(p, s);
-  if (mblk <= 2 && !(NW == 8 && CNT == 14)) return launch<NW, 2, CNT>(p, s);   // (that one instance spills; 4 blocks do not)
-  if (mblk <= 4) return launch<NW, 4, CNT>(p, s);
+  if (mblk <= 1) return launch<NW, 1, CNT, OUT32>(p, s);
+  if constexpr (!(NW == 8 && CNT == 14)) {              // (that instance spills 14 VGPRs; the 4-block one does not)
+    if (mblk <= 2) return launch<NW, 2, CNT, OUT32>(p, s);
+  }
+  if (mblk <= 4) return launch<NW, 4, CNT, OUT32>(p, s);
   if constexpr (CNT <= 8) {
-    if (mblk <= 8) return launch<NW, 8, CNT>(p, s);
-    if (mblk <= 16) return launch<NW, 16, CNT>(p, s);
+    if (mblk <= 8) return launch<NW, 8, CNT, OUT32>(p, s);
+    if (mblk <= 16) return launch<NW, 16, CNT, OUT32>(p, s);
   }
   return ATOM_ERR_SHAPE;
+}
+
+// u4 epilogue of the decode path (reference: DenseLayerGEMM_i4_o4.cu:704-788; same arithmetic as the tile kernel's epilogue
+// in gemm_w4a4_v2.hip): every 128-column group of a row of the FP32 sums -> scale = (max-min)/15, zero = -min,
+// q = clamp(round_half_away((x + zero) * (1/scale)), 0, 15).  Half a wave per group, 4 values per lane.
+__global__ __launch_bounds__(256) void o4_quant_kernel(const float *__restrict__ x, uint8_t *__restrict__ q, half_t *__restrict__ sz,
+                                                        int64_t groups, int gpr /* groups per row */) {
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int l = threadIdx.x & 31;
+  if (grp >= groups) return;
+  const int64_t m = grp / gpr;
+  const int g = (int)(grp % gpr);
+  const v4f v = *reinterpret_cast<const v4f *>(x + (m * gpr + g) * 128 + 4 * l);
+  float lo = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), hi = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+  for (int k = 16; k >= 1; k >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, k));
+    hi = fmaxf(hi, __shfl_xor(hi, k));
+  }
+  const float scale = (hi - lo) / 15.f, zero = -lo, rs = 1.0f / scale;
+  unsigned w = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = (v[k] + zero) * rs;
+    float tr = truncf(t);
+    if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);
+    tr = fminf(fmaxf(tr, 0.f), 15.f);
+    if (scale == 0.f) tr = 0.f;
+    w |= (unsigned)(int)tr << (4 * k);
+  }
+  *reinterpret_cast<unsigned short *>(q + (m * gpr + g) * 64 + 2 * l) = (unsigned short)w;
+  if (l == 0) {
+    half_t *d = sz + (m * gpr + g) * 2;
+    d[0] = f2h(scale);
+    d[1] = f2h(zero);
+  }
 }
 
 }  // namespace skinny
@@ -211,6 +251,24 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s) {
   if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
   if (per <= 4) return skinny::launch_m<8, 4>(p, s);
   return per <= 8 ? skinny::launch_m<8, 8>(p, s) : skinny::launch_m<8, 14>(p, s);
+}
+
+
+// Decode path of the u4-output GEMM (k_proj / v_proj of a serving step): the same kernel with FP32 sums into the caller's
+// workspace [M, N], then the u4 epilogue as a second launch.  Same shapes as launch_gemm_skinny.
+int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s) {
+  if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 128) != 0 || !p.ws || !p.D4 || !p.Dsz) return ATOM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
+  const int per = (p.G + 1 + 7) / 8;
+  if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
+  const int st = per <= 4 ? skinny::launch_m<8, 4, true>(p, s)
+                          : (per <= 8 ? skinny::launch_m<8, 8, true>(p, s) : skinny::launch_m<8, 14, true>(p, s));
+  if (st != ATOM_OK) return st;
+  const int gpr = p.N / 128;
+  const int64_t groups = (int64_t)p.M * gpr;
+  hipLaunchKernelGGL(skinny::o4_quant_kernel, dim3((unsigned)((groups * 32 + 255) / 256)), dim3(256), 0, s, p.ws, p.D4, p.Dsz,
+                     groups, gpr);
+  return check_launch();
 }
 
 }  // namespace atom

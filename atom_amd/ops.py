@@ -50,8 +50,9 @@ def f6_rows(rows: int) -> int:
 
 
 def _alloc_act_outputs(bs, hidden_dim, device, layout, return_dequant, wide=False):
-    # zeros, not empty, for the replicated layout: it has slots no row ever writes
-    alloc = torch.zeros if layout == "ref" else torch.empty
+    # empty, like the reference's wrappers (punica/ops/__init__.py:189-196): the replicated layout has slots no row ever
+    # writes, and no kernel here reads them (rows are clamped to M - 1); zero-filling them cost two fill launches per op
+    alloc = torch.empty
     o_outlier = torch.empty((bs, GROUP_SIZE), dtype=torch.int8, device=device)
     if wide == "f6":        # [G][rows_pad][104] BF6 streams + in-row scales; pad rows are never read into a result
         o_norms = torch.empty((hidden_dim // GROUP_SIZE - 1, f6_rows(bs), L.F6_PITCH), dtype=torch.uint8, device=device)
@@ -199,18 +200,23 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
 
 
 def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
-                           scale_layout="ref"):
+                           scale_layout="ref", use_workspace=True):
     """Same GEMM, output asymmetric-quantised to u4 per 128-column group: (d u8[M,N/2], d_scale f16[M,N/128*2]).
-    Reference: punica/ops/__init__.py:170-180 -> DenseLayerGEMM_i4_o4 (DenseLayerGEMM_i4_o4.cu:808-856)."""
+    Reference: punica/ops/__init__.py:170-180 -> DenseLayerGEMM_i4_o4 (DenseLayerGEMM_i4_o4.cu:808-856).
+    Decode batches (the shapes of the decode-batch GEMM) go through atom_gemm_w4a4_o4_ws with the cached workspace (weight-streaming kernel + u4
+    epilogue launch); ``use_workspace=False`` forces the tile kernel."""
     m, n, k = _gemm_dims(a, b, a_keeper)
     assert n % 128 == 0
     d = torch.empty((m, n // 2), dtype=torch.uint8, device=a.device)
     d_scale = torch.empty((m, n // 128 * 2), dtype=torch.float16, device=a.device)
-    st = L.lib().atom_gemm_w4a4_o4(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
-                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
-                                    b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
-                                    GROUP_SIZE, _LAYOUTS[scale_layout], L.current_stream(a.device))
-    L.check(st, "atom_gemm_w4a4_o4")
+    lib = L.lib()
+    ws_bytes = lib.atom_gemm_w4a4_o4_workspace_bytes(m, n, k) if use_workspace else 0
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    st = lib.atom_gemm_w4a4_o4_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
+                                  a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
+                                  b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
+                                  GROUP_SIZE, _LAYOUTS[scale_layout], L.ptr(ws), ws_bytes, L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_o4_ws")
     return d, d_scale
 
 

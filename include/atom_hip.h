@@ -132,6 +132,21 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
                       int group, int keeper, int scale_layout, void *stream);
 
 /*
+ * Same result contract, with an optional caller-owned scratch buffer for DECODE batches (the k/v projections of a
+ * serving step; the shapes the decode-batch GEMM takes, M <= 256 at most).  The plain entry point runs the 256-row
+ * tile kernel whatever M is (88 us at M = 16, N = K = 4096); with
+ * a workspace of atom_gemm_w4a4_o4_workspace_bytes() bytes the weight-streaming decode kernel writes FP32 sums [M, N]
+ * there and a second launch applies the u4 epilogue (same arithmetic; the FP32 summation order is the decode kernel's,
+ * so a code can differ by one from the tile kernel's where a value sits on a rounding boundary).  0 bytes = the shape
+ * does not use it; then, or with a NULL / too small workspace, this is atom_gemm_w4a4_o4.
+ */
+size_t atom_gemm_w4a4_o4_workspace_bytes(int64_t M, int64_t N, int64_t K_total);
+int atom_gemm_w4a4_o4_ws(const void *A4, const void *B4, const void *sA, const void *sB,
+                         const void *A8, const void *B8, const void *sA8, const void *sB8,
+                         void *D_u4, void *D_scale_zero, int64_t M, int64_t N, int64_t K_total,
+                         int group, int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The three fused activation-quantisation ops.  Common outputs (row r, hidden = H, K4 = H-128):
  *   o_outliers     int8  [M, 128]        INT8 codes of the last 128 (reordered) channels
  *   o_norms        uint8 [M, K4/2]       packed INT4 codes of the first K4 channels

@@ -155,7 +155,7 @@ def test_gemm_o4_epilogue(M, N, K):
     ops = _ops()
     d = rand_gemm_operands(M, N, K, seed=M + 3 * N)
     dev = to_device(d, "plain")
-    q, sz = ops.dense_layer_gemm_i4_o4(*dev, scale_layout="plain")
+    q, sz = ops.dense_layer_gemm_i4_o4(*dev, scale_layout="plain", use_workspace=False)      # the tile kernel
     assert q.shape == (M, N // 2) and q.dtype == torch.uint8 and sz.shape == (M, N // 128 * 2)
     c32 = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"],
                  d["sB8"], fp32=True)
@@ -189,6 +189,32 @@ def test_gemm_split_k_path(M, N, K):
     assert (np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-3 * np.sqrt((b ** 2).mean())).all()    # different FP32 summation order
     if lib.atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
         assert np.array_equal(bits16(t2n(out)), bits16(t2n(plain)))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 256), (16, 4096, 4096), (40, 128, 640), (64, 4096, 1152), (33, 512, 11008),
+                                   (128, 4096, 4096), (200, 256, 1152)])
+@pytest.mark.parametrize("layout", ["ref", "plain"])
+def test_gemm_o4_decode_path(M, N, K, layout):
+    """atom_gemm_w4a4_o4_ws: decode batches run the weight-streaming kernel (FP32 sums into the workspace) + a u4
+    epilogue launch.  Same epilogue arithmetic as the tile kernel on sums that differ in the last FP32 bits (wave-order
+    summation): (scale, zero) within one fp16 ulp, codes equal except where a value sits on a rounding boundary (then
+    off by one), de-quantised tensor within half a step of the fp16 GEMM."""
+    ops = _ops()
+    assert ops.L.lib().atom_gemm_w4a4_o4_workspace_bytes(M, N, K) == 4 * M * N
+    d = rand_gemm_operands(M, N, K, seed=M + 7 * N)
+    dev = to_device(d, layout)
+    q, sz = ops.dense_layer_gemm_i4_o4(*dev, scale_layout=layout)
+    q_t, sz_t = ops.dense_layer_gemm_i4_o4(*dev, scale_layout=layout, use_workspace=False)
+    a, b = t2n(sz).astype(np.float64), t2n(sz_t).astype(np.float64)
+    assert (np.abs(a - b) <= 2e-3 * np.abs(b) + 1e-6).all()
+    ca = np.stack([t2n(q) & 0xF, t2n(q) >> 4], axis=-1).reshape(M, N).astype(np.int32)
+    cb = np.stack([t2n(q_t) & 0xF, t2n(q_t) >> 4], axis=-1).reshape(M, N).astype(np.int32)
+    assert np.abs(ca - cb).max() <= 1 and (ca != cb).mean() < 0.02
+    s = t2n(sz).reshape(M, N // 128, 2).astype(np.float32)
+    deq = ca.astype(np.float32).reshape(M, N // 128, 128) * s[..., 0:1] - s[..., 1:2]
+    ref = t2n(ops.dense_layer_gemm_i4_fp16(*dev, scale_layout=layout)).astype(np.float32).reshape(M, N // 128, 128)
+    assert np.abs(deq - ref).max() <= 0.51 * s[..., 0].max() + 0.1
+    assert torch.equal(q, ops.dense_layer_gemm_i4_o4(*dev, scale_layout=layout)[0])              # deterministic
 
 
 # decode batches: gemm_w4a4_skinny.hip (2 <= M <= 256; 8 waves split K: 1..14 groups per wave incl. waves with no work,
