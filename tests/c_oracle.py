@@ -31,6 +31,8 @@ def lib():
         L.oracle_gemm_w4a4_f16.argtypes = [vp] * 9 + [ctypes.c_long] * 3
         L.oracle_gemm_w4a4_f32.restype = None
         L.oracle_gemm_w4a4_f32.argtypes = [vp] * 9 + [ctypes.c_long] * 3
+        L.oracle_gemm_w4a4_f16_split.restype = None
+        L.oracle_gemm_w4a4_f16_split.argtypes = [vp] * 9 + [ctypes.c_long] * 3 + [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -51,9 +53,9 @@ def act_quant(op, x, b, idx, sim, clip, eps=0.0):
     return dict(q4=q4, s4=s4, q8=q8, s8=s8)
 
 
-def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False):
+def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False, nsplit=1):
     """Packed operands, sA_GM plain [G, M].  Returns float16 [M, N] under the C-ABI arithmetic contract
-    (fp32=True: the FP32 accumulators before the final rounding)."""
+    (fp32=True: the FP32 accumulators before the final rounding; nsplit=8: the decode-batch kernel's summation order)."""
     A4 = np.ascontiguousarray(A4, np.uint8); B4 = np.ascontiguousarray(B4, np.uint8)
     M, N = A4.shape[0], B4.shape[0]
     K = A4.shape[1] * 2 + 128
@@ -65,5 +67,8 @@ def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False):
         lib().oracle_gemm_w4a4_f32(*[_p(a) for a in arrs], _p(D), M, N, K)
         return D
     D = np.empty((M, N), np.float16)
-    lib().oracle_gemm_w4a4_f16(*[_p(a) for a in arrs], _p(D), M, N, K)
+    if nsplit > 1:
+        lib().oracle_gemm_w4a4_f16_split(*[_p(a) for a in arrs], _p(D), M, N, K, int(nsplit))
+    else:
+        lib().oracle_gemm_w4a4_f16(*[_p(a) for a in arrs], _p(D), M, N, K)
     return D

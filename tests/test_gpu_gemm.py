@@ -240,6 +240,21 @@ def test_gemm_decode_batches(M, N, K, layout):
         assert_gemm_close(t2n(row), exact[M - 1:M], "last row alone")
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 256, 256), (8, 64, 384), (16, 512, 512), (17, 1408, 2176), (31, 320, 1152),
+                                   (64, 1024, 1280), (100, 1408, 2176), (129, 320, 384), (16, 256, 13824)])
+def test_gemm_decode_batches_bit_exact_vs_c_contract(M, N, K):
+    """The decode-batch kernel is bit-identical to the C restatement of ITS summation order (oracle/atom_oracle.c,
+    nsplit = 8: the G + 1 items dealt to 8 waves in consecutive slices, per-item arithmetic of the contract, partial sums
+    added in wave order)."""
+    from tests import c_oracle as C
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M * 17 + N + K)
+    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
+    want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"],
+                  nsplit=8)
+    assert np.array_equal(bits16(t2n(out)), bits16(want))
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 512, 512), (129, 320, 384), (257, 1024, 1152), (300, 64, 1280), (8, 4096, 4096),
                                    (64, 5120, 5120), (1024, 1024, 2176), (5, 256, 640)])
 @pytest.mark.parametrize("layout", ["ref", "plain"])

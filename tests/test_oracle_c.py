@@ -64,3 +64,22 @@ def test_gemm_contract_vs_exact():
         exh = ex.astype(np.float16)
     ulp = np.abs(bits16(D).astype(np.int32) - bits16(exh).astype(np.int32))
     assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02        # FP32 accumulation vs FP64: at most the last fp16 bit
+
+
+@pytest.mark.parametrize("K", [256, 640, 2176])
+def test_gemm_decode_summation_order(K):
+    """oracle_gemm_w4a4_f16_split (the decode-batch kernel's order: items dealt to 8 waves, partial sums added in wave
+    order): identical to the contract order when one wave gets every item, within 1 fp16 ulp of exact otherwise."""
+    d = rand_gemm_operands(9, 64, K, seed=K)
+    args = (O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+    base = C.gemm(*args)
+    assert np.array_equal(bits16(C.gemm(*args, nsplit=1)), bits16(base))
+    split = C.gemm(*args, nsplit=8)
+    ex = O.gemm_w4a4_exact(d["qa4"], d["qb4"], d["sA"], d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+    with np.errstate(over="ignore"):
+        exh = ex.astype(np.float16)
+    ulp = np.abs(bits16(split).astype(np.int32) - bits16(exh).astype(np.int32))
+    assert ulp.max() <= 1
+    G = (K - 128) // 128
+    huge = C.gemm(*args, nsplit=2 * (G + 1))       # per = 1 -> every item its own wave: still a valid order
+    assert np.abs(bits16(huge).astype(np.int32) - bits16(exh).astype(np.int32)).max() <= 1
