@@ -27,6 +27,7 @@
 // are merged once at the end.
 #include <math.h>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace atom {
@@ -353,15 +354,23 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
   return ATOM_OK;
 }
 
-// KV splits so that batch*heads*splits waves give the chip about two rounds of its 12 resident waves per CU, at least 8
-// tiles per split (a split costs a prologue of 32 sincos and a 16-quad merge)
+// KV splits: batch*heads*splits waves run in rounds of 3072 (12 resident waves per CU); a wave costs its tiles plus about
+// two tiles of prologue (32 sincos) and merge, the merge kernel grows with the splits.  Pick the split count that minimises
+// rounds x (tiles per wave + 2) under at least 8 tiles per split (measured: profiles/r01_kv_decode.txt).
 static int decode_splits(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
-  const int64_t tiles = (int64_t)max_pages * (P / 16);
-  int64_t s = (6144 + (int64_t)batch * N - 1) / ((int64_t)batch * N);      // ~2 rounds of 12 resident waves per CU
-  if (s > tiles / 8) s = tiles / 8;                                        // prologue + merge cost about 2 tiles
-  if (s > 64) s = 64;
-  return s < 2 ? 1 : (int)s;
+  const int64_t tiles = (int64_t)max_pages * (P / 16), pairs = (int64_t)batch * N;
+  static const int min_tiles = [] { const char *e = getenv("ATOM_DECODE_MIN_TILES"); return e ? atoi(e) : 8; }();   // tuning only
+  int64_t smax = tiles / min_tiles;
+  if (smax > 64) smax = 64;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int64_t s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
+    const int64_t rounds = (pairs * s + 3071) / 3072;
+    const double cost = (double)rounds * ((double)tiles / (double)s + 2.0) + 0.15 * (double)s;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)s; }
+  }
+  return best;
 }
 
 }  // namespace atom
