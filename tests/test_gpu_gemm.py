@@ -291,7 +291,9 @@ def test_gemm_wide_full_size_and_errors():
         ops.L.check(st, "atom_gemm_w4a4_o4")
 
 
-@pytest.mark.parametrize("M,N,K", [(16, 512, 512), (257, 1024, 1152), (300, 64, 1280), (1024, 1024, 2176), (5, 256, 640)])
+# (1500, 1408, 640) and (2048, 2048, 1152) run the 128x128 geometry (ragged / whole tiles), the others 64x128
+@pytest.mark.parametrize("M,N,K", [(16, 512, 512), (257, 1024, 1152), (300, 64, 1280), (1024, 1024, 2176), (5, 256, 640),
+                                   (1500, 1408, 640), (2048, 2048, 1152)])
 def test_gemm_f6_operands_bit_identical(M, N, K):
     """ATOM_AB_F6: both operands as BF6 streams on the block-scaled MFMA (gemm_w4a4_f6.hip).  Integer dot products are
     exact there too and the FP32 de-quantisation order is the same: equal to the packed call bit for bit where that one
