@@ -65,7 +65,8 @@ int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s);         // gemm_w4a4_
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_v3.hip (templated geometry)
 int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
 int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_skinny.hip (decode batches, M <= 256)
-int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... with the u4 epilogue (FP32 sums through p.ws)
+int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
+int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -224,6 +224,20 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
   return launch_gemm_v2_o4(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                       const void *sA8, const void *sB8, void *D_f32, int64_t M, int64_t N, int64_t K_total, int group,
+                       int keeper, int scale_layout, void *stream) {
+  if (!D_f32) return ATOM_ERR_INVALID_ARG;
+  if (scale_layout & (ATOM_A_WIDE | ATOM_AB_F6)) return ATOM_ERR_INVALID_ARG;
+  GemmParams p;
+  const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+  if (st != ATOM_OK) return st;
+  if (!aligned16(D_f32)) return ATOM_ERR_ALIGN;
+  if (!skinny_fits(M, N, K_total)) return ATOM_ERR_SHAPE;
+  p.ws = (float *)D_f32;
+  return launch_gemm_skinny_f32(p, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t atom_gemm_w4a4_o4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 128 || (N % 128) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   return skinny_fits(M, N, K_total) ? (size_t)M * (size_t)N * sizeof(float) : 0;

@@ -256,13 +256,19 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s) {
 
 // Decode path of the u4-output GEMM (k_proj / v_proj of a serving step): the same kernel with FP32 sums into the caller's
 // workspace [M, N], then the u4 epilogue as a second launch.  Same shapes as launch_gemm_skinny.
-int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s) {
-  if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 128) != 0 || !p.ws || !p.D4 || !p.Dsz) return ATOM_ERR_SHAPE;
+// FP32 sums [M, N] into p.ws (no final rounding): the k / v projections of a decode step, ahead of the u4 epilogue
+int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
+  if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0 || !p.ws) return ATOM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
   const int per = (p.G + 1 + 7) / 8;
   if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
-  const int st = per <= 4 ? skinny::launch_m<8, 4, true>(p, s)
-                          : (per <= 8 ? skinny::launch_m<8, 8, true>(p, s) : skinny::launch_m<8, 14, true>(p, s));
+  return per <= 4 ? skinny::launch_m<8, 4, true>(p, s)
+                  : (per <= 8 ? skinny::launch_m<8, 8, true>(p, s) : skinny::launch_m<8, 14, true>(p, s));
+}
+
+int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s) {
+  if ((p.N % 128) != 0 || !p.D4 || !p.Dsz) return ATOM_ERR_SHAPE;
+  const int st = launch_gemm_skinny_f32(p, s);
   if (st != ATOM_OK) return st;
   const int gpr = p.N / 128;
   const int64_t groups = (int64_t)p.M * gpr;

@@ -88,6 +88,56 @@ __global__ __launch_bounds__(256) void kv_append_kernel(AppendParams p) {
   }
 }
 
+// Decode step, fused: the FP32 sums of the k / v projections (decode-batch GEMM, atom_gemm_w4a4_f32) are quantised per
+// head (the u4 epilogue of the reference's _o4 GEMM: scale = (max-min)/15, zero = -min, q = clamp(round_half_away((x+zero)
+// * (1/scale)), 0, 15), DenseLayerGEMM_i4_o4.cu:704-788) and written straight into the last token's slot of the paged
+// cache (FlashInferAppendKvKernel_i4, flashinfer_impl.cuh:72-96) -- one launch instead of two epilogues + an append.
+// One workgroup per sequence, half a wave per (K|V, head), 4 values per lane.
+struct QuantAppendParams {
+  KvParams kv;
+  const float *k, *v;   // [batch, N * 128]
+};
+
+__global__ __launch_bounds__(256) void kv_quant_append_kernel(QuantAppendParams p) {
+  const int b = blockIdx.x;
+  const int l = threadIdx.x & 31;
+  const int P = p.kv.P, N = p.kv.N;
+  const int seq_len = (p.kv.indptr[b + 1] - p.kv.indptr[b] - 1) * P + p.kv.last_page_offset[b];
+  const int pos = seq_len - 1;
+  if (pos < 0) return;
+  const int64_t page = p.kv.indices[p.kv.indptr[b] + pos / P];
+  const int e = pos % P;
+  const int64_t base = (page * p.kv.L + p.kv.layer) * 2;             // [.., 2, N, P, ..]
+  for (int gi = threadIdx.x >> 5; gi < 2 * N; gi += 8) {
+    const int kv = gi / N, h = gi % N;
+    const v4f x = *reinterpret_cast<const v4f *>((kv ? p.v : p.k) + ((int64_t)b * N + h) * kHeadDim + 4 * l);
+    float lo = fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), hi = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+#pragma unroll
+    for (int k = 16; k >= 1; k >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, k));
+      hi = fmaxf(hi, __shfl_xor(hi, k));
+    }
+    const float scale = (hi - lo) / 15.f, zero = -lo, rs = 1.0f / scale;
+    unsigned w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = (x[k] + zero) * rs;
+      float tr = truncf(t);
+      if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);
+      tr = fminf(fmaxf(tr, 0.f), 15.f);
+      if (scale == 0.f) tr = 0.f;
+      w |= (unsigned)(int)tr << (4 * k);
+    }
+    const int64_t slot = ((base + kv) * N + h) * P + e;
+    *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = (unsigned short)w;
+    if (l == 0) {
+      half_t *d = p.kv.param + slot * 2;
+      d[0] = f2h(scale);
+      d[1] = f2h(zero);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ decode
 struct DecodeParams {
   KvParams kv;
@@ -396,6 +446,21 @@ int atom_kv_append_i4(void *kv_data, void *kv_param, const int32_t *kv_indptr, c
                  (const uint8_t *)k, (const uint8_t *)v, (const half_t *)k_param, (const half_t *)v_param,
                  append_indptr, total_tokens};
   hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)total_tokens), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+int atom_kv_quant_append_f32(void *kv_data, void *kv_param, const int32_t *kv_indptr, const int32_t *kv_indices,
+                             const int32_t *last_page_offset, const void *k_f32, const void *v_f32, int batch,
+                             int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, void *stream) {
+  const int st = check_kv(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
+                          num_heads, page_size, head_dim);
+  if (st != ATOM_OK) return st;
+  if (!k_f32 || !v_f32) return ATOM_ERR_INVALID_ARG;
+  if (!aligned16(k_f32) || !aligned16(v_f32)) return ATOM_ERR_ALIGN;
+  QuantAppendParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
+                       layer_idx, num_heads, page_size},
+                      (const float *)k_f32, (const float *)v_f32};
+  hipLaunchKernelGGL(kv_quant_append_kernel, dim3((unsigned)batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch();
 }
 

@@ -10,11 +10,15 @@ import torch
 from torch import nn
 
 import math
+import os
 
 from .. import ops
 from ..utils import BatchedKvCacheInt4, BatchLenInfo
 
 GROUP = 128
+
+
+_FUSED_KV_APPEND = os.environ.get("ATOM_FUSED_KV_APPEND", "1") != "0"   # 0: the reference's op sequence in decode steps too
 
 
 class LinearInt4(nn.Module):
@@ -55,6 +59,12 @@ class LinearInt4(nn.Module):
         f = {"int4": ops.dense_layer_gemm_i4_o4, "fp16": ops.dense_layer_gemm_i4_fp16}[self.out_dtype]
         return f(norms, self.weight_int4, norm_scales, self.scale_int4, outlier, self.weight_int8, outlier_scales,
                  self.scale_int8)
+
+    def forward_f32(self, input):
+        """FP32 sums (decode batches only): what the "int4" epilogue would quantise; see LlamaAttention.forward."""
+        outlier, norms, outlier_scales, norm_scales = input
+        return ops.dense_layer_gemm_i4_f32(norms, self.weight_int4, norm_scales, self.scale_int4, outlier, self.weight_int8,
+                                           outlier_scales, self.scale_int8)
 
 
 class LlamaRMSNormInt4(nn.Module):
@@ -139,9 +149,19 @@ class LlamaAttention(nn.Module):
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv: BatchedKvCacheInt4 | None,
                 decode_kv: BatchedKvCacheInt4 | None) -> torch.Tensor:
         q_proj = self.q_proj(hidden_states)
+        nh, hd = self.num_heads, self.head_dim
+        rows = hidden_states[0].size(0)
+        if (len(blen.prefills) == 0 and blen.decode == rows and _FUSED_KV_APPEND
+                and ops.decode_gemm_fits(rows, self.hidden_size, self.hidden_size)):
+            # pure decode step: k / v sums in FP32, then ONE launch quantises both per head and writes the cache slots
+            # (same cache contents as the u4-epilogue GEMMs + append_kv_i4 below; three launches fewer)
+            assert decode_kv is not None
+            ops.quant_append_kv_i4(decode_kv, self.k_proj.forward_f32(hidden_states), self.v_proj.forward_f32(hidden_states),
+                                   self.layer_idx)
+            o = ops.batch_decode_i4(q_proj.view(rows, nh, hd), decode_kv, self.layer_idx, rope_theta=self.rope_theta)
+            return self.o_proj(ops.reorder_fp16_i4(o.view(rows, self.hidden_size), self.reorder_index))
         k_u4, k_sz = self.k_proj(hidden_states)
         v_u4, v_sz = self.v_proj(hidden_states)
-        nh, hd = self.num_heads, self.head_dim
         outs = []
         if len(blen.prefills) > 0:
             assert prefill_kv is not None

@@ -220,6 +220,25 @@ def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_
     return d, d_scale
 
 
+def decode_gemm_fits(m: int, n: int, k: int) -> bool:
+    """True when (m, n, k) is a shape the decode-batch GEMM takes, i.e. dense_layer_gemm_i4_f32 is available."""
+    return m >= 1 and n % 128 == 0 and L.lib().atom_gemm_w4a4_o4_workspace_bytes(m, n, k) > 0
+
+
+def dense_layer_gemm_i4_f32(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
+                            scale_layout="ref"):
+    """NEW (no reference counterpart): the FP32 sums of the GEMM, float [M, N], for decode batches (decode_gemm_fits) --
+    what the u4 epilogue quantises; feeds quant_append_kv_i4."""
+    m, n, k = _gemm_dims(a, b, a_keeper)
+    d = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    st = L.lib().atom_gemm_w4a4_f32(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
+                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
+                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
+                                    _LAYOUTS[scale_layout], L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_f32")
+    return d
+
+
 def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: int = 2, return_fake_quant=False):
     """NEW (no reference counterpart): quantise + pack a (column-reordered) FP16 weight [N,K] the
     way QLinearLayer.quant does (qLinearLayer.py:42-78).  Returns (B4 u8[N,K4/2], B8 i8[N,128], sB f16[G,N],
@@ -296,6 +315,22 @@ def init_kv_i4(kv, k, v, k_param, v_param, seqlen_indptr, layer_idx: int):
 def append_kv_i4(kv, k, v, k_param, v_param, layer_idx: int):
     """Append ONE token per sequence.  Reference: punica/ops/__init__.py:48-59 -> FlashInferAppendKvKernel_i4."""
     _kv_append(kv, k, v, k_param, v_param, None, layer_idx, "atom_kv_append_i4")
+
+
+def quant_append_kv_i4(kv, k_f32: torch.Tensor, v_f32: torch.Tensor, layer_idx: int):
+    """NEW (fused decode step): quantise the FP32 k / v projections [batch, heads*128] per head (the _o4 epilogue) and
+    append them as the last token of every sequence.  Same cache contents as dense_layer_gemm_i4_o4 + append_kv_i4."""
+    num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
+    batch = kv.last_page_offset.numel()
+    for t in (k_f32, v_f32):
+        if not t.is_cuda:
+            raise L.AtomHipError("KV-cache operands must live on the GPU: no CPU fallback")
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (batch, num_heads * head_dim)
+    st = L.lib().atom_kv_quant_append_f32(kv.data.data_ptr(), kv.param.data_ptr(), kv.indptr.data_ptr(),
+                                          kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), k_f32.data_ptr(),
+                                          v_f32.data_ptr(), batch, num_layers, int(layer_idx), num_heads, page_size, head_dim,
+                                          L.current_stream(k_f32.device))
+    L.check(st, "atom_kv_quant_append_f32")
 
 
 def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0):

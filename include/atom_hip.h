@@ -147,6 +147,17 @@ int atom_gemm_w4a4_o4_ws(const void *A4, const void *B4, const void *sA, const v
                          int group, int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same sums WITHOUT the final rounding: D_f32 float [M, N] = the FP32 accumulators the u4 epilogue quantises.
+ * Decode batches in the packed format only (the shapes the decode-batch GEMM takes; ATOM_ERR_SHAPE otherwise).  Feeds
+ * atom_kv_quant_append_f32 below: k / v projection -> u4 codes -> paged cache in two launches per projection pair
+ * instead of five.  No reference counterpart (its _o4 GEMM quantises in its epilogue, the append is a separate kernel).
+ */
+int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const void *sB,
+                       const void *A8, const void *B8, const void *sA8, const void *sB8,
+                       void *D_f32, int64_t M, int64_t N, int64_t K_total,
+                       int group, int keeper, int scale_layout, void *stream);
+
+/*
  * The three fused activation-quantisation ops.  Common outputs (row r, hidden = H, K4 = H-128):
  *   o_outliers     int8  [M, 128]        INT8 codes of the last 128 (reordered) channels
  *   o_norms        uint8 [M, K4/2]       packed INT4 codes of the first K4 channels
@@ -240,6 +251,14 @@ int atom_kv_append_i4(void *kv_data, void *kv_param, const int32_t *kv_indptr, c
                       const int32_t *last_page_offset, const void *k, const void *v, const void *k_param,
                       const void *v_param, const int32_t *append_indptr, int64_t total_tokens, int batch,
                       int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, void *stream);
+
+/* Decode step, fused: quantise the FP32 sums of the k / v projections (atom_gemm_w4a4_f32: float [batch, heads*128] each)
+ * per head with the arithmetic of the _o4 epilogue (DenseLayerGEMM_i4_o4.cu:704-788) and write codes + (scale, zero)
+ * into the LAST token's slot of each sequence (the one-token-per-sequence form of FlashInferAppendKvKernel_i4,
+ * flashinfer_impl.cuh:72-96).  Bit-identical cache contents to atom_gemm_w4a4_o4_ws + atom_kv_append_i4. */
+int atom_kv_quant_append_f32(void *kv_data, void *kv_param, const int32_t *kv_indptr, const int32_t *kv_indices,
+                             const int32_t *last_page_offset, const void *k_f32, const void *v_f32, int batch,
+                             int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, void *stream);
 
 /* o[b,h,:] (fp16) = softmax_j( <RoPE(q[b,h], len_b-1), RoPE(dequant K[b,h,j], j)> / sqrt(128) ) . dequant V[b,h,j].
  * Replaces: FlashInferBatchDecodeKernel_i4 (flashinfer_impl.cuh:9-46; decode.cuh:480-676) = punica_ops.cc:82-120

@@ -139,3 +139,38 @@ def test_kv_fake_quant_bit_exact(golden_dir):
     from atom_amd.model import quant as Q
     args = types.SimpleNamespace(abits=4, kv_clip_ratio=1.0)
     assert np.array_equal(bits16(t2n(Q.quantize_attn_k_wrapper(xt, args))), bits16(z["k_b4_c1.0"]))
+
+
+@pytest.mark.parametrize("seqlens,heads,block", [([5, 17, 32, 1], 4, 16), ([40] * 9, 2, 32)])
+def test_fused_quant_append_equals_o4_gemm_plus_append(seqlens, heads, block):
+    """Decode step: atom_gemm_w4a4_f32 + atom_kv_quant_append_f32 (FP32 k / v sums -> u4 codes straight into the cache)
+    leaves exactly the cache contents of the reference's op sequence dense_layer_gemm_i4_o4 (decode path) + append_kv_i4,
+    and touches nothing but the last token's slots."""
+    from atom_amd import ops
+    from atom_amd.utils import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    from tests.helpers import rand_gemm_operands, to_device
+    dev = torch.device("cuda")
+    B, N, K = len(seqlens), heads * 128, 640
+    dk = to_device(rand_gemm_operands(B, N, K, seed=3), "ref")
+    dv = to_device(rand_gemm_operands(B, N, K, seed=4), "ref")
+    assert ops.decode_gemm_fits(B, N, K)
+    pools = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        pool = KvPoolInt4(num_layers=2, num_heads=heads, head_dim=128, capacity=64, block_len=block, device=dev)
+        pool.buf.copy_(torch.randint(0, 256, pool.buf.shape, dtype=torch.uint8))
+        pool.param.copy_(torch.rand(pool.param.shape).half())
+        pool._free = set(range(64))                                  # same page numbering in both runs
+        kv = BatchedKvCacheInt4([KvCacheInt4(pool, n) for n in seqlens])
+        before = (pool.buf.clone(), pool.param.clone())
+        if fused:
+            ops.quant_append_kv_i4(kv, ops.dense_layer_gemm_i4_f32(*dk), ops.dense_layer_gemm_i4_f32(*dv), 1)
+        else:
+            k, ks = ops.dense_layer_gemm_i4_o4(*dk)
+            v, vs = ops.dense_layer_gemm_i4_o4(*dv)
+            ops.append_kv_i4(kv, k.view(B, heads, 64), v.view(B, heads, 64), ks.view(B, heads, 2), vs.view(B, heads, 2), 1)
+        changed = (pool.buf != before[0]).any(dim=-1)                # [page, layer, kv, head, slot]
+        assert not changed[:, 0].any()                               # layer 0 untouched
+        assert changed.sum().item() <= 2 * heads * B
+        pools.append(pool)
+    assert torch.equal(pools[0].buf, pools[1].buf) and torch.equal(pools[0].param, pools[1].param)

@@ -15,7 +15,7 @@ from atom_amd.e2e import LlamaDecoderLayer  # noqa: E402
 from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4  # noqa: E402
 
 TIMED = ["rmsnorm_fp16_i4", "add_rmsnorm_fp16_i4", "reorder_fp16_i4", "activate_fp16_i4", "dense_layer_gemm_i4_fp16",
-         "dense_layer_gemm_i4_o4", "append_kv_i4", "batch_decode_i4"]
+         "dense_layer_gemm_i4_o4", "dense_layer_gemm_i4_f32", "append_kv_i4", "quant_append_kv_i4", "batch_decode_i4"]
 
 
 def main(ctx=1024, batches=(1, 4, 8, 16, 32, 64, 128), hidden=4096, heads=32, inter=11008, iters=20):
