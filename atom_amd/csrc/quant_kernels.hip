@@ -214,6 +214,28 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   double *red = reinterpret_cast<double *>(smem + 2 * stage);      // [2][4] partial sums of squares
   const int j = tid & 7;
 
+  auto issue_row = [&](int64_t r, int b) {                  // DMA row r into buffer b
+    const char *src = reinterpret_cast<const char *>(p.x + r * (int64_t)H);
+    const char *src2 = reinterpret_cast<const char *>(p.res + r * (int64_t)H);
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) {
+      const int blk = i * 4 + wave;                         // 1 KiB block
+      if (blk * 64 < nchunks) {
+        const int c = min(blk * 64 + lane, nchunks - 1);    // tail lanes re-read the last chunk into the padding
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 16), (lptr_t)(smem + b * stage + blk * 1024), 16, 0, 0);
+        if constexpr (ADD)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src2 + c * 16), (lptr_t)(smem + b * stage + bufbytes + blk * 1024),
+                                           16, 0, 0);
+      }
+    }
+  };
+
+  // the first row is on its way before anything else: with one row per workgroup (decode batches) the kernel is a chain
+  // of memory round trips, and the index / weight gathers below are two of them
+  int64_t r = blockIdx.x;
+  int b = 0;
+  if (r < p.M) issue_row(r, 0);
+
   // loop-invariant per-thread state: LDS byte offsets of my channels, gathered RMSNorm weights
   int off[NP][16];
   float wg[NP][16];
@@ -238,25 +260,6 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
     }
   }
 
-  auto issue_row = [&](int64_t r, int b) {                  // DMA row r into buffer b
-    const char *src = reinterpret_cast<const char *>(p.x + r * (int64_t)H);
-    const char *src2 = reinterpret_cast<const char *>(p.res + r * (int64_t)H);
-#pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) {
-      const int blk = i * 4 + wave;                         // 1 KiB block
-      if (blk * 64 < nchunks) {
-        const int c = min(blk * 64 + lane, nchunks - 1);    // tail lanes re-read the last chunk into the padding
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 16), (lptr_t)(smem + b * stage + blk * 1024), 16, 0, 0);
-        if constexpr (ADD)
-          __builtin_amdgcn_global_load_lds((gptr_t)(src2 + c * 16), (lptr_t)(smem + b * stage + bufbytes + blk * 1024),
-                                           16, 0, 0);
-      }
-    }
-  };
-
-  int64_t r = blockIdx.x;
-  int b = 0;
-  if (r < p.M) issue_row(r, 0);
   for (; r < p.M; r += gridDim.x, b ^= 1) {
     __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0): my DMA writes have landed
     __syncthreads();
