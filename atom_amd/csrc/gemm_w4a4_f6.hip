@@ -419,6 +419,244 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
   }
 }
 
+// ================================================================================================================
+// The 256x256 geometry on v_mfma_scale_f32_16x16x128_f8f6f4 (the product kernel of that geometry): one MFMA covers a whole
+// 128-channel group of a 16x16 tile -- no dependent MFMA pair -- and its result is 4 VGPRs, so a second accumulator set
+// costs 8 registers instead of 16 and the next tiles' MFMAs are issued ahead of the previous tiles' de-quantisation.
+// Measured against the 32x32x64 kernel above (same contract, bit-identical output): 67.4 vs 69.7 us at 4096^3, 485 vs 501 us
+// at 8192^3; tiles in pairs (2 MFMAs in flight, then 8 multiplies + 8 FMAs) beat single tiles and quads (69.1 us each), one
+// pair of look-ahead beats two (68.7), and the mid-step priority swap of the two waves of a SIMD is worth 6 % here (71.2
+// without).
+// Wave tile: 64 features (4 blocks fb) x 128 tokens (8 blocks tb).  Lane l: MFMA row / column l % 16, k-block l / 16
+// (32 codes = 24 bytes at byte 24 * (l / 16) of the row); result: token l % 16, features 4 * (l / 16) + r.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dequant4x(const v4f_t &acc, float sa, const v2u &sb, float (&c)[4]) {
+  const half_t *hv = reinterpret_cast<const half_t *>(&sb);
+  float t[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = acc[r] * sa;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c[r] = __builtin_fmaf(t[r], (float)hv[r], c[r]);
+    asm volatile("" : "+v"(c[r]));
+  }
+}
+
+template <class C, class F = NoDma>
+__device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4], F dma = F(),
+                                                 bool older = false) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const char *pw = slot + (wn * 64 + l15) * PITCH + kb * 24;                  // + fb*16*PITCH
+  const char *pa = slot + C::A_OFF + (wm * 128 + l15) * PITCH + kb * 24;      // + tb*16*PITCH
+  const char *psa = slot + C::A_OFF + (wm * 128 + l15) * PITCH + 96;          // + tb*16*PITCH
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;                // + fb*32
+  v8i af[4], bf[2];
+  v2u sb[4];
+  // fragment loads in the order the MFMAs consume them (all 8 waves hit the LDS at once behind the barrier)
+  bf[0] = frag24(pa);
+  af[0] = frag24(pw);
+  half_t sah = *reinterpret_cast<const half_t *>(psa);
+#pragma unroll
+  for (int fb = 1; fb < 4; ++fb) af[fb] = frag24(pw + fb * 16 * PITCH);
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb) sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
+  // tiles in pairs (fb 0,1 / 2,3 of a token block): a pair's MFMAs are issued one pair ahead of its 16 VALU instructions
+  // (8 multiplies, then 8 FMAs: no dependent back-to-back issue)
+  constexpr int GS = 2, NG = 32 / GS, GPB = 4 / GS, DEPTH = 1;
+  v4f_t acc[DEPTH + 1][GS];
+  auto mma = [&](int g) {
+    const int tb = g / GPB, f0 = (g % GPB) * GS;
+#pragma unroll
+    for (int k = 0; k < GS; ++k) {
+      acc[g % (DEPTH + 1)][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
+      acc[g % (DEPTH + 1)][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[f0 + k], bf[tb & 1], acc[g % (DEPTH + 1)][k], 3, 3, 0, 127, 0, 127);
+    }
+  };
+  mma(0);
+  float sa = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int tb = g / GPB, f0 = (g % GPB) * GS;
+    __builtin_amdgcn_sched_barrier(0);
+    if (g % GPB == 0) {
+      sa = (float)sah;
+      if (tb + 1 < 8) {
+        bf[(tb + 1) & 1] = frag24(pa + (tb + 1) * 16 * PITCH);
+        sah = *reinterpret_cast<const half_t *>(psa + (tb + 1) * 16 * PITCH);
+      }
+      // the two waves of a SIMD swap priority mid-step (see compute_int4)
+      if (tb == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+      if (tb == 4) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+    }
+    if (g + DEPTH < NG) mma(g + DEPTH);
+    if (g % GPB == GPB - 1) {
+#pragma unroll
+      for (int i = (tb * C::GLDS + 7) / 8; i < ((tb + 1) * C::GLDS + 7) / 8; ++i) dma(i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float t[4 * GS];
+#pragma unroll
+      for (int k = 0; k < GS; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[4 * k + r] = acc[g % (DEPTH + 1)][k][r] * sa;
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        const half_t *hv = reinterpret_cast<const half_t *>(&sb[f0 + k]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c[f0 + k][tb][r] = __builtin_fmaf(t[4 * k + r], (float)hv[r], c[f0 + k][tb][r]);
+          asm volatile("" : "+v"(c[f0 + k][tb][r]));
+        }
+      }
+    }
+  }
+}
+
+// keeper half-step on v_mfma_i32_16x16x64_i8, same tile layout; each half de-quantised on its own (the contract)
+template <class C>
+__device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4]) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int sw = (l15 >> 2) & 3;
+  const char *pw = slot + (wn * 64 + l15) * 64 + ((kb ^ sw) << 4);                     // + fb*16*64
+  const char *pa = slot + (C::BN + wm * 128 + l15) * 64 + ((kb ^ sw) << 4);            // + tb*16*64
+  const char *psa = slot + C::KP_SA_OFF + (wm * 128 + l15) * 4;                        // + tb*64
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;
+  v4i af[4];
+  v2u sb[4];
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb) {
+    af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + fb * 1024));
+    sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
+  }
+#pragma unroll
+  for (int tb = 0; tb < 8; ++tb) {
+    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + tb * 1024));
+    const float sa = (float)*reinterpret_cast<const half_t *>(psa + tb * 64);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+      v4i a = {0, 0, 0, 0};
+      a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[fb], b, a, 0, 0, 0);
+      const v4f_t f = {(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+      dequant4x(f, sa, sb[fb], c[fb][tb]);
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6x16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NS = C::NS;
+  static_assert(C::BM == 256 && C::BN == 256 && C::TM == 4 && NS == 3, "x16 experiment: the 256x256 geometry");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[4][8][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
+
+  const int nsteps = p.G + 2;
+  auto issue = [&](int step) {
+    char *slot = lds + (step % NS) * C::STAGE_BYTES;
+    const int s = min(step, nsteps - 1);
+    if (s < p.G) issue_int4<C>(p, s, slot, wave, lane, m0, n0);
+    else issue_keeper<C>(p, s - p.G, slot, wave, lane, m0, n0);
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+  const bool older = wave < C::NW / 2;
+  int step = 0;
+  for (; step + NS - 1 < p.G; ++step) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    char *nslot = lds + ((step + NS - 1) % NS) * C::STAGE_BYTES;
+    const int g = step + NS - 1;
+    auto dma = [&](int i) { issue_int4_piece<C>(p, g, nslot, wave, lane, m0, n0, i); };
+    __builtin_amdgcn_sched_barrier(0);
+    compute_int4_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, older);
+  }
+  for (; step < p.G; ++step) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(step + NS - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_int4_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), older);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  for (; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(step + NS - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_keeper_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // epilogue: per wave [64 tokens][64 features] fp16 through LDS (row stride 144 B), two halves of 64 tokens
+  const int l15 = lane & 15, kb = lane >> 4;
+  constexpr int EP_STRIDE = 144;
+  char *ep = lds + wave * (64 * EP_STRIDE);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int tb = half * 4 + t4;
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) {
+        v2u o;
+        half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ov[k] = f2h(c[fb][tb][k]);
+        *reinterpret_cast<v2u *>(ep + (t4 * 16 + l15) * EP_STRIDE + (fb * 16 + 4 * kb) * 2) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = i * 8 + (lane >> 3);
+      const int ch = lane & 7;
+      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
+      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int n = n0 + wn * 64 + ch * 8;
+      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+    }
+  }
+}
+
+template <class C>
+static int launch_x16(const GemmParams &p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return ATOM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  return check_launch();
+}
+
 template <class C, bool SK, int ABL = 0>
 static int launch(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
@@ -440,8 +678,8 @@ static int launch(const GemmParams &p, hipStream_t s) {
 
 }  // namespace f6
 
-// cfg: 0 = 256x256 (8 waves), 1 = 256x128 (4 waves, 2 stages, two workgroups per CU), 2 = 64x128 (2 waves; split-K when
-// p.splits > 1 and p.ws is set)
+// cfg: 0 = 256x256 (8 waves, 16x16x128 MFMA micro-tiles), 3 = 128x128 (4 waves, three workgroups per CU), 2 = 64x128
+// (2 waves; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128, 10 = 256x256 on the 32x32x64 MFMA
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
 #ifdef ATOM_F6_ABLATE
   if (cfg == 116) {   // traced run (tools/trace_f6.cpp): the stamp buffer arrives in ATOM_TRACE_PTR
@@ -461,9 +699,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.splits > 1 && p.ws) return f6::launch<f6::Cfg<64, 128, 2, 3>, true>(p, s);
     return f6::launch<f6::Cfg<64, 128, 2, 3>, false>(p, s);
   }
+  if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 3) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);   // 4 waves, three workgroups per CU
-  return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);
+  return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // 256x256 on the 16x16x128 MFMA
 }
 
 }  // namespace atom
