@@ -420,13 +420,13 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
 }
 
 // ================================================================================================================
-// The 256x256 geometry on v_mfma_scale_f32_16x16x128_f8f6f4 (the product kernel of that geometry): one MFMA covers a whole
+// The 256x256 and 128x128 geometries on v_mfma_scale_f32_16x16x128_f8f6f4 (their product kernel): one MFMA covers a whole
 // 128-channel group of a 16x16 tile -- no dependent MFMA pair -- and its result is 4 VGPRs, so a second accumulator set
 // costs 8 registers instead of 16 and the next tiles' MFMAs are issued ahead of the previous tiles' de-quantisation.
 // Measured against the 32x32x64 kernel above (same contract, bit-identical output): 67.4 vs 69.7 us at 4096^3, 485 vs 501 us
 // at 8192^3; tiles in pairs (2 MFMAs in flight, then 8 multiplies + 8 FMAs) beat single tiles and quads (69.1 us each), one
 // pair of look-ahead beats two (68.7), and the mid-step priority swap of the two waves of a SIMD is worth 6 % here (71.2
-// without).
+// without).  128x128 (three workgroups per CU): 43.1 vs 44.1 us at 2048x4096x4096, 107 vs 110 us at 2048x11008x4096.
 // Wave tile: 64 features (4 blocks fb) x 128 tokens (8 blocks tb).  Lane l: MFMA row / column l % 16, k-block l / 16
 // (32 codes = 24 bytes at byte 24 * (l / 16) of the row); result: token l % 16, features 4 * (l / 16) + r.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
@@ -444,12 +444,13 @@ __device__ __forceinline__ void dequant4x(const v4f_t &acc, float sa, const v2u 
 }
 
 template <class C, class F = NoDma>
-__device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4], F dma = F(),
+__device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4], F dma = F(),
                                                  bool older = false) {
   const int l15 = lane & 15, kb = lane >> 4;
   const char *pw = slot + (wn * 64 + l15) * PITCH + kb * 24;                  // + fb*16*PITCH
-  const char *pa = slot + C::A_OFF + (wm * 128 + l15) * PITCH + kb * 24;      // + tb*16*PITCH
-  const char *psa = slot + C::A_OFF + (wm * 128 + l15) * PITCH + 96;          // + tb*16*PITCH
+  constexpr int NTB = C::WM / 16;                                             // token blocks of the wave tile
+  const char *pa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + kb * 24;    // + tb*16*PITCH
+  const char *psa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + 96;        // + tb*16*PITCH
   const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;                // + fb*32
   v8i af[4], bf[2];
   v2u sb[4];
@@ -463,7 +464,7 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
   for (int fb = 0; fb < 4; ++fb) sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
   // tiles in pairs (fb 0,1 / 2,3 of a token block): a pair's MFMAs are issued one pair ahead of its 16 VALU instructions
   // (8 multiplies, then 8 FMAs: no dependent back-to-back issue)
-  constexpr int GS = 2, NG = 32 / GS, GPB = 4 / GS, DEPTH = 1;
+  constexpr int GS = 2, NG = 4 * NTB / GS, GPB = 4 / GS, DEPTH = 1;
   v4f_t acc[DEPTH + 1][GS];
   auto mma = [&](int g) {
     const int tb = g / GPB, f0 = (g % GPB) * GS;
@@ -481,18 +482,20 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
     __builtin_amdgcn_sched_barrier(0);
     if (g % GPB == 0) {
       sa = (float)sah;
-      if (tb + 1 < 8) {
+      if (tb + 1 < NTB) {
         bf[(tb + 1) & 1] = frag24(pa + (tb + 1) * 16 * PITCH);
         sah = *reinterpret_cast<const half_t *>(psa + (tb + 1) * 16 * PITCH);
       }
       // the two waves of a SIMD swap priority mid-step (see compute_int4)
-      if (tb == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
-      if (tb == 4) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+      if constexpr (C::NW >= 8) {
+        if (tb == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+        if (tb == NTB / 2) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+      }
     }
     if (g + DEPTH < NG) mma(g + DEPTH);
     if (g % GPB == GPB - 1) {
 #pragma unroll
-      for (int i = (tb * C::GLDS + 7) / 8; i < ((tb + 1) * C::GLDS + 7) / 8; ++i) dma(i);
+      for (int i = (tb * C::GLDS + NTB - 1) / NTB; i < ((tb + 1) * C::GLDS + NTB - 1) / NTB; ++i) dma(i);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -516,12 +519,13 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
 
 // keeper half-step on v_mfma_i32_16x16x64_i8, same tile layout; each half de-quantised on its own (the contract)
 template <class C>
-__device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4]) {
+__device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4]) {
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 2) & 3;
   const char *pw = slot + (wn * 64 + l15) * 64 + ((kb ^ sw) << 4);                     // + fb*16*64
-  const char *pa = slot + (C::BN + wm * 128 + l15) * 64 + ((kb ^ sw) << 4);            // + tb*16*64
-  const char *psa = slot + C::KP_SA_OFF + (wm * 128 + l15) * 4;                        // + tb*64
+  constexpr int NTB = C::WM / 16;
+  const char *pa = slot + (C::BN + wm * C::WM + l15) * 64 + ((kb ^ sw) << 4);          // + tb*16*64
+  const char *psa = slot + C::KP_SA_OFF + (wm * C::WM + l15) * 4;                      // + tb*64
   const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;
   v4i af[4];
   v2u sb[4];
@@ -531,7 +535,7 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
     sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
   }
 #pragma unroll
-  for (int tb = 0; tb < 8; ++tb) {
+  for (int tb = 0; tb < NTB; ++tb) {
     const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + tb * 1024));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + tb * 64);
 #pragma unroll
@@ -545,10 +549,11 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6x16_kernel(GemmParams p) {
+__global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NS = C::NS;
-  static_assert(C::BM == 256 && C::BN == 256 && C::TM == 4 && NS == 3, "x16 experiment: the 256x256 geometry");
+  constexpr int NTB = C::WM / 16;
+  static_assert(C::WM % 64 == 0 && NS >= 2, "x16: wave tiles of 64 features x 64 or 128 tokens");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -567,11 +572,11 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6x16_kernel(GemmParams p)
   const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
   const int m0 = bm * C::BM, n0 = bn * C::BN;
 
-  float c[4][8][4];
+  float c[4][NTB][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < NTB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
 
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6x16_kernel(GemmParams p)
   constexpr int EP_STRIDE = 144;
   char *ep = lds + wave * (64 * EP_STRIDE);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < C::WM / 64; ++half) {
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
       const int tb = half * 4 + t4;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6x16_kernel(GemmParams p)
       const int rl = i * 8 + (lane >> 3);
       const int ch = lane & 7;
       const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
-      const int m = m0 + wm * 128 + half * 64 + rl;
+      const int m = m0 + wm * C::WM + half * 64 + rl;
       const int n = n0 + wn * 64 + ch * 8;
       if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
     }
@@ -678,8 +683,9 @@ static int launch(const GemmParams &p, hipStream_t s) {
 
 }  // namespace f6
 
-// cfg: 0 = 256x256 (8 waves, 16x16x128 MFMA micro-tiles), 3 = 128x128 (4 waves, three workgroups per CU), 2 = 64x128
-// (2 waves; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128, 10 = 256x256 on the 32x32x64 MFMA
+// cfg: 0 = 256x256 (8 waves) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA micro-tiles, 2 = 64x128
+// (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128, 10 / 13 = 256x256 /
+// 128x128 on the 32x32x64 MFMA
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
 #ifdef ATOM_F6_ABLATE
   if (cfg == 116) {   // traced run (tools/trace_f6.cpp): the stamp buffer arrives in ATOM_TRACE_PTR
@@ -701,7 +707,8 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   }
   if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
-  if (cfg == 3) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);   // 4 waves, three workgroups per CU
+  if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
+  if (cfg == 3) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);      // 4 waves, three workgroups per CU
   return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // 256x256 on the 16x16x128 MFMA
 }
 
