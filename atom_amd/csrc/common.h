@@ -69,6 +69,12 @@ int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 s
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 
+// quant_kernels.hip: packed operand (+ scales) -> F6 buffer [G][round_up(rows, 256)][104]
+int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,
+                     uint8_t *out, hipStream_t s);
+int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_t ldA, int ref_layout, uint8_t *outA,
+                          const uint8_t *B4, int64_t N, uint8_t *outB, int K4h, int G, hipStream_t s);
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? ATOM_OK : ATOM_ERR_LAUNCH; }

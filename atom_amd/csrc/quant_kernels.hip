@@ -740,36 +740,78 @@ struct RepackF6Params {
   uint8_t *out;
   int64_t N, rows_pad;
   int K4h, G;
+  const half_t *scale;     // optional: per-(row, group) scales to embed at byte 96 (activation operands); NULL for weights
+  int64_t ld;              // halves between groups of `scale`
+  int ref_layout;
 };
 
-__global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Params p) {
+// One workgroup per (group, block of 256 rows): thread t re-codes the 128 codes of row t (64 packed bytes -> 96 bytes of
+// BF6 fields + the scale) into LDS in record order; the block's 26,624 output bytes are contiguous in the group-major
+// format and leave as 16 bytes per lane.  (The first version wrote 12 bytes per thread at a 12-byte stride straight to
+// HBM: 2.5 TB/s; this one is bound by the 64-byte row pieces it reads.)
+struct RepackF6Pair { RepackF6Params op[2]; };
+
+__global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
+  const RepackF6Params &p = pp.op[blockIdx.z];
+  if ((int64_t)blockIdx.x * 256 >= p.rows_pad) return;
   typedef float v16f __attribute__((ext_vector_type(16)));
   typedef unsigned v6u __attribute__((ext_vector_type(6)));
-  typedef unsigned v3u __attribute__((ext_vector_type(3)));
-  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (row, group, j): 16 codes each
-  const int j = (int)(unit & 7);
-  const int64_t rg = unit >> 3;
-  const int g = (int)(rg % p.G);
-  const int64_t n = rg / p.G;
-  if (n >= p.rows_pad) return;
-  uint8_t *dst = p.out + ((int64_t)g * p.rows_pad + n) * 104;
-  v3u o = v3u{0u, 0u, 0u};
+  __shared__ __attribute__((aligned(16))) unsigned char rec[256 * 104];
+  const int g = blockIdx.y;
+  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  const int t = threadIdx.x;
+  const int64_t n = n0 + t;
+  unsigned *dst = reinterpret_cast<unsigned *>(rec + t * 104);
   if (n < p.N) {
-    const v2u raw = *reinterpret_cast<const v2u *>(p.B4 + n * p.K4h + g * 64 + j * 8);
-    v16f ea, eb;
+    const uint8_t *src = p.B4 + n * p.K4h + g * 64;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const unsigned byte = (raw[i >> 2] >> (8 * (i & 3))) & 0xFF;
-      ea[i] = (float)((int)(byte << 28) >> 28);                        // element 2i: low nibble, sign-extended
-      eb[i] = (float)((int)(byte << 24) >> 28);                        // element 2i+1: high nibble
-      ea[8 + i] = 0.f;
-      eb[8 + i] = 0.f;
+    for (int q = 0; q < 4; ++q) {                          // 32 codes = 16 packed bytes -> 24 bytes
+      const v4u raw = *reinterpret_cast<const v4u *>(src + 16 * q);
+      v16f ea, eb;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned byte = (raw[i >> 2] >> (8 * (i & 3))) & 0xFF;
+        ea[i] = (float)((int)(byte << 28) >> 28);          // element 2i: low nibble, sign-extended
+        eb[i] = (float)((int)(byte << 24) >> 28);          // element 2i+1: high nibble
+      }
+      const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[6 * q + k] = f[k];
     }
-    const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
-    o = v3u{f[0], f[1], f[2]};
+    unsigned sc = 0u;
+    if (p.scale)
+      sc = (unsigned)__builtin_bit_cast(unsigned short, p.scale[(int64_t)g * p.ld + (p.ref_layout ? ref_scale_index((int)n) : (int)n)]);
+    dst[24] = sc;
+    dst[25] = 0u;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 26; ++k) dst[k] = 0u;              // pad rows: zeros
   }
-  *reinterpret_cast<v3u *>(dst + 12 * j) = o;
-  if (j == 0) *reinterpret_cast<v2u *>(dst + 96) = v2u{0u, 0u};
+  __syncthreads();
+  uint8_t *out = p.out + ((int64_t)g * p.rows_pad + n0) * 104;
+  for (int i = t; i < 256 * 104 / 16; i += 256)
+    *reinterpret_cast<v4u *>(out + i * 16) = *reinterpret_cast<const v4u *>(rec + i * 16);
+}
+
+// packed operand [rows, K4/2] (+ its scales, for activations) -> F6 buffer [G][round_up(rows, 256)][104]
+int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,
+                     uint8_t *out, hipStream_t s) {
+  RepackF6Pair pp;
+  pp.op[0] = RepackF6Params{src, out, rows, (rows + 255) / 256 * 256, K4h, G, scale, ld, ref_layout};
+  pp.op[1] = pp.op[0];
+  hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(pp.op[0].rows_pad / 256), (unsigned)G, 1), dim3(256), 0, s, pp);
+  return check_launch();
+}
+
+// both operands of a GEMM in one launch: activations (with their scales) and weights
+int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_t ldA, int ref_layout, uint8_t *outA,
+                          const uint8_t *B4, int64_t N, uint8_t *outB, int K4h, int G, hipStream_t s) {
+  RepackF6Pair pp;
+  pp.op[0] = RepackF6Params{A4, outA, M, (M + 255) / 256 * 256, K4h, G, sA, ldA, ref_layout};
+  pp.op[1] = RepackF6Params{B4, outB, N, (N + 255) / 256 * 256, K4h, G, nullptr, 0, 0};
+  const int64_t rp = pp.op[0].rows_pad > pp.op[1].rows_pad ? pp.op[0].rows_pad : pp.op[1].rows_pad;
+  hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(rp / 256), (unsigned)G, 2), dim3(256), 0, s, pp);
+  return check_launch();
 }
 
 }  // namespace atom
@@ -875,12 +917,8 @@ int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6
   if (!B4 || !B_f6) return ATOM_ERR_INVALID_ARG;
   if (N < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
   if (!aligned16(B4) || !aligned16(B_f6)) return ATOM_ERR_ALIGN;
-  RepackF6Params p{(const uint8_t *)B4, (uint8_t *)B_f6, N, (int64_t)atom_f6_rows(N), (int)((K_total - kKeeper) / 2),
-                   (int)((K_total - kKeeper) / kGroup)};
-  const int64_t units = p.rows_pad * p.G * 8;
-  hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), p);
-  return check_launch();
+  return launch_repack_f6((const uint8_t *)B4, N, (int)((K_total - kKeeper) / 2), (int)((K_total - kKeeper) / kGroup), nullptr, 0,
+                          0, (uint8_t *)B_f6, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

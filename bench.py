@@ -172,15 +172,23 @@ def main():
         "wide": ([wide.data_ptr()] + ptrs[1:], L.SCALE_LAYOUT_PLAIN | L.A_WIDE,
                  "activations int8 = code*16 (ATOM_A_WIDE), weights packed INT4, INT8 MFMA"),
         "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6,
-               "both operands BF6 group-major (ATOM_AB_F6): v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, "
+               "both operands BF6 group-major (ATOM_AB_F6): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, "
                "exact integer dot products; the format the fused quantisers emit for prefill batches"),
+        "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+                      "reference packed format through atom_gemm_w4a4_f16_ws: both operands re-coded to BF6 in the caller's "
+                      "workspace (one launch), then the block-scaled-MFMA kernel; what atom_amd.ops does for packed operands"),
     }
+    ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
 
     def make_step(name):
         vp, layout, _ = variants[name]
 
         def step():
-            st = lib.atom_gemm_w4a4_f16(*vp, D.data_ptr(), M, N, K, 128, 128, layout, stream)
+            if name == "packed_ws":
+                st = lib.atom_gemm_w4a4_f16_ws(*vp, D.data_ptr(), M, N, K, 128, 128, layout, ws.data_ptr(), ws_bytes, stream)
+            else:
+                st = lib.atom_gemm_w4a4_f16(*vp, D.data_ptr(), M, N, K, 128, 128, layout, stream)
             if st != 0:
                 L.check(st, "atom_gemm_w4a4_f16")
         return step
