@@ -13,9 +13,9 @@
 //   * token blocks of 16 (up to 16) re-use the weight registers; a block's activation chunks come from L2 and are
 //     re-filled in place for the next block as soon as they have been widened;
 //   * per group and 16x16 tile: t = round_f32(idot * sA[m,g]), c = fma(t, sB[g,n], c) -- the contract of
-//     include/atom_hip.h; the partial sums of the NW waves are added in wave order through LDS (the FP32 summation ORDER
+//     include/atom_hip.h; the partial sums of the 8 waves are added in wave order through LDS (the FP32 summation ORDER
 //     therefore differs from the prefill kernels, like the decode kernel's; all are within 1 fp16 ulp of the exact value).
-// Replaces the M = 16..64 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
+// Replaces the M = 16..256 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
 // which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
 #include <cstdlib>
 #include "common.h"
@@ -253,10 +253,8 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s) {
   return per <= 8 ? skinny::launch_m<8, 8>(p, s) : skinny::launch_m<8, 14>(p, s);
 }
 
-
-// Decode path of the u4-output GEMM (k_proj / v_proj of a serving step): the same kernel with FP32 sums into the caller's
-// workspace [M, N], then the u4 epilogue as a second launch.  Same shapes as launch_gemm_skinny.
-// FP32 sums [M, N] into p.ws (no final rounding): the k / v projections of a decode step, ahead of the u4 epilogue
+// FP32 sums [M, N] into p.ws (no final rounding): the k / v projections of a decode step, ahead of the u4 epilogue.  Same
+// shapes as launch_gemm_skinny.
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
   if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0 || !p.ws) return ATOM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
@@ -266,6 +264,7 @@ int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
                   : (per <= 8 ? skinny::launch_m<8, 8, true>(p, s) : skinny::launch_m<8, 14, true>(p, s));
 }
 
+// Decode path of the u4-output GEMM: the FP32 sums into the caller's workspace, then the u4 epilogue as a second launch
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s) {
   if ((p.N % 128) != 0 || !p.D4 || !p.Dsz) return ATOM_ERR_SHAPE;
   const int st = launch_gemm_skinny_f32(p, s);
