@@ -255,6 +255,26 @@ def test_gemm_decode_batches_bit_exact_vs_c_contract(M, N, K):
     assert np.array_equal(bits16(t2n(out)), bits16(want))
 
 
+def test_gemm_decode_batches_random_shapes_bit_exact():
+    """24 seeded random decode shapes (M 2..256, N 64..1024, K 256..3712, both scale layouts) against the C restatement
+    of the kernel's summation order: every slice length 1..4 and 5..8 per wave, idle waves, ragged token blocks."""
+    from tests import c_oracle as C
+    ops = _ops()
+    g = np.random.default_rng(2024)
+    for i in range(24):
+        M = int(g.integers(2, 257))
+        N = 64 * int(g.integers(1, 17))
+        K = 128 * int(g.integers(2, 30))
+        if ops.L.lib().atom_gemm_w4a4_o4_workspace_bytes(M, (N + 127) // 128 * 128, K) == 0:
+            continue                                         # not a decode-kernel shape (the policy keeps the tile kernels)
+        layout = ("ref", "plain")[i & 1]
+        d = rand_gemm_operands(M, N, K, seed=1000 + i)
+        out = ops.dense_layer_gemm_i4_fp16(*to_device(d, layout), scale_layout=layout)
+        want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"],
+                      d["sB8"], nsplit=8)
+        assert np.array_equal(bits16(t2n(out)), bits16(want)), (M, N, K, layout)
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 512, 512), (129, 320, 384), (257, 1024, 1152), (300, 64, 1280), (8, 4096, 4096),
                                    (64, 5120, 5120), (1024, 1024, 2176), (5, 256, 640)])
 @pytest.mark.parametrize("layout", ["ref", "plain"])
