@@ -66,7 +66,7 @@ extern "C" {
 
 /*
  * Native "F6" operand format of the block-scaled-MFMA prefill kernel (gemm_w4a4_f6.hip; no reference counterpart): every
- * INT4 code is a BF6 (E3M2) number, and v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales multiplies them exactly
+ * INT4 code is a BF6 (E3M2) number, and v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4 with unit block scales multiply them exactly
  * at the FP4 rate.  OR ATOM_AB_F6 into `scale_layout` of atom_gemm_w4a4_f16: BOTH A4 and B4 are then
  *   uint8 [G][atom_f6_rows(rows)][104]   group-major; bytes 0..95 = the 128 codes of (row, group) as a little-endian
  *                                         stream of 6-bit BF6 fields, bytes 96..97 = the fp16 scale of (row, group) (A4
