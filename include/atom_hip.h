@@ -74,8 +74,8 @@ extern "C" {
  * with atom_f6_rows(rows) = rows rounded up to 256 (pad rows: any bytes).  sB / keeper operands and scales as before.
  * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
  * still written).  Weights: atom_repack_weight_f6.  Results are bit-identical to the INT8 kernels.  M, N >= 1 as usual;
- * three tile geometries (256x256, 256x128, 64x128 + split-K through atom_gemm_w4a4_f16_ws) picked by tile count; it pays
- * off for prefill-sized M (>= ~2-3k rows), below that the INT8 kernels are as fast.
+ * three tile geometries (256x256, 128x128, 64x128 + split-K through atom_gemm_w4a4_f16_ws) picked by shape; ahead of the
+ * INT8 kernels from 256 rows up (1.3-1.4x at 1-2k rows, 1.35x at 4096^3).
  */
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
