@@ -42,11 +42,12 @@ def want_wide_codes(rows: int):
     "f6"   rows >= 256: the BF6 group-major format of the block-scaled-MFMA kernels (three tile geometries, picked by
            shape; measured against the INT8 kernels over Llama projection shapes in profiles/r01_f6_dispatch.txt: ahead
            from 256 rows up, 1.3-1.4x at 1k-2k rows);
-    True   129 <= rows: pre-widened int8 codes for the INT8 MFMA tile kernels;
-    False  rows <= 128: packed nibbles, which the weight-streaming decode kernels (gemv / skinny) consume."""
+    False  rows <= 255: packed nibbles -- the decode kernels (gemv / decode-batch GEMM, up to 256 rows where the shape
+           fits) take only these, and at these sizes the INT8 tile kernels run packed and pre-widened codes equally fast.
+    (True = pre-widened int8 codes for the INT8 tile kernels is still accepted by every op; nothing here asks for it.)"""
     if rows >= 256:
         return "f6"
-    return rows >= 129
+    return False
 
 
 def is_hot_act_config(args, hidden: int) -> bool:
