@@ -229,7 +229,15 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.splits = choose_splits(M, N, K_total);
   if (p.f6_rows_a) {
     const int cfg = f6_pick_cfg(M, N, K_total);
-    if (cfg != 2) { p.ws = nullptr; p.splits = 1; }
+    if (cfg == 3) {   // 128x128: two K splits when the tiles fill a sixth of the 768 slots (512x4096x4096: 28.7 -> 26.3 us;
+                      // 768x4096x4096 and 256x11008x4096 gain nothing)
+      static const int s3 = [] { const char *e = getenv("ATOM_F6_SPLITS3"); return e ? atoi(e) : 0; }();   // tuning only
+      const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+      int sp = s3 > 0 ? s3 : (t128 <= 144 ? 2 : 1);
+      if (sp > p.splits) sp = p.splits;                      // the workspace was sized for choose_splits()
+      p.splits = sp;
+      if (sp < 2) p.ws = nullptr;
+    } else if (cfg != 2) { p.ws = nullptr; p.splits = 1; }
     return launch_gemm_f6(p, cfg, reinterpret_cast<hipStream_t>(stream));
   }
   return launch_gemm_v3(p, p.a_wide ? 25 : 5, reinterpret_cast<hipStream_t>(stream));

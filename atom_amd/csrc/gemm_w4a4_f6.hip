@@ -548,7 +548,7 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
   }
 }
 
-template <class C>
+template <class C, bool SK = false>
 __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NS = C::NS;
@@ -580,7 +580,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
 
-  const int nsteps = p.G + 2;
+  // split-K (SK): blockIdx.y owns the K steps [s_begin, nsteps) and writes FP32 partial sums to p.ws
+  const int total_steps = p.G + 2;
+  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
+  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;
   auto issue = [&](int step) {
     char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
@@ -588,10 +591,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
     else issue_keeper<C>(p, s - p.G, slot, wave, lane, m0, n0);
   };
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s);
+  for (int s = 0; s < NS - 1; ++s) issue(s_begin + s);
   const bool older = wave < C::NW / 2;
-  int step = 0;
-  for (; step + NS - 1 < p.G; ++step) {
+  int step = s_begin;
+  for (; step + NS - 1 < min(p.G, nsteps); ++step) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     char *nslot = lds + ((step + NS - 1) % NS) * C::STAGE_BYTES;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
     __builtin_amdgcn_sched_barrier(0);
     compute_int4_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, older);
   }
-  for (; step < p.G; ++step) {
+  for (; step < min(p.G, nsteps); ++step) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     issue(step + NS - 1);
@@ -618,8 +621,23 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // epilogue: per wave [64 tokens][64 features] fp16 through LDS (row stride 144 B), two halves of 64 tokens
   const int l15 = lane & 15, kb = lane >> 4;
+  if constexpr (SK) {                                     // FP32 partial tile: 4 consecutive features per lane and micro-tile
+    float *wsp = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const int m = m0 + wm * C::WM + tb * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) {
+        const int n = n0 + wn * 64 + fb * 16 + 4 * kb;
+        if (n >= p.N) continue;
+        *reinterpret_cast<v4f *>(wsp + (int64_t)m * p.N + n) = v4f{c[fb][tb][0], c[fb][tb][1], c[fb][tb][2], c[fb][tb][3]};
+      }
+    }
+    return;
+  }
+  // epilogue: per wave [64 tokens][64 features] fp16 through LDS (row stride 144 B), halves of 64 tokens
   constexpr int EP_STRIDE = 144;
   char *ep = lds + wave * (64 * EP_STRIDE);
 #pragma unroll
@@ -648,17 +666,22 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
   }
 }
 
-template <class C>
+template <class C, bool SK = false>
 static int launch_x16(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return ATOM_ERR_LAUNCH;
     attr_set = true;
   }
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C, SK>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
+                     C::LDS_BYTES, s, p);
+  if (SK) {
+    const int64_t MN = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.ws, p.D, MN, p.splits);
+  }
   return check_launch();
 }
 
@@ -708,7 +731,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
-  if (cfg == 3) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);      // 4 waves, three workgroups per CU
+  if (cfg == 3) {                                                              // 4 waves, three workgroups per CU
+    if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, true>(p, s);
+    return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
+  }
   return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // 256x256 on the 16x16x128 MFMA
 }
 
