@@ -6,10 +6,12 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
+                    [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle)
 
 The headline runs the operand format the drop-in modules use for prefill batches (F6: both operands BF6-coded, block-scaled
 MFMA); at N=1 the reference's packed-nibble format and the wide-activation format are timed beside it (same codes, same
-scales, outputs compared bit for bit) and reported under "other_operand_formats".
+scales, outputs compared bit for bit) and reported under "other_operand_formats", as is the packed format through the
+workspace entry point (operands re-coded to BF6 on the fly).
 
 N > 1: one process per GPU (torch.distributed.run), every rank runs an independent replica (the path is a
 single-device per-layer GEMM: "replicas only", no collective on the data path); value = all ranks' ops / max time.
