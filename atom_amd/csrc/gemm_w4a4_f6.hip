@@ -666,6 +666,308 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
   }
 }
 
+// ================================================================================================================
+// The 256x256 product kernel, second generation ("p" = pipelined across K steps).  Same stage layout, DMA, arithmetic
+// contract and output as gemm_w4a4_f6x16_kernel; what changed follows from tools/probes/issue_probe (profiles/r02):
+//  * MFMA and VALU share a SIMD's issue port: one 16x16x128 BF6 MFMA hides ~2 VALU instructions, every further one costs
+//    ~2.4 cycles whatever the number of waves -- the loop is bound by MFMA + VALU issue, so everything that is not one of
+//    the 8 de-quantisation instructions per micro-tile had to go: the weight scales are converted to FP32 once per step
+//    (plain v_fma_f32: v_fma_mix_f32 costs 1.5x a v_fma_f32), and the MFMA is the UNSCALED v_mfma_f32_16x16x128_f8f6f4
+//    (the scaled form with unit scales is 10 % slower: 18.5 vs 16.8 cycles back to back).
+//  * One s_barrier per K step, in the MIDDLE of the step: it publishes stage s+1 (landed since the previous step) and
+//    releases slot (s+2) % 3 for the next LDS-DMA.  Nothing happens at the step boundary any more -- the first fragments of
+//    stage s+1 are read during the tail of step s (the r01 kernel idled ~500 of 4500 cycles per step between its barrier
+//    and the first MFMA while all 8 waves hit the LDS at once).
+//  * Fragment rows are interleaved: micro-tile row i of fragment f of a 32-row block is data row 2i + (f & 1).  With the
+//    104-byte pitch the 32 ds_read_b64 of a lane group then fall into 32 distinct bank pairs (consecutive rows collide
+//    once per group: 26*15 + 0 == 26*0 + 6 (mod 64) -- SQ_LDS_BANK_CONFLICT 2.1 M per launch in r01), each fragment is
+//    three ds_read_b64 (the compiler's ds_read2_b64 runs at half the LDS rate), and a lane ends up with 8 CONSECUTIVE
+//    output features per token: the epilogue is one 16-byte global store per lane and feature-block pair, no LDS pass.
+//  * Token fragments are re-loaded as soon as the last MFMA reading the register has issued (3 pair-slots ahead of their
+//    use instead of 1); block 0 of the next step has a buffer of its own.
+// Wave tile: 64 features (4 blocks fb) x 128 tokens (8 blocks tb); lane l: micro-tile row / column l % 16, k-block l / 16.
+template <class C>
+struct PRegs {
+  v8i af[4];            // feature fragments of the current stage
+  v8i bf[3];            // token fragments: [2] block 0, [0] blocks 2,4,6, [1] odd blocks
+  float sb[4][4];       // FP32 weight scales [fb][r]
+  v4u sbp[2];           // the next stage's weight scales, packed fp16 (8 consecutive features per fb pair)
+  float sa[8];          // token scales of the current step (converted on arrival)
+  half_t sah[3];        // token scales in flight, by token-fragment buffer
+  v4f_t acc[2][2];
+  int lo[3];            // lane offset of a fragment's three 8-byte pieces; [1], [2] opaque to the compiler (see frag3)
+};
+
+// 24 bytes of a row as three ds_read_b64.  The three addresses come from three registers the compiler cannot relate to each
+// other (lo[1], lo[2] went through an empty asm), otherwise it merges two of the loads into a ds_read2_b64, which runs at
+// half the LDS rate (MI355X_MICROARCH.md, LDS table).
+template <class C>
+__device__ __forceinline__ v8i frag3(const PRegs<C> &R, const char *base, int off) {
+  const v2u a = *reinterpret_cast<const v2u *>(base + R.lo[0] + off);
+  const v2u b = *reinterpret_cast<const v2u *>(base + R.lo[1] + off);
+  const v2u c = *reinterpret_cast<const v2u *>(base + R.lo[2] + off);
+  asm volatile("" ::: "memory");   // ... and keeps it from pairing this fragment's loads with the next fragment's (same registers)
+  return v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
+}
+
+// pair slot i of a step -> token block, feature-block pair (0 = fb 0,1; 1 = fb 2,3).  Blocks 6 and 7 run A, A, B, B so that
+// the registers of fragments fb 0,1 are free two slots before the step ends.
+__device__ __forceinline__ constexpr int p_tb(int i) { return i < 12 ? i / 2 : (i == 12 || i == 14 ? 6 : 7); }
+__device__ __forceinline__ constexpr int p_h(int i) { return i < 12 ? i % 2 : (i >= 14 ? 1 : 0); }
+__device__ __forceinline__ constexpr int p_buf(int tb) { return tb == 0 ? 2 : (tb & 1); }
+__device__ __forceinline__ constexpr int p_row(int blk) { return 32 * (blk >> 1) + (blk & 1); }   // + 2 * (l % 16)
+
+template <class C>
+__device__ __forceinline__ void p_load_sb(PRegs<C> &R, const char *slot, int wn, int kb) {
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
+  R.sbp[0] = *reinterpret_cast<const v4u *>(psb);
+  R.sbp[1] = *reinterpret_cast<const v4u *>(psb + 64);
+}
+template <class C>
+__device__ __forceinline__ void p_cvt_sb(PRegs<C> &R, int h) {   // feature 8kb + 2r + (fb & 1) of pair h -> sb[2h + (fb & 1)][r]
+  const half_t *hv = reinterpret_cast<const half_t *>(&R.sbp[h]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    R.sb[2 * h][r] = (float)hv[2 * r];
+    R.sb[2 * h + 1][r] = (float)hv[2 * r + 1];
+    asm volatile("" : "+v"(R.sb[2 * h][r]), "+v"(R.sb[2 * h + 1][r]));   // opaque: else the conversion is folded back into
+  }                                                                        // v_fma_mix_f32 (1.5x the cost of v_fma_f32)
+}
+
+// One K step (an int4 group) of the pipelined kernel.  LAST: no next int4 stage to prefetch from.  `mid(i)` is called behind
+// the MFMAs of slots 8..15 with i = 0..7 (the caller issues its LDS-DMA there); `sync()` is the mid-step wait + barrier.
+// Slot 0 de-quantises the pair carried over from the previous step (all-zero registers in the first step).
+template <class C, bool LAST, class FS, class FD>
+__device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char *nslot, int wm, int wn, int lane,
+                                       float (&c)[4][8][4], FS sync, FD mid) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const char *pw = slot + wn * 64 * PITCH, *pa = slot + C::A_OFF + wm * 128 * PITCH;
+  const char *npw = nslot + wn * 64 * PITCH, *npa = nslot + C::A_OFF + wm * 128 * PITCH;
+  const char *psa = pa + l15 * (2 * PITCH) + 96, *npsa = npa + l15 * (2 * PITCH) + 96;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int tb = p_tb(i), h = p_h(i);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 8) sync();
+    if (h == 0) R.sa[tb] = (float)R.sah[p_buf(tb)];         // this block's token scale arrived with its fragment
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[p_buf(tb)], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- loads behind this slot's MFMAs, into registers whose last reader has just issued
+    if (h == 1 && i < 12 && tb + 2 < 8) {                    // token block tb + 2 (the buffer of block tb; block 0: of block 6
+      R.bf[p_buf(tb + 2)] = frag3<C>(R, pa, p_row(tb + 2) * PITCH);   // of the previous step)
+      R.sah[p_buf(tb + 2)] = *reinterpret_cast<const half_t *>(psa + p_row(tb + 2) * PITCH);
+    }
+    if constexpr (!LAST) {
+      if (i == 10) p_load_sb<C>(R, nslot, wn, kb);
+      if (i == 12) {                                         // next step's block 0 (buffer 2: free since slot 1)
+        R.bf[2] = frag3<C>(R, npa, p_row(0) * PITCH);
+        R.sah[2] = *reinterpret_cast<const half_t *>(npsa + p_row(0) * PITCH);
+      }
+      if (i == 13) {                                         // fragments fb 0,1: last read by this slot
+        R.af[0] = frag3<C>(R, npw, p_row(0) * PITCH);
+        R.af[1] = frag3<C>(R, npw, p_row(1) * PITCH);
+      }
+      if (i == 15) {
+        R.af[2] = frag3<C>(R, npw, p_row(2) * PITCH);
+        R.af[3] = frag3<C>(R, npw, p_row(3) * PITCH);
+        R.bf[1] = frag3<C>(R, npa, p_row(1) * PITCH);        // next step's block 1
+        R.sah[1] = *reinterpret_cast<const half_t *>(npsa + p_row(1) * PITCH);
+      }
+    }
+    if (i >= 8) mid(i - 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
+    {
+      const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
+      const float sa = R.sa[dtb];
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[2 * dh + k][r], c[2 * dh + k][dtb][r]);
+          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
+        }
+    }
+    // the next stage's weight scales replace a pair's FP32 copies once its last de-quantisation of this step is done:
+    // pair 0 (slot 13 = block 7) after slot 14's de-quantisation, pair 1 after the carried one in the next step's slot 0
+    if constexpr (!LAST) { if (i == 14) p_cvt_sb<C>(R, 0); }
+    if (i == 0) p_cvt_sb<C>(R, 1);
+  }
+}
+
+// the carried pair (slot 15) of the last int4 step
+template <class C>
+__device__ __forceinline__ void p_drain(PRegs<C> &R, float (&c)[4][8][4]) {
+  const float sa = R.sa[7];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[2 + k][r], c[2 + k][7][r]);
+}
+
+// keeper half-step on v_mfma_i32_16x16x64_i8 with the interleaved row mapping; each half de-quantised on its own (the contract)
+template <class C>
+__device__ __forceinline__ void p_keeper(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4]) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int sw = (l15 >> 1) & 3;                                       // swizzle key (row >> 2) & 3 of row 2 * l15 + (blk & 1)
+  const char *pw = slot + (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const char *pa = slot + (C::BN + wm * 128 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const char *psa = slot + C::KP_SA_OFF + (wm * 128 + 2 * l15) * 4;
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
+  v4i af[4];
+  v4u sbp[2];
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb) af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + p_row(fb) * 64));
+  sbp[0] = *reinterpret_cast<const v4u *>(psb);
+  sbp[1] = *reinterpret_cast<const v4u *>(psb + 64);
+#pragma unroll
+  for (int tb = 0; tb < 8; ++tb) {
+    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(tb) * 64));
+    const float sa = (float)*reinterpret_cast<const half_t *>(psa + p_row(tb) * 4);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+      __builtin_amdgcn_sched_barrier(0);
+      v4i a = {0, 0, 0, 0};
+      a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[fb], b, a, 0, 0, 0);
+      const half_t *hv = reinterpret_cast<const half_t *>(&sbp[fb >> 1]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = (float)a[r] * sa;
+        c[fb][tb][r] = __builtin_fmaf(t, (float)hv[2 * r + (fb & 1)], c[fb][tb][r]);
+        asm volatile("" : "+v"(c[fb][tb][r]));
+      }
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3, "p kernel: 256x256, 8 waves of 64 x 128");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[4][8][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
+
+  const int G = p.G;                                        // stages 0..G-1: int4 groups; G, G+1: keeper halves
+  auto slot_of = [&](int stage) { return lds + (stage % 3) * C::STAGE_BYTES; };
+  auto issue = [&](int stage) {
+    if (stage < G) issue_int4<C>(p, stage, slot_of(stage), wave, lane, m0, n0);
+    else if (stage < G + 2) issue_keeper<C>(p, stage - G, slot_of(stage), wave, lane, m0, n0);
+  };
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS) : "memory");
+  __builtin_amdgcn_s_barrier();
+  const int l15 = lane & 15, kb = lane >> 4;
+  PRegs<C> R;
+  R.lo[0] = l15 * (2 * PITCH) + kb * 24;
+  R.lo[1] = R.lo[0] + 8;
+  R.lo[2] = R.lo[0] + 16;
+  asm volatile("" : "+v"(R.lo[1]));
+  asm volatile("" : "+v"(R.lo[2]));
+  {
+    const char *slot = slot_of(0);
+    const char *pw = slot + wn * 64 * PITCH, *pa = slot + C::A_OFF + wm * 128 * PITCH;
+    const char *psa = pa + l15 * (2 * PITCH) + 96;
+    R.bf[2] = frag3<C>(R, pa, p_row(0) * PITCH);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) R.af[fb] = frag3<C>(R, pw, p_row(fb) * PITCH);
+    R.bf[1] = frag3<C>(R, pa, p_row(1) * PITCH);
+    R.bf[0] = R.bf[1];
+    R.sah[2] = *reinterpret_cast<const half_t *>(psa + p_row(0) * PITCH);
+    R.sah[1] = *reinterpret_cast<const half_t *>(psa + p_row(1) * PITCH);
+    R.sah[0] = (half_t)0;
+    p_load_sb<C>(R, slot, wn, kb);
+    p_cvt_sb<C>(R, 0);
+    p_cvt_sb<C>(R, 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) R.acc[1][k] = v4f_t{0.f, 0.f, 0.f, 0.f};   // the "carried pair" of the first step: zeros
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R.sa[t] = 0.f;
+  }
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // Steps 0 .. G-1.  The LDS-DMA of stage s + 2 goes out behind the mid-step barrier of step s: int4 stages one instruction
+  // per pair slot, the keeper halves (the last two stages) in one block.
+  {
+    int s = 0;
+    auto dma4 = [&](int i) { if (i < C::GLDS) issue_int4_piece<C>(p, s + 2, slot_of(s + 2), wave, lane, m0, n0, i); };
+    auto dmak0 = [&](int i) { if (i == 0) issue_keeper<C>(p, 0, slot_of(G), wave, lane, m0, n0); };
+    auto dmak1 = [&](int i) { if (i == 0) issue_keeper<C>(p, 1, slot_of(G + 1), wave, lane, m0, n0); };
+    for (; s + 2 < G; ++s) p_step<C, false>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dma4);
+    if (G >= 2) { p_step<C, false>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak0); ++s; }
+    p_step<C, true>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak1);
+  }
+  p_drain<C>(R, c);
+  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
+  p_keeper<C>(slot_of(G), wm, wn, lane, c);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  p_keeper<C>(slot_of(G + 1), wm, wn, lane, c);
+
+  // epilogue: a lane holds 8 consecutive features per token and feature-block pair -> one 16-byte store each
+#pragma unroll
+  for (int tb = 0; tb < 8; ++tb) {
+    const int m = m0 + wm * 128 + p_row(tb) + 2 * l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + wn * 64 + 32 * h + 8 * kb;
+      if (n >= p.N) continue;
+      v4u o;
+      half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ov[2 * r] = f2h(c[2 * h][tb][r]);
+        ov[2 * r + 1] = f2h(c[2 * h + 1][tb][r]);
+      }
+      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = o;
+    }
+  }
+}
+
+template <class C>
+static int launch_p(const GemmParams &p, hipStream_t s) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6p_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          C::LDS_BYTES) != hipSuccess)
+    return ATOM_ERR_LAUNCH;
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6p_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  return check_launch();
+}
+
 template <class C, bool SK = false>
 static int launch_x16(const GemmParams &p, hipStream_t s) {
   static bool attr_set = false;
@@ -735,6 +1037,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, true>(p, s);
     return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
   }
+  if (cfg == 30) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);          // 256x256, pipelined across K steps
   return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // 256x256 on the 16x16x128 MFMA
 }
 
