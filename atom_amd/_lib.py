@@ -22,6 +22,7 @@ QUANT_WIDE_CODES = 0x100   # ATOM_QUANT_WIDE_CODES
 A_WIDE = 0x100             # ATOM_A_WIDE
 QUANT_F6_CODES = 0x200     # ATOM_QUANT_F6_CODES
 AB_F6 = 0x200              # ATOM_AB_F6
+B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
 F6_PITCH = 104
 
 _vp = ctypes.c_void_p
@@ -50,6 +51,8 @@ SIGNATURES = {
     "atom_pack_weight_w4": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_f6_rows": (ctypes.c_size_t, [_i64]),
     "atom_repack_weight_f6": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "atom_f6_weight_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "atom_repack_weight_f6s": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "atom_kv_fake_quant_f16": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "atom_kv_append_i4": (_int, [_vp] * 10 + [_i64] + [_int] * 6 + [_vp]),
     "atom_kv_quant_append_f32": (_int, [_vp] * 7 + [_int] * 6 + [_vp]),

@@ -2,8 +2,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/atom_hip.h"
+
+// Tuning overrides.  The product library takes NO behaviour from the environment (include/atom_hip.h: "no global state"):
+// ATOM_TUNE(name, default) is the default, and the string does not even reach the binary.  The tools build (make tools,
+// -DATOM_TOOLS) reads the override from the environment variable `name` once.
+#ifdef ATOM_TOOLS
+#include <cstdlib>
+#define ATOM_TUNE(name, dflt) ([]() -> int { static const int v = [] { const char *e = getenv(name); return e ? atoi(e) : (dflt); }(); return v; }())
+#else
+#define ATOM_TUNE(name, dflt) (dflt)
+#endif
 
 namespace atom {
 
@@ -58,6 +69,7 @@ struct GemmParams {
   int a_wide;       // A4 is the wide activation format: int8 [M, K4] = code*16, even/odd de-interleaved per 32 channels
   int64_t ldA;      // halves between groups of sA
   int64_t f6_rows_a, f6_rows_b;   // F6 operand format: padded rows per group of A4 / B4 (gemm_w4a4_f6.hip)
+  const float *sB32;              // ATOM_SB_F32: weight scales float32 [G][f6_rows_b] (then sB is not read by the 256x256 kernel)
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
@@ -73,9 +85,37 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_
 int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,
                      uint8_t *out, hipStream_t s);
 int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_t ldA, int ref_layout, uint8_t *outA,
+                          const half_t *sB, float *sB32,   // weight scales fp16 [G, N] -> float32 [G][Npad] (both or neither)
                           const uint8_t *B4, int64_t N, uint8_t *outB, int K4h, int G, hipStream_t s);
 
+// LDS-DMA (global_load_lds_*: global memory -> LDS at M0 + lane * size, no VGPR round trip), issued through inline asm and
+// NOT through __builtin_amdgcn_global_load_lds: with the builtin in a loop the compiler's wait-count pass treats the DMA as a
+// pending FLAT access and emits `s_waitcnt lgkmcnt(0)` -- a full drain -- in front of EVERY later LDS-read consumer instead of
+// the counted wait, which serialises the fragment prefetch of the GEMM kernels (measured on a reduced case: lgkmcnt(2)/(1)
+// with the asm form, lgkmcnt(0) with the builtin).  The callers order the DMA themselves (s_waitcnt vmcnt + s_barrier before
+// the landed bytes are read); `lds_dst` must be wave-uniform; nothing else in these kernels uses M0.
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(const void *gsrc, const void *lds_dst) {
+  static_assert(BYTES == 16 || BYTES == 4 || BYTES == 2, "LDS-DMA piece size");
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char *)lds_dst);
+  if constexpr (BYTES == 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+  else if constexpr (BYTES == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+  else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: done once per device and kernel (`done` is a
+// per-kernel bit mask of device ids; setting the attribute twice is harmless, so a relaxed race costs one extra call).
+inline int ensure_max_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return ATOM_ERR_LAUNCH;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return ATOM_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ATOM_ERR_LAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return ATOM_OK;
+}
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? ATOM_OK : ATOM_ERR_LAUNCH; }
 

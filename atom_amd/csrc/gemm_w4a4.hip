@@ -26,19 +26,13 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
                        int keeper, int scale_layout);
 
 // largest M served by the weight-streaming decode kernel (ATOM_GEMV_MAXM overrides it for tuning)
-static int gemv_max_m() {
-  static const int v = [] { const char *e = getenv("ATOM_GEMV_MAXM"); return e ? atoi(e) : 7; }();
-  return v;
-}
+static int gemv_max_m() { return ATOM_TUNE("ATOM_GEMV_MAXM", 7); }
 
 // Decode batches go to the register-resident weight-streaming MFMA kernel (gemm_w4a4_skinny.hip) where it measures
 // faster than the tile kernels + split-K (profiles/r01_skinny.txt): always up to 16 tokens, up to 32 unless K is very
 // long, up to 128 (256 for K <= 4096) while the shape is small enough that its one-workgroup-per-16-features grid and
 // the per-workgroup re-widening of the activations are not the bottleneck.
-static int skinny_max_m() {
-  static const int v = [] { const char *e = getenv("ATOM_SKINNY_MAXM"); return e ? atoi(e) : 256; }();   // tuning only
-  return v;
-}
+static int skinny_max_m() { return ATOM_TUNE("ATOM_SKINNY_MAXM", 256); }
 static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   const int64_t items = (K_total - kKeeper) / kGroup + 1;
   if (M > skinny_max_m() || items > 8 * 14) return false;
@@ -53,7 +47,7 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
 // the tiles fill whole rounds of the 256 CUs; else 128x128 (three workgroups per CU) while that yields >= 256 tiles (>= 128
 // for short K); else 64x128, which splits K when the caller passes a workspace.
 static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
-  static const int force = [] { const char *e = getenv("ATOM_F6_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+  const int force = ATOM_TUNE("ATOM_F6_CFG", -1);
   if (force >= 0) return force;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
   if (t256 >= 256 && 5 * t256 >= 4 * ((t256 + 255) / 256) * 256) return 0;
@@ -86,10 +80,11 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
   if (!aligned16(D)) return ATOM_ERR_ALIGN;
   p.D = (half_t *)D;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  static const int variant = [] { const char *e = getenv("ATOM_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+#ifdef ATOM_TOOLS
+  const int variant = ATOM_TUNE("ATOM_GEMM_VARIANT", 0);   // tuning / ablation variants (tools build only); 0 is the product path
   if (p.a_wide && variant != 0 && !(variant >= 320 && variant <= 330)) return ATOM_ERR_INVALID_ARG;
   if (p.f6_rows_a && variant != 0) return ATOM_ERR_INVALID_ARG;
-  switch (variant) {   // tuning / ablation variants; 0 is the product path
+  switch (variant) {
     case 320: case 324: case 325: return launch_gemm_v3(p, variant - 300, hs);
     case 203: return launch_gemm_v2(p, 3, hs);
     case 204: return launch_gemm_v2(p, 4, hs);
@@ -103,7 +98,10 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
       p.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
       return launch_gemm_v3(p, variant - 300, hs);
     }
-    default:                                                        // product path
+    default: break;
+  }
+#endif
+  {
       if (p.f6_rows_a) return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);   // BF6 operands: block-scaled MFMA kernels
       if (p.a_wide) {   // activations pre-widened by the quant kernels: 256x256 tiles once they fill half the chip
         const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
@@ -138,9 +136,9 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
                        int keeper, int scale_layout) {
   if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8) return ATOM_ERR_INVALID_ARG;
   const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
-  const int f6 = (scale_layout & ATOM_AB_F6) != 0;
-  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6);
-  if (a_wide && f6) return ATOM_ERR_INVALID_ARG;
+  const int f6 = (scale_layout & ATOM_AB_F6) != 0, f6s = (scale_layout & ATOM_B_F6S) != 0;
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S);
+  if ((a_wide && f6) || (f6s && !f6)) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
   if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return ATOM_ERR_SHAPE;
@@ -161,6 +159,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.a_wide = a_wide;
   p.f6_rows_a = f6 ? (M + 255) / 256 * 256 : 0;              // == atom_f6_rows(): rows per group, padded to the tile
   p.f6_rows_b = f6 ? (N + 255) / 256 * 256 : 0;
+  p.sB32 = f6s ? reinterpret_cast<const float *>((const uint8_t *)B4 + (size_t)p.G * (size_t)p.f6_rows_b * 104) : nullptr;
   p.ldA = (int64_t)atom_scale_size(M, scale_layout);
   return ATOM_OK;
 }
@@ -171,7 +170,7 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
   if (M <= gemv_max_m() || skinny_fits(M, N, K_total)) return 1;   // decode kernels
   const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
-  static const int force = [] { const char *e = getenv("ATOM_SPLITS"); return e ? atoi(e) : 0; }();   // tuning only
+  const int force = ATOM_TUNE("ATOM_SPLITS", 0);
   if (force > 0) return force > nsteps / 2 ? (int)(nsteps / 2) : force;
   if (tiles >= 512 || nsteps < 8) return 1;
   int64_t s = 1024 / tiles;                                // measured (profiles/r01_gemm_sweeps.txt): 512x4096x4096 1 -> 4
@@ -185,7 +184,7 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
 // the block-scaled-MFMA kernels -- 80 instead of 88 us at 4096^3, bit-identical.  From 2048 rows (1024x4096x4096: 47 vs 43 us
 // once the re-coding is paid).
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
-  static const int off = [] { const char *e = getenv("ATOM_NO_F6_ROUTE"); return e ? atoi(e) : 0; }();   // tuning only
+  const int off = ATOM_TUNE("ATOM_NO_F6_ROUTE", 0);
   return !off && M >= 2048 && N >= 2048 && K_total >= 1024;
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
@@ -194,7 +193,7 @@ static size_t f6_bytes(int64_t rows, int64_t K_total) {
 
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
-  if (f6_route(M, N, K_total)) return f6_bytes(M, K_total) + f6_bytes(N, K_total);
+  if (f6_route(M, N, K_total)) return f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;   // B: + float32 scales
   const int s = choose_splits(M, N, K_total);
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -214,11 +213,13 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   if (!p.a_wide && !p.f6_rows_a && f6_route(M, N, K_total)) {        // packed operands -> F6 copies in the workspace
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     uint8_t *a6 = (uint8_t *)workspace, *b6 = a6 + f6_bytes(M, K_total);
-    const int r = launch_repack_f6_pair(p.A4, M, p.sA, p.ldA, p.ref_layout, a6, p.B4, N, b6, p.K4h, p.G, hs);
+    float *sb32 = reinterpret_cast<float *>(b6 + f6_bytes(N, K_total));
+    const int r = launch_repack_f6_pair(p.A4, M, p.sA, p.ldA, p.ref_layout, a6, p.sB, sb32, p.B4, N, b6, p.K4h, p.G, hs);
     if (r != ATOM_OK) return r;
     p.A4 = a6; p.B4 = b6;
     p.f6_rows_a = (M + 255) / 256 * 256;
     p.f6_rows_b = (N + 255) / 256 * 256;
+    p.sB32 = sb32;
     return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);
   }
   if (p.a_wide || p.f6_rows_a) {                                      // native formats: no workspace route for these sizes
@@ -231,7 +232,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
     const int cfg = f6_pick_cfg(M, N, K_total);
     if (cfg == 3) {   // 128x128: two K splits when the tiles fill a sixth of the 768 slots (512x4096x4096: 28.7 -> 26.3 us;
                       // 768x4096x4096 and 256x11008x4096 gain nothing)
-      static const int s3 = [] { const char *e = getenv("ATOM_F6_SPLITS3"); return e ? atoi(e) : 0; }();   // tuning only
+      const int s3 = ATOM_TUNE("ATOM_F6_SPLITS3", 0);
       const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
       int sp = s3 > 0 ? s3 : (t128 <= 144 ? 2 : 1);
       if (sp > p.splits) sp = p.splits;                      // the workspace was sized for choose_splits()

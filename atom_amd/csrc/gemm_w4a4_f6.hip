@@ -17,7 +17,7 @@
 // fp16 array.  The INT8 keeper runs as the two 64-column half-steps of the INT8 kernel in the same stage buffer.
 // Arithmetic is the same contract: t = round_f32(idot * sA), c = fma(t, sB, c) per group in order, keeper last --
 // results are bit-identical to the INT8 kernels.
-#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace atom {
@@ -73,17 +73,17 @@ __device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, cha
   j = j < C::NPIECE ? j : j - C::NSB;                      // padding repeats a scale piece (same bytes, same place)
   if (i * C::NDW + C::NDW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {              // compile time: whole data blocks only
     const uint8_t *base = (i * C::NDW + C::NDW <= C::NBW || j < C::NBW) ? wsrc : asrc;
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+    lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
   } else if (j < C::NBW + C::NBA) {
     const uint8_t *base = j < C::NBW ? wsrc : asrc;
     // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
     if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + j * 1024 + lane * 16), (lptr_t)(slot + j * 1024), 16, 0, 0);
+      lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
   } else {                                                 // 128 weight scales per piece, a dword (2 channels) per lane
     const int part = j - (C::NBW + C::NBA);
     const half_t *sBb = p.sB + (int64_t)g * p.N;
     const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-    __builtin_amdgcn_global_load_lds((gptr_t)(sBb + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
+    lds_dma<4>(sBb + n, slot + C::SB_OFF + part * 256);
   }
 }
 
@@ -107,16 +107,16 @@ __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char
       const int row = j * 16 + (lane >> 2);
       const unsigned idx = (unsigned)(j < C::BN / 16 ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
       const uint8_t *base = (j < C::BN / 16 ? p.B8 : p.A8) + half * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + idx * kKeeper + kj), (lptr_t)(slot + j * 1024), 16, 0, 0);
+      lds_dma<16>(base + idx * kKeeper + kj, slot + j * 1024);
     } else if (j < ND + NSA) {                             // sA8 of 64 tokens: one fp16 per lane -> zero-extended dword
       const int pc = j - ND;
       const int idx = min(m0 + pc * 64 + lane, p.M - 1);
       const unsigned ksa = (unsigned)(p.ref_layout ? ref_scale_index(idx) : idx);
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.sA8 + ksa), (lptr_t)(slot + C::KP_SA_OFF + pc * 256), 2, 0, 0);
+      lds_dma<2>(p.sA8 + ksa, slot + C::KP_SA_OFF + pc * 256);
     } else {
       const int part = j - ND - NSA;
       const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.sB8 + n), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
+      lds_dma<4>(p.sB8 + n, slot + C::SB_OFF + part * 256);
     }
   }
 }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void dequant16(float (&acc)[16], float sa, const char
 }
 
 // one int4 group out of LDS: 2 BF6 MFMAs per 32x32 tile
-// ABL (tools only, -DATOM_F6_ABLATE): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment refills, 16 = s_memtime
+// ABL (tools only, -DATOM_TOOLS): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment refills, 16 = s_memtime
 // stamps, 32 = no priority swap
 struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 
@@ -710,6 +710,16 @@ __device__ __forceinline__ v8i frag3(const PRegs<C> &R, const char *base, int of
   return v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
 }
 
+template <class C>
+__device__ __forceinline__ v8i frag3_untracked(const PRegs<C> &R, const char *base, int off) {   // tools only (ABL & 256)
+  v2u a, b, c;
+  const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(base + R.lo[0] + off);
+  const unsigned a1 = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(base + R.lo[1] + off);
+  const unsigned a2 = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(base + R.lo[2] + off);
+  asm volatile("s_waitcnt lgkmcnt(8)\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5" : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(a0), "v"(a1), "v"(a2));
+  return v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
+}
+
 // pair slot i of a step -> token block, feature-block pair (0 = fb 0,1; 1 = fb 2,3).  Blocks 6 and 7 run A, A, B, B so that
 // the registers of fragments fb 0,1 are free two slots before the step ends.
 __device__ __forceinline__ constexpr int p_tb(int i) { return i < 12 ? i / 2 : (i == 12 || i == 14 ? 6 : 7); }
@@ -737,50 +747,78 @@ __device__ __forceinline__ void p_cvt_sb(PRegs<C> &R, int h) {   // feature 8kb 
 // One K step (an int4 group) of the pipelined kernel.  LAST: no next int4 stage to prefetch from.  `mid(i)` is called behind
 // the MFMAs of slots 8..15 with i = 0..7 (the caller issues its LDS-DMA there); `sync()` is the mid-step wait + barrier.
 // Slot 0 de-quantises the pair carried over from the previous step (all-zero registers in the first step).
-template <class C, bool LAST, class FS, class FD>
+// ABL (tools build only): 1 = no LDS-DMA after the prologue, 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment / scale
+// re-loads, 16 = s_memtime stamps through `stamp(k)`, 64 = no output stores, 128 = no keeper steps
+template <class C, bool LAST, int ABL, class FS, class FD, class FT>
 __device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char *nslot, int wm, int wn, int lane,
-                                       float (&c)[4][8][4], FS sync, FD mid) {
+                                       float (&c)[4][8][4], FS sync, FD mid, FT stamp) {
   const int l15 = lane & 15, kb = lane >> 4;
+  const bool older = wm == 0;                               // waves 0-3 (the first wave of each SIMD)
   const char *pw = slot + wn * 64 * PITCH, *pa = slot + C::A_OFF + wm * 128 * PITCH;
   const char *npw = nslot + wn * 64 * PITCH, *npa = nslot + C::A_OFF + wm * 128 * PITCH;
   const char *psa = pa + l15 * (2 * PITCH) + 96, *npsa = npa + l15 * (2 * PITCH) + 96;
+  // ABL & 256 (tools): the same LDS reads into the same registers, but issued through inline asm the compiler does not track, so
+  // nothing ever waits for them (a guard keeps <= 12 in flight): prices the s_waitcnt stalls of the fragment prefetch.  Results
+  // are garbage.
+#define ATOM_P_LOADF(dst, base, off) { if constexpr ((ABL & 256) != 0) dst = frag3_untracked<C>(R, base, off); else dst = frag3<C>(R, base, off); }
+#define ATOM_P_LOADH(dst, ptr) { if constexpr ((ABL & 256) != 0) { unsigned t_; asm volatile("ds_read_u16 %0, %1" : "=v"(t_) : "v"((unsigned)(size_t)(const __attribute__((address_space(3))) char *)(ptr))); dst = __builtin_bit_cast(half_t, (unsigned short)t_); } else dst = *reinterpret_cast<const half_t *>(ptr); }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int tb = p_tb(i), h = p_h(i);
     __builtin_amdgcn_sched_barrier(0);
-    if (i == 8) sync();
+    if constexpr ((ABL & 16) != 0) { if (i == 0) stamp(0); if (i == 4) stamp(1); if (i == 12) stamp(4); }
+    if (i == 8) {
+      if constexpr ((ABL & 16) != 0) stamp(2);
+      sync();
+      if constexpr ((ABL & 16) != 0) stamp(3);
+    }
     if (h == 0) R.sa[tb] = (float)R.sah[p_buf(tb)];         // this block's token scale arrived with its fragment
+    if constexpr ((ABL & 2048) != 0) {                      // tools: the two waves of a SIMD swap priority mid-step (as in the x16 kernel)
+      if (i == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+      if (i == 8) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+    }
+    if constexpr ((ABL & 4096) != 0) {                      // tools: ... the other way round
+      if (i == 0) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+      if (i == 8) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[p_buf(tb)], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+    for (int k = 0; k < 2; ++k) {
+      if constexpr (!(ABL & 4))
+        R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[p_buf(tb)], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+      else { R.acc[i & 1][k] = v4f_t{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(R.acc[i & 1][k]) : "v"(R.af[2 * h + k]), "v"(R.bf[p_buf(tb)])); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- loads behind this slot's MFMAs, into registers whose last reader has just issued
-    if (h == 1 && i < 12 && tb + 2 < 8) {                    // token block tb + 2 (the buffer of block tb; block 0: of block 6
-      R.bf[p_buf(tb + 2)] = frag3<C>(R, pa, p_row(tb + 2) * PITCH);   // of the previous step)
-      R.sah[p_buf(tb + 2)] = *reinterpret_cast<const half_t *>(psa + p_row(tb + 2) * PITCH);
+    if (!(ABL & 8) && h == 1 && i < 12 && tb + 2 < 8) {      // token block tb + 2 (the buffer of block tb; block 0: of block 6
+      ATOM_P_LOADF(R.bf[p_buf(tb + 2)], pa, p_row(tb + 2) * PITCH)   // of the previous step)
+      ATOM_P_LOADH(R.sah[p_buf(tb + 2)], psa + p_row(tb + 2) * PITCH)
     }
-    if constexpr (!LAST) {
+    if constexpr (!LAST && !(ABL & 8)) {
       if (i == 10) p_load_sb<C>(R, nslot, wn, kb);
       if (i == 12) {                                         // next step's block 0 (buffer 2: free since slot 1)
-        R.bf[2] = frag3<C>(R, npa, p_row(0) * PITCH);
-        R.sah[2] = *reinterpret_cast<const half_t *>(npsa + p_row(0) * PITCH);
+        ATOM_P_LOADF(R.bf[2], npa, p_row(0) * PITCH)
+        ATOM_P_LOADH(R.sah[2], npsa + p_row(0) * PITCH)
       }
       if (i == 13) {                                         // fragments fb 0,1: last read by this slot
-        R.af[0] = frag3<C>(R, npw, p_row(0) * PITCH);
-        R.af[1] = frag3<C>(R, npw, p_row(1) * PITCH);
+        ATOM_P_LOADF(R.af[0], npw, p_row(0) * PITCH)
+        ATOM_P_LOADF(R.af[1], npw, p_row(1) * PITCH)
       }
       if (i == 15) {
-        R.af[2] = frag3<C>(R, npw, p_row(2) * PITCH);
-        R.af[3] = frag3<C>(R, npw, p_row(3) * PITCH);
-        R.bf[1] = frag3<C>(R, npa, p_row(1) * PITCH);        // next step's block 1
-        R.sah[1] = *reinterpret_cast<const half_t *>(npsa + p_row(1) * PITCH);
+        ATOM_P_LOADF(R.af[2], npw, p_row(2) * PITCH)
+        ATOM_P_LOADF(R.af[3], npw, p_row(3) * PITCH)
+        ATOM_P_LOADF(R.bf[1], npa, p_row(1) * PITCH)        // next step's block 1
+        ATOM_P_LOADH(R.sah[1], npsa + p_row(1) * PITCH)
       }
     }
-    if (i >= 8) mid(i - 8);
+    if (i >= 8 && !(ABL & 1)) mid(i - 8);
     __builtin_amdgcn_sched_barrier(0);
     // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
-    {
+    if constexpr ((ABL & 2) != 0) {
+      const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
+      c[2 * dh][dtb][0] += R.acc[j & 1][0][0] + R.acc[j & 1][1][3];
+      asm volatile("" : "+v"(c[2 * dh][dtb][0]) : "v"(R.acc[j & 1][0]), "v"(R.acc[j & 1][1]));
+    } else {
       const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
       const float sa = R.sa[dtb];
       float t[8];
@@ -801,6 +839,9 @@ __device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char
     if constexpr (!LAST) { if (i == 14) p_cvt_sb<C>(R, 0); }
     if (i == 0) p_cvt_sb<C>(R, 1);
   }
+  if constexpr ((ABL & 16) != 0) stamp(5);
+#undef ATOM_P_LOADF
+#undef ATOM_P_LOADH
 }
 
 // the carried pair (slot 15) of the last int4 step
@@ -848,9 +889,30 @@ __device__ __forceinline__ void p_keeper(const char *slot, int wm, int wn, int l
   }
 }
 
-template <class C>
+template <class C, int ABL = 0>
 __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // tools build, ABL & 16: 80 dwords of s_memtime stamps per wave of workgroup 0, kept in the 2,560 bytes of LDS behind the
+  // three stages and copied to p.Dsz (u32 [8][80]) at the end.  [0..9] kernel phases, [10 + 6 j + k] stamp k of the j-th traced
+  // step, [78], [79] s_memrealtime (100 MHz) at entry and exit
+  unsigned *trl = nullptr;
+  bool tr_on = false;
+  int tr_i = 10;
+  auto kstamp = [&](int k) {
+    if constexpr ((ABL & 16) != 0) {
+      if (blockIdx.x == 0) { const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) trl[k] = t; }
+    }
+  };
+  auto stamp = [&](int k) {
+    if constexpr ((ABL & 16) != 0) {
+      if (tr_on) { const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) trl[tr_i + k] = t; }
+    }
+  };
+  if constexpr ((ABL & 16) != 0) {
+    trl = reinterpret_cast<unsigned *>(lds + 3 * C::STAGE_BYTES) + (threadIdx.x >> 6) * 80;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) trl[78] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    kstamp(0);
+  }
   static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3, "p kernel: 256x256, 8 waves of 64 x 128");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -886,8 +948,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
   };
   issue(0);
   issue(1);
+  kstamp(1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS) : "memory");
   __builtin_amdgcn_s_barrier();
+  kstamp(2);
   const int l15 = lane & 15, kb = lane >> 4;
   PRegs<C> R;
   R.lo[0] = l15 * (2 * PITCH) + kb * 24;
@@ -917,7 +981,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
   }
   auto sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(ABL & 512)) __builtin_amdgcn_s_barrier();   // (512, tools: timing without the barrier -- results are garbage)
   };
   // Steps 0 .. G-1.  The LDS-DMA of stage s + 2 goes out behind the mid-step barrier of step s: int4 stages one instruction
   // per pair slot, the keeper halves (the last two stages) in one block.
@@ -926,11 +990,345 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
     auto dma4 = [&](int i) { if (i < C::GLDS) issue_int4_piece<C>(p, s + 2, slot_of(s + 2), wave, lane, m0, n0, i); };
     auto dmak0 = [&](int i) { if (i == 0) issue_keeper<C>(p, 0, slot_of(G), wave, lane, m0, n0); };
     auto dmak1 = [&](int i) { if (i == 0) issue_keeper<C>(p, 1, slot_of(G + 1), wave, lane, m0, n0); };
-    for (; s + 2 < G; ++s) p_step<C, false>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dma4);
-    if (G >= 2) { p_step<C, false>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak0); ++s; }
-    p_step<C, true>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak1);
+    // (traced steps, tools build: 0, 1, 2, two in the middle, the last three)
+    auto tr_sel = [&]() {
+      if constexpr ((ABL & 16) != 0) {
+        if (tr_on) tr_i += 6;
+        tr_on = blockIdx.x == 0 && tr_i + 6 <= 78 && (s < 3 || s == G / 2 || s == G / 2 + 1 || s + 3 >= G);
+      }
+    };
+    kstamp(3);
+    if constexpr ((ABL & 1024) != 0) {   // tools: fixed stage slots (what an unrolled-by-3 loop's addressing would cost); results are garbage
+      auto dma4f = [&](int i) { if (i < C::GLDS) issue_int4_piece<C>(p, s + 2, lds + 2 * C::STAGE_BYTES, wave, lane, m0, n0, i); };
+      for (; s + 2 < G; ++s) p_step<C, false, ABL>(R, lds, lds + C::STAGE_BYTES, wm, wn, lane, c, sync, dma4f, stamp);
+    }
+    for (; s + 2 < G; ++s) { tr_sel(); p_step<C, false, ABL>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dma4, stamp); }
+    if (G >= 2) { tr_sel(); p_step<C, false, ABL>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak0, stamp); ++s; }
+    tr_sel();
+    p_step<C, true, ABL>(R, slot_of(s), slot_of(s + 1), wm, wn, lane, c, sync, dmak1, stamp);
   }
+  kstamp(4);
   p_drain<C>(R, c);
+  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
+  if constexpr (!(ABL & 128)) p_keeper<C>(slot_of(G), wm, wn, lane, c);
+  kstamp(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  kstamp(6);
+  if constexpr (!(ABL & 128)) p_keeper<C>(slot_of(G + 1), wm, wn, lane, c);
+  kstamp(7);
+
+  // epilogue: a lane holds 8 consecutive features per token and feature-block pair -> one 16-byte store each
+#pragma unroll
+  for (int tb = 0; tb < 8; ++tb) {
+    const int m = m0 + wm * 128 + p_row(tb) + 2 * l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + wn * 64 + 32 * h + 8 * kb;
+      if (n >= p.N) continue;
+      v4u o;
+      half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ov[2 * r] = f2h(c[2 * h][tb][r]);
+        ov[2 * r + 1] = f2h(c[2 * h + 1][tb][r]);
+      }
+      if constexpr ((ABL & 64) != 0) { if (o.x != 0x12345678u) continue; }
+      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = o;
+    }
+  }
+  if constexpr ((ABL & 16) != 0) {
+    kstamp(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    kstamp(9);
+    if (blockIdx.x == 0) {
+      if (lane == 0) trl[79] = (unsigned)__builtin_amdgcn_s_memrealtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = lane; i < 80; i += 64) reinterpret_cast<unsigned *>(p.Dsz)[wave * 80 + i] = trl[i];
+    }
+  }
+}
+
+// ================================================================================================================
+// The 256x256 kernel, third generation ("q").  Same tiles, MFMA / de-quantisation stream, arithmetic contract and output as the
+// pipelined kernel above; what changed is everything ELSE a K step issues (profiles/r02: on a gfx950 SIMD every instruction's
+// pipe time adds up -- MFMA 16 cycles, VALU 2, LDS / DMA / SALU their issue slots -- so the ~190 instructions per wave and step
+// that were neither MFMA nor de-quantisation cost ~40 % of the loop):
+//  * the K loop is unrolled by 3 = the number of LDS stages, so every stage slot is a compile-time constant: LDS addresses are
+//    lane registers set up once + instruction offsets (one register set for slots 0/1, a second one, + 2 stages, for slot 2:
+//    ds_read offsets are 16 bits), no `step % 3` arithmetic, no per-load v_add;
+//  * token scales are read as the fp32 copy the F6 format carries at byte 100 of a row (no v_cvt), weight scales arrive as
+//    fp32 (ATOM_B_F6S: one 1 KiB LDS-DMA piece per stage) and are loaded with ds_read_b128 straight into the registers the
+//    de-quantisation FMAs read, at the point where their previous contents die (no packed staging copy, no v_cvt);
+//  * LDS-DMA: a wave owns CONSECUTIVE 1 KiB pieces (3 weight + 3 activation, waves 0-4 one more), addressed as SGPR base + one
+//    loop-invariant lane offset + instruction offset 0 / 1024 / 2048 -- the offset moves the LDS destination too
+//    (tools/probes/dma_offset_probe.cpp) -- so a step computes no DMA address in VALU at all.
+template <class C>
+struct QC {
+  static constexpr int SB_OFF = C::SB_OFF;                  // 256 float32 weight scales (keeper steps: C's fp16 layout)
+  static constexpr int STAGE = C::SB_OFF + 1024;
+  static constexpr int LDS_BYTES = 3 * STAGE;
+  static_assert(LDS_BYTES <= 160 * 1024 && STAGE + (32 * 3 + 1) * PITCH + 100 < 65536, "q kernel: stage layout / ds offsets");
+};
+
+template <class C>
+struct QRegs {
+  v8i af[4];            // feature fragments of the current stage
+  v8i bf[3];            // token fragments: [2] block 0, [0] blocks 2,4,6, [1] odd blocks
+  float sb[2][8];       // weight scales of feature-block pair h: [h][2 r + (fb & 1)]
+  float sa[4];          // token scales, ring by token block % 4
+  v4f_t acc[2][2];
+  // lane byte addresses in LDS, [set][piece]: set 0 serves stage slots 0 and 1 (+ instruction offset), set 1 = + 2 stages for
+  // slot 2.  All opaque to the compiler: it would otherwise re-derive one from another with a v_add per use, or merge two 8-byte
+  // loads of a fragment into a ds_read2_b64 (half the LDS rate).
+  int aW[2][3], aA[2][3], aS[2], aB[2];
+};
+
+// SL = 0..2: compile-time stage slot; SL < 0: the slot's byte offset arrives at run time in `ro` (the two keeper-prefetch steps
+// at the end of the K loop, executed once: one code body each instead of one per slot)
+template <int SL> __device__ __forceinline__ constexpr int q_set() { return SL == 2 ? 1 : 0; }
+template <class C, int SL> __device__ __forceinline__ constexpr int q_imm() { return SL == 1 ? QC<C>::STAGE : 0; }
+
+template <class C, int SL>
+__device__ __forceinline__ v8i q_frag(const char *lds, const int (&a)[2][3], int off, int ro) {
+  const char *b = lds + (SL < 0 ? ro : q_imm<C, SL>()) + off;
+  const v2u x = *reinterpret_cast<const v2u *>(b + a[q_set<SL>()][0]);
+  const v2u y = *reinterpret_cast<const v2u *>(b + a[q_set<SL>()][1]);
+  const v2u z = *reinterpret_cast<const v2u *>(b + a[q_set<SL>()][2]);
+  asm volatile("" ::: "memory");   // keeps the compiler from pairing this fragment's loads with the next fragment's
+  return v8i{(int)x.x, (int)x.y, (int)y.x, (int)y.y, (int)z.x, (int)z.y, 0, 0};
+}
+template <class C, int SL>
+__device__ __forceinline__ float q_scale(const char *lds, const QRegs<C> &R, int off, int ro) {
+  return *reinterpret_cast<const float *>(lds + (SL < 0 ? ro : q_imm<C, SL>()) + off + R.aS[q_set<SL>()]);
+}
+template <class C, int SL>
+__device__ __forceinline__ void q_load_sb(const char *lds, QRegs<C> &R, int h, int ro) {   // 8 consecutive features of pair h
+  const char *b = lds + (SL < 0 ? ro : q_imm<C, SL>()) + QC<C>::SB_OFF + 128 * h + R.aB[q_set<SL>()];
+  const v4f_t lo = *reinterpret_cast<const v4f_t *>(b), hi = *reinterpret_cast<const v4f_t *>(b + 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { R.sb[h][k] = lo[k]; R.sb[h][4 + k] = hi[k]; }
+}
+
+// LDS-DMA piece through SGPR base + lane offset + instruction offset (which also moves the LDS destination)
+template <int OFF>
+__device__ __forceinline__ void q_dma16(unsigned m0v, unsigned voff, const void *sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+struct QDma {            // per wave, loop invariant
+  unsigned voffW, voffA, voffX;   // lane offsets (bytes) from the stage's weight / activation / extra base
+  int m0W, m0A, m0X;              // LDS offsets of the wave's first piece inside a stage
+  int xkind;                      // extra piece: 0 none, 1 weight rows, 2 activation rows, 3 weight scales
+};
+// piece i (0..6) of this wave for the stage whose global bases are wsrc / asrc / sbsrc, into stage slot DS
+template <class C, int DS>
+__device__ __forceinline__ void q_piece(const QDma &d, const uint8_t *wsrc, const uint8_t *asrc, const float *sbsrc, int i) {
+  constexpr int base = DS * QC<C>::STAGE;
+  if (i == 0) q_dma16<0>(base + d.m0W, d.voffW, wsrc);
+  else if (i == 1) q_dma16<1024>(base + d.m0W, d.voffW, wsrc);
+  else if (i == 2) q_dma16<2048>(base + d.m0W, d.voffW, wsrc);
+  else if (i == 3) q_dma16<0>(base + d.m0A, d.voffA, asrc);
+  else if (i == 4) q_dma16<1024>(base + d.m0A, d.voffA, asrc);
+  else if (i == 5) q_dma16<2048>(base + d.m0A, d.voffA, asrc);
+  else if (i == 6 && d.xkind) {
+    const void *xb = d.xkind == 1 ? (const void *)wsrc : (d.xkind == 2 ? (const void *)asrc : (const void *)sbsrc);
+    q_dma16<0>(base + d.m0X, d.voffX, xb);
+  }
+}
+
+// One K step on stage slot SL (next stage in slot (SL + 1) % 3; SL < 0: slots at byte offsets ro / rn).  `mid(i)`, i = 0..7:
+// behind the MFMAs of slots 8..15.
+template <class C, int SL, class FS, class FD>
+__device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[4][8][4], FS sync, FD mid, int ro = 0, int rn = 0,
+                                       bool LAST = false) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
+  constexpr int NX = SL < 0 ? -1 : (SL + 1) % 3;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int tb = p_tb(i), h = p_h(i);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 8) sync();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[p_buf(tb)], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- loads behind this slot's MFMAs, into registers whose last reader has just issued
+    if (h == 1 && i < 12 && tb + 2 < 8) {
+      R.bf[p_buf(tb + 2)] = q_frag<C, SL>(lds, R.aA, p_row(tb + 2) * PITCH, ro);
+      R.sa[(tb + 2) & 3] = q_scale<C, SL>(lds, R, p_row(tb + 2) * PITCH, ro);
+    }
+    if (!LAST) {
+      if (i == 12) {                                         // next step's block 0 (buffer 2: free since slot 1)
+        R.bf[2] = q_frag<C, NX>(lds, R.aA, p_row(0) * PITCH, rn);
+        R.sa[0] = q_scale<C, NX>(lds, R, p_row(0) * PITCH, rn);
+      }
+      if (i == 13) {                                         // fragments fb 0,1: last read by this slot
+        R.af[0] = q_frag<C, NX>(lds, R.aW, p_row(0) * PITCH, rn);
+        R.af[1] = q_frag<C, NX>(lds, R.aW, p_row(1) * PITCH, rn);
+      }
+      if (i == 15) {
+        R.af[2] = q_frag<C, NX>(lds, R.aW, p_row(2) * PITCH, rn);
+        R.af[3] = q_frag<C, NX>(lds, R.aW, p_row(3) * PITCH, rn);
+        R.bf[1] = q_frag<C, NX>(lds, R.aA, p_row(1) * PITCH, rn);        // next step's block 1
+        R.sa[1] = q_scale<C, NX>(lds, R, p_row(1) * PITCH, rn);
+      }
+    }
+    if (i >= 8) mid(i - 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
+    {
+      const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
+      const float sa = R.sa[dtb & 3];
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[dh][2 * r + k], c[2 * dh + k][dtb][r]);
+          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
+        }
+    }
+    // weight scales: pair 0's registers die with slot 13's de-quantisation (done in slot 14) and take the next stage's values;
+    // pair 1's die with the carried pair (slot 15, done in the next step's slot 0) and take the current stage's
+    __builtin_amdgcn_sched_barrier(0);
+    if (!LAST && i == 14) q_load_sb<C, NX>(lds, R, 0, rn);
+    if (i == 0) q_load_sb<C, SL>(lds, R, 1, ro);
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3 && C::NW == 8, "q kernel: 256x256, 8 waves of 64 x 128");
+  using Q = QC<C>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[4][8][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
+
+  const int G = p.G;                                        // stages 0..G-1: int4 groups; G, G+1: keeper halves
+  // ---- LDS-DMA: consecutive pieces per wave.  Weight rows: pieces 3w..3w+2 (+ 24, 25 on waves 0, 1), activation rows the same
+  // (+ 24, 25 on waves 2, 3), the stage's 256 float32 weight scales on wave 4
+  QDma d;
+  d.voffW = d.voffA = (unsigned)(wave * 3072 + lane * 16);
+  d.m0W = wave * 3072;
+  d.m0A = C::A_OFF + wave * 3072;
+  d.xkind = wave < 2 ? 1 : (wave < 4 ? 2 : (wave == 4 ? 3 : 0));
+  d.voffX = (unsigned)((wave < 4 ? (24 + (wave & 1)) * 1024 : 0) + lane * 16);
+  d.m0X = wave < 2 ? (24 + wave) * 1024 : (wave < 4 ? C::A_OFF + (24 + (wave & 1)) * 1024 : Q::SB_OFF);
+  const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
+  const uint8_t *wsrc0 = p.B4 + (int64_t)n0 * PITCH, *asrc0 = p.A4 + (int64_t)m0 * PITCH;
+  const float *sbsrc0 = p.sB32 + n0;
+  auto slot_of = [&](int stage) { return lds + (stage % 3) * Q::STAGE; };
+  auto issue_all = [&](auto ds, int g) {                    // every piece of int4 stage g into slot decltype(ds)::value
+    constexpr int DS = decltype(ds)::value;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) q_piece<C, DS>(d, wsrc0 + g * wstep, asrc0 + g * astep, sbsrc0 + (int64_t)g * p.f6_rows_b, i);
+  };
+  issue_all(std::integral_constant<int, 0>(), 0);
+  if (G >= 2) issue_all(std::integral_constant<int, 1>(), 1);
+  else issue_keeper<C>(p, 0, slot_of(1), wave, lane, m0, n0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int l15 = lane & 15, kb = lane >> 4;
+  QRegs<C> R;
+  {
+    const int lw = wn * 64 * PITCH + l15 * (2 * PITCH) + kb * 24;
+    const int la = C::A_OFF + wm * 128 * PITCH + l15 * (2 * PITCH);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        R.aW[st][k] = lw + 8 * k + st * 2 * Q::STAGE;
+        R.aA[st][k] = la + kb * 24 + 8 * k + st * 2 * Q::STAGE;
+        asm volatile("" : "+v"(R.aW[st][k]), "+v"(R.aA[st][k]));
+      }
+      R.aS[st] = la + 100 + st * 2 * Q::STAGE;
+      R.aB[st] = (wn * 64 + 8 * kb) * 4 + st * 2 * Q::STAGE;
+      asm volatile("" : "+v"(R.aS[st]), "+v"(R.aB[st]));
+    }
+    R.bf[2] = q_frag<C, 0>(lds, R.aA, p_row(0) * PITCH, 0);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) R.af[fb] = q_frag<C, 0>(lds, R.aW, p_row(fb) * PITCH, 0);
+    R.bf[1] = q_frag<C, 0>(lds, R.aA, p_row(1) * PITCH, 0);
+    R.bf[0] = R.bf[1];
+    R.sa[0] = q_scale<C, 0>(lds, R, p_row(0) * PITCH, 0);
+    R.sa[1] = q_scale<C, 0>(lds, R, p_row(1) * PITCH, 0);
+    R.sa[2] = 0.f;
+    R.sa[3] = 0.f;                                          // the "carried pair" of the first step: zeros x 0
+    q_load_sb<C, 0>(lds, R, 0, 0);
+    q_load_sb<C, 0>(lds, R, 1, 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) R.acc[1][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
+  }
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // step s on slot SL: regular (the LDS-DMA of int4 stage s + 2 behind the mid-step barrier), K0 / K1 (the keeper halves instead)
+  auto reg = [&](auto sl, int s) {
+    constexpr int SL = decltype(sl)::value;
+    const int g = s + 2;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    q_step<C, SL>(R, lds, c, sync, [&](int i) { q_piece<C, (SL + 2) % 3>(d, wsrc, asrc, sbsrc, i); });
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int s = 0;
+  for (; s + 4 < G; s += 3) { reg(S0(), s); reg(S1(), s + 1); reg(S2(), s + 2); }
+  // The last 2..4 steps run on ONE generic code body (run-time stage slots): 0..2 regular steps, then the two whose LDS-DMA is a
+  // keeper half instead of an int4 stage (the second one has no next int4 stage to prefetch from).
+  for (; s < G; ++s) {
+    const int g = s + 2;                                    // the stage this step's LDS-DMA fetches: int4 g, or keeper half g - G
+    const int dsl = g % 3;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    q_step<C, -1>(R, lds, c, sync,
+                  [&](int i) {
+                    if (g < G) {
+                      if (dsl == 0) q_piece<C, 0>(d, wsrc, asrc, sbsrc, i);
+                      else if (dsl == 1) q_piece<C, 1>(d, wsrc, asrc, sbsrc, i);
+                      else q_piece<C, 2>(d, wsrc, asrc, sbsrc, i);
+                    } else if (i == 0) issue_keeper<C>(p, g - G, slot_of(g), wave, lane, m0, n0);
+                  },
+                  (s % 3) * Q::STAGE, ((s + 1) % 3) * Q::STAGE, s + 1 == G);
+  }
+  {                                                         // the carried pair (slot 15) of the last int4 step
+    const float sa = R.sa[3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][7][r]);
+  }
   // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
   p_keeper<C>(slot_of(G), wm, wn, lane, c);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -959,24 +1357,29 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
 }
 
 template <class C>
-static int launch_p(const GemmParams &p, hipStream_t s) {
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6p_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          C::LDS_BYTES) != hipSuccess)
-    return ATOM_ERR_LAUNCH;
+static int launch_q(const GemmParams &p, hipStream_t s) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6p_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
+  return check_launch();
+}
+
+template <class C, int ABL = 0>
+static int launch_p(const GemmParams &p, hipStream_t s) {
+  constexpr int lds_bytes = C::LDS_BYTES + ((ABL & 16) ? 8 * 80 * 4 : 0);
+  static_assert(lds_bytes <= 160 * 1024, "LDS");
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6p_kernel<C, ABL>), lds_bytes, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6p_kernel<C, ABL>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), lds_bytes, s, p);
   return check_launch();
 }
 
 template <class C, bool SK = false>
 static int launch_x16(const GemmParams &p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
   hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C, SK>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
                      C::LDS_BYTES, s, p);
@@ -989,13 +1392,8 @@ static int launch_x16(const GemmParams &p, hipStream_t s) {
 
 template <class C, bool SK, int ABL = 0>
 static int launch(const GemmParams &p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_f6_kernel<C, SK, ABL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6_kernel<C, SK, ABL>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
   hipLaunchKernelGGL((gemm_w4a4_f6_kernel<C, SK, ABL>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
                      C::LDS_BYTES, s, p);
@@ -1008,11 +1406,11 @@ static int launch(const GemmParams &p, hipStream_t s) {
 
 }  // namespace f6
 
-// cfg: 0 = 256x256 (8 waves) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA micro-tiles, 2 = 64x128
-// (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128, 10 / 13 = 256x256 /
-// 128x128 on the 32x32x64 MFMA
+// cfg: 0 = 256x256 (8 waves, the pipelined kernel) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA
+// micro-tiles, 2 = 64x128 (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128,
+// 10 / 13 = 256x256 / 128x128 on the 32x32x64 MFMA, 40 = 256x256 first-generation micro-tile kernel
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
-#ifdef ATOM_F6_ABLATE
+#ifdef ATOM_TOOLS
   if (cfg == 116) {   // traced run (tools/trace_f6.cpp): the stamp buffer arrives in ATOM_TRACE_PTR
     const char *e = getenv("ATOM_TRACE_PTR");
     if (!e) return ATOM_ERR_INVALID_ARG;
@@ -1023,6 +1421,20 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   switch (cfg) {   // tools/gemm_bench only: 100 + ablation mask on the 256x256 geometry
 #define ATOM_ABL(a) case 100 + a: return f6::launch<f6::Cfg<256, 256, 4, 3>, false, a>(p, s);
     ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15) ATOM_ABL(32)
+#undef ATOM_ABL
+  }
+  if (cfg == 1016) {   // traced run of the pipelined kernel (tools/trace_f6.cpp)
+    const char *e = getenv("ATOM_TRACE_PTR");
+    if (!e) return ATOM_ERR_INVALID_ARG;
+    GemmParams q = p;
+    q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+    return f6::launch_p<f6::Cfg<256, 256, 4, 3>, 16>(q, s);
+  }
+  switch (cfg) {   // 1000 + ablation mask on the pipelined kernel
+#define ATOM_ABL(a) case 1000 + a: return f6::launch_p<f6::Cfg<256, 256, 4, 3>, a>(p, s);
+    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15)
+    ATOM_ABL(64) ATOM_ABL(128) ATOM_ABL(192) ATOM_ABL(207) ATOM_ABL(256) ATOM_ABL(257) ATOM_ABL(512) ATOM_ABL(513) ATOM_ABL(768) ATOM_ABL(769)
+    ATOM_ABL(520) ATOM_ABL(9) ATOM_ABL(1024) ATOM_ABL(2048) ATOM_ABL(4096)
 #undef ATOM_ABL
   }
 #endif
@@ -1037,8 +1449,9 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, true>(p, s);
     return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
   }
-  if (cfg == 30) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);          // 256x256, pipelined across K steps
-  return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // 256x256 on the 16x16x128 MFMA
+  if (cfg == 40) return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // tuning: 256x256, first-generation micro-tile kernel
+  if (cfg == 30 || !p.sB32) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);   // 256x256, pipelined across K steps (fp16 weight scales)
+  return f6::launch_q<f6::Cfg<256, 256, 4, 3>>(p, s);                          // ... third generation (ATOM_B_F6S; the headline)
 }
 
 }  // namespace atom

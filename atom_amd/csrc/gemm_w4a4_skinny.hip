@@ -175,13 +175,9 @@ template <int NW, int MBLK, int CNT, bool OUT32 = false>
 static int launch(const GemmParams &p, hipStream_t s) {
   constexpr size_t lds = (size_t)NW * MBLK * 64 * 16;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ATOM_ERR_LAUNCH;
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>), (int)lds, attr_done) != ATOM_OK)
+      return ATOM_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();

@@ -454,14 +454,9 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
 
 template <int NS, int ABL = 0, bool O4 = false>
 static int launch_v2(const GemmParams &p, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   constexpr int lds_bytes = NS * v2::STAGE_BYTES > 8 * 64 * 144 ? NS * v2::STAGE_BYTES : 8 * 64 * 144;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v2::gemm_w4a4_v2_kernel<NS, ABL, O4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  if (ensure_max_lds(reinterpret_cast<const void *>(&v2::gemm_w4a4_v2_kernel<NS, ABL, O4>), lds_bytes, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + v2::BM - 1) / v2::BM, nbn = (p.N + v2::BN - 1) / v2::BN;
   hipLaunchKernelGGL((v2::gemm_w4a4_v2_kernel<NS, ABL, O4>), dim3((unsigned)(nbm * nbn)), dim3(v2::NT), lds_bytes, s, p);
   return check_launch();
@@ -472,6 +467,7 @@ int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s) { return launch_v2<4, 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s) {
   switch (ns) {
     case 3: return launch_v2<3>(p, s);
+#ifdef ATOM_TOOLS   // ablation masks (profiles/r01_ablation_v1_v2.txt): tools build only
     case 1001: return launch_v2<4, 1>(p, s);
     case 1002: return launch_v2<4, 2>(p, s);
     case 1003: return launch_v2<4, 3>(p, s);
@@ -487,6 +483,7 @@ int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s) {
     case 1064: return launch_v2<4, 64>(p, s);
     case 1128: return launch_v2<4, 128>(p, s);
     case 1256: return launch_v2<4, 256>(p, s);
+#endif
     default: return launch_v2<4>(p, s);
   }
 }

@@ -434,13 +434,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, hal
 
 template <class C>
 static int launch_v3_splitk(const GemmParams &p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, false, true>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
   hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.splits), dim3(C::NT),
                      C::LDS_BYTES, s, p);
@@ -451,13 +446,8 @@ static int launch_v3_splitk(const GemmParams &p, hipStream_t s) {
 
 template <class C, bool TRACE = false>
 static int launch_v3_cfg(const GemmParams &p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, TRACE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&v3::gemm_w4a4_v3_kernel<C, TRACE>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
   hipLaunchKernelGGL((v3::gemm_w4a4_v3_kernel<C, TRACE>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
   return check_launch();
@@ -475,9 +465,11 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     case 4: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2>>(p, s);     // skinny M: one wave per workgroup, 64x64 tile
     case 5: return launch_v3_cfg<v3::Cfg<64, 128, 3, 2>>(p, s);    // skinny M: two waves, 64x128 tile
     case 6: return launch_v3_cfg<v3::Cfg<128, 64, 3, 4>>(p, s);    // one wave, 128x64 tile
+#ifdef ATOM_TOOLS
     case 10: return launch_v3_cfg<v3::Cfg<256, 256, 4>, true>(p, s);   // traced (p.Dsz = u64 trace buffer)
     case 11: return launch_v3_cfg<v3::Cfg<256, 128, 3>, true>(p, s);
     case 30: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>, true>(p, s);   // traced
+#endif
     case 20: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>>(p, s);   // wide activations (p.A4 = int8 [M, K4])
     case 24: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2, true>>(p, s);
     case 25: return launch_v3_cfg<v3::Cfg<64, 128, 3, 2, true>>(p, s);

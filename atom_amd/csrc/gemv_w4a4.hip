@@ -117,13 +117,8 @@ template <int MB>
 static int launch_gemv_mb(const GemmParams &p, hipStream_t s) {
   const size_t lds = (size_t)((MB * (p.K4h + kKeeper) + 15) & ~15) + (size_t)MB * (p.G + 1) * 4;
   if (lds > 160 * 1024) return ATOM_ERR_SHAPE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_w4a4_kernel<MB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return ATOM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemv_w4a4_kernel<MB>), 160 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   int blocks = (p.N + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL((gemv_w4a4_kernel<MB>), dim3((unsigned)blocks), dim3(256), lds, s, p);

@@ -410,7 +410,7 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
 static int decode_splits(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
   const int64_t tiles = (int64_t)max_pages * (P / 16), pairs = (int64_t)batch * N;
-  static const int min_tiles = [] { const char *e = getenv("ATOM_DECODE_MIN_TILES"); return e ? atoi(e) : 8; }();   // tuning only
+  const int min_tiles = ATOM_TUNE("ATOM_DECODE_MIN_TILES", 8);
   int64_t smax = tiles / min_tiles;
   if (smax > 64) smax = 64;
   int best = 1;

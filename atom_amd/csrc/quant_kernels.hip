@@ -161,8 +161,9 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
       uint8_t *dst = p.o4 + ((int64_t)g * p.f6_rows + r) * 104;
       *reinterpret_cast<v3u *>(dst + 12 * j) = v3u{f[0], f[1], f[2]};
       if (j == 0) {                                       // the GEMM reads the token scale from the row itself
-        const unsigned sh = (unsigned)__builtin_bit_cast(unsigned short, f2h(s_store));
-        *reinterpret_cast<v2u *>(dst + 96) = v2u{sh, 0u};
+        const half_t shh = f2h(s_store);                  // fp16 at byte 96, the same value as fp32 at byte 100
+        const unsigned sh = (unsigned)__builtin_bit_cast(unsigned short, shh);
+        *reinterpret_cast<v2u *>(dst + 96) = v2u{sh, __builtin_bit_cast(unsigned, (float)shh)};
       }
     } else if (p.wide) {
       // my 16 channels are half `j & 1` of 32-channel block g*4 + j/2: even channels -> chunk 0, odd -> chunk 1
@@ -743,6 +744,8 @@ struct RepackF6Params {
   const half_t *scale;     // optional: per-(row, group) scales to embed at byte 96 (activation operands); NULL for weights
   int64_t ld;              // halves between groups of `scale`
   int ref_layout;
+  const half_t *wscale;    // optional (weights): fp16 scales [G, N] ...
+  float *wscale_out;       // ... written as float32 [G][rows_pad] (ATOM_SB_F32)
 };
 
 // One workgroup per (group, block of 256 rows): thread t re-codes the 128 codes of row t (64 packed bytes -> 96 bytes of
@@ -778,15 +781,19 @@ __global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) dst[6 * q + k] = f[k];
     }
-    unsigned sc = 0u;
-    if (p.scale)
-      sc = (unsigned)__builtin_bit_cast(unsigned short, p.scale[(int64_t)g * p.ld + (p.ref_layout ? ref_scale_index((int)n) : (int)n)]);
+    unsigned sc = 0u, sc32 = 0u;
+    if (p.scale) {
+      const half_t sv = p.scale[(int64_t)g * p.ld + (p.ref_layout ? ref_scale_index((int)n) : (int)n)];
+      sc = (unsigned)__builtin_bit_cast(unsigned short, sv);
+      sc32 = __builtin_bit_cast(unsigned, (float)sv);
+    }
     dst[24] = sc;
-    dst[25] = 0u;
+    dst[25] = sc32;
   } else {
 #pragma unroll
     for (int k = 0; k < 26; ++k) dst[k] = 0u;              // pad rows: zeros
   }
+  if (p.wscale_out) p.wscale_out[(int64_t)g * p.rows_pad + n] = n < p.N ? (float)p.wscale[(int64_t)g * p.N + n] : 0.f;
   __syncthreads();
   uint8_t *out = p.out + ((int64_t)g * p.rows_pad + n0) * 104;
   for (int i = t; i < 256 * 104 / 16; i += 256)
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
 int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,
                      uint8_t *out, hipStream_t s) {
   RepackF6Pair pp;
-  pp.op[0] = RepackF6Params{src, out, rows, (rows + 255) / 256 * 256, K4h, G, scale, ld, ref_layout};
+  pp.op[0] = RepackF6Params{src, out, rows, (rows + 255) / 256 * 256, K4h, G, scale, ld, ref_layout, nullptr, nullptr};
   pp.op[1] = pp.op[0];
   hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(pp.op[0].rows_pad / 256), (unsigned)G, 1), dim3(256), 0, s, pp);
   return check_launch();
@@ -805,10 +812,11 @@ int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const hal
 
 // both operands of a GEMM in one launch: activations (with their scales) and weights
 int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_t ldA, int ref_layout, uint8_t *outA,
+                          const half_t *sB, float *sB32,
                           const uint8_t *B4, int64_t N, uint8_t *outB, int K4h, int G, hipStream_t s) {
   RepackF6Pair pp;
-  pp.op[0] = RepackF6Params{A4, outA, M, (M + 255) / 256 * 256, K4h, G, sA, ldA, ref_layout};
-  pp.op[1] = RepackF6Params{B4, outB, N, (N + 255) / 256 * 256, K4h, G, nullptr, 0, 0};
+  pp.op[0] = RepackF6Params{A4, outA, M, (M + 255) / 256 * 256, K4h, G, sA, ldA, ref_layout, nullptr, nullptr};
+  pp.op[1] = RepackF6Params{B4, outB, N, (N + 255) / 256 * 256, K4h, G, nullptr, 0, 0, sB, sB32};
   const int64_t rp = pp.op[0].rows_pad > pp.op[1].rows_pad ? pp.op[0].rows_pad : pp.op[1].rows_pad;
   hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(rp / 256), (unsigned)G, 2), dim3(256), 0, s, pp);
   return check_launch();
@@ -919,6 +927,25 @@ int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6
   if (!aligned16(B4) || !aligned16(B_f6)) return ATOM_ERR_ALIGN;
   return launch_repack_f6((const uint8_t *)B4, N, (int)((K_total - kKeeper) / 2), (int)((K_total - kKeeper) / kGroup), nullptr, 0,
                           0, (uint8_t *)B_f6, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t atom_f6_weight_bytes(int64_t N, int64_t K_total) {
+  if (N < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  return (size_t)((K_total - kKeeper) / kGroup) * atom_f6_rows(N) * (104 + 4);
+}
+
+int atom_repack_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_total, void *B_f6s, void *stream) {
+  if (!B4 || !sB || !B_f6s) return ATOM_ERR_INVALID_ARG;
+  if (N < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if (!aligned16(B4) || !aligned16(B_f6s)) return ATOM_ERR_ALIGN;
+  const int G = (int)((K_total - kKeeper) / kGroup);
+  RepackF6Pair pp;
+  const int64_t Npad = (N + 255) / 256 * 256;
+  pp.op[0] = RepackF6Params{(const uint8_t *)B4, (uint8_t *)B_f6s, N, Npad, (int)((K_total - kKeeper) / 2), G, nullptr, 0, 0,
+                            (const half_t *)sB, reinterpret_cast<float *>((uint8_t *)B_f6s + (size_t)G * Npad * 104)};
+  pp.op[1] = pp.op[0];
+  hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(Npad / 256), (unsigned)G, 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pp);
+  return check_launch();
 }
 
 }  // extern "C"

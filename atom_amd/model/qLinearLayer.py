@@ -90,7 +90,7 @@ class QLinearLayer(nn.Module):
             b4, b8, sb, sb8 = packed
             if codes.wide == "f6":                        # BF6 operands: the weight is repacked once per packed form
                 if self._f6 is None or self._f6[0] is not b4:
-                    self._f6 = (b4, _ops.repack_weight_f6(b4))
+                    self._f6 = (b4, _ops.repack_weight_f6(b4, sb))
                 b4 = self._f6[1]
             y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
                                               scale_layout=codes.layout, a_wide=codes.wide)

@@ -193,7 +193,8 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
-                                   _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0)),
+                                   _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0))
+                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0),
                                    L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
@@ -368,12 +369,25 @@ def kv_fake_quant(x: torch.Tensor, n_bits: int = 4, clip: float = 1.0) -> torch.
     return y
 
 
-def repack_weight_f6(b4: torch.Tensor) -> torch.Tensor:
-    """Packed INT4 weights uint8 [N, K4/2] -> the F6 operand format uint8 [G][f6_rows(N)][104] (atom_repack_weight_f6)."""
+def repack_weight_f6(b4: torch.Tensor, b_scale: torch.Tensor = None) -> torch.Tensor:
+    """Packed INT4 weights uint8 [N, K4/2] -> the F6 operand format uint8 [G][f6_rows(N)][104] (atom_repack_weight_f6).
+    With the fp16 weight scales `b_scale` [G, N]: atom_repack_weight_f6s -- the returned tensor is a view of a buffer that
+    carries the scales as float32 [G][f6_rows(N)] behind the codes (ATOM_B_F6S; dense_layer_gemm_i4_fp16 recognises it by the
+    `atom_f6s` attribute and the 256x256 kernel then takes its weight scales from there)."""
     if not b4.is_cuda:
         raise L.AtomHipError("repack_weight_f6 needs a GPU tensor: no CPU fallback")
     n, k4h = b4.shape
     g = k4h // 64
+    if b_scale is not None:
+        assert b_scale.is_cuda and b_scale.dtype == torch.float16 and b_scale.numel() == g * n
+        nbytes = L.lib().atom_f6_weight_bytes(n, k4h * 2 + GROUP_SIZE)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=b4.device)
+        st = L.lib().atom_repack_weight_f6s(b4.contiguous().data_ptr(), b_scale.contiguous().data_ptr(), n, k4h * 2 + GROUP_SIZE,
+                                             buf.data_ptr(), L.current_stream(b4.device))
+        L.check(st, "atom_repack_weight_f6s")
+        out = buf[:g * f6_rows(n) * L.F6_PITCH].view(g, f6_rows(n), L.F6_PITCH)
+        out.atom_f6s = buf                       # the whole buffer (codes + float32 scales) stays alive with the view
+        return out
     out = torch.empty((g, f6_rows(n), L.F6_PITCH), dtype=torch.uint8, device=b4.device)
     st = L.lib().atom_repack_weight_f6(b4.contiguous().data_ptr(), n, k4h * 2 + GROUP_SIZE, out.data_ptr(),
                                         L.current_stream(b4.device))

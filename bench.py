@@ -6,7 +6,12 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
-                    [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle)
+                    [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle;
+                                     reported as "ramp" in the JSON line)
+
+--gpus N > 1 without a torch.distributed environment (no WORLD_SIZE): bench.py starts the N ranks itself
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>); under
+torch.distributed.run WORLD_SIZE must equal --gpus.  "n_gpus" in the JSON line is the number of ranks that ran.
 
 The headline runs the operand format the drop-in modules use for prefill batches (F6: both operands BF6-coded, block-scaled
 MFMA); at N=1 the reference's packed-nibble format and the wide-activation format are timed beside it (same codes, same
@@ -51,28 +56,45 @@ def algorithmic_bytes(M, N, K):
     return M * K4 // 2 + N * K4 // 2 + 128 * (M + N) + 2 * (M * G + N * G + M + N) + 2 * M * N
 
 
-def cpu_baseline(M, N, K, budget_s=15.0):
-    """The reference's CPU path for this GEMM: QLinearLayer.forward == F.linear on fake-quant FP16 operands
-    (model/qLinearLayer.py:32-35), torch CPU kernels, all host threads.  Bounded sample."""
-    from oracle import atom_oracle as O
-    g = torch.Generator().manual_seed(0)
-    Ms = M
-    x = (torch.randn(Ms, K, generator=g) * 0.5).half()
-    w = (torch.randn(N, K, generator=g) * 0.05).half()
+def _median_time(fn, budget_s, max_runs=10):
     t0 = time.perf_counter()
-    O.sim_linear_torch(x, w)                                     # warm-up
+    fn()                                                         # warm-up
     first = time.perf_counter() - t0
     times = []
     start = time.perf_counter()
-    while len(times) < 10 and (time.perf_counter() - start) < budget_s:
+    while len(times) < max_runs and (time.perf_counter() - start) < budget_s:
         t0 = time.perf_counter()
-        O.sim_linear_torch(x, w)
+        fn()
         times.append(time.perf_counter() - t0)
-    t = float(np.median(times)) if times else first
-    return {"value": round(2.0 * Ms * N * K / t / 1e12, 4), "unit": "TOPS", "cores": torch.get_num_threads(),
+    return (float(np.median(times)) if times else first), max(len(times), 1)
+
+
+def cpu_baseline(M, N, K, budget_s=12.0):
+    """The reference's CPU path for this GEMM: QLinearLayer.forward == F.linear on fake-quant FP16
+    operands (model/qLinearLayer.py:32-35), torch CPU kernels, all host threads -- the faithful FP16 line is `value`; beside
+    it the FP32-upcast line ("best CPU") and the CPU time of the activation quantiser that feeds the GEMM
+    (quantize_activation_wrapper, model/quant.py:187-231, restated in oracle.reorder_quant).  Bounded samples."""
+    from oracle import atom_oracle as O
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    ops = 2.0 * M * N * K
+    t16, n16 = _median_time(lambda: O.sim_linear_torch(x, w), budget_s)
+    x32, w32 = x.float(), w.float()
+    t32, n32 = _median_time(lambda: O.sim_linear_torch(x32, w32), budget_s / 3)
+    Mq = min(M, 1024)                                            # quantiser sample: 1024 tokens of the same hidden size
+    xq = x[:Mq].numpy()
+    idx = np.random.default_rng(0).permutation(K).astype(np.int16)
+    tq, nq = _median_time(lambda: O.reorder_quant(xq, idx, "sim", 0.9), budget_s / 3, max_runs=3)
+    return {"value": round(ops / t16 / 1e12, 4), "unit": "TOPS", "cores": os.cpu_count(), "threads": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"torch F.linear fp16 {Ms}x{N}x{K} on CPU (reference QLinearLayer.forward), "
-                      f"median of {max(len(times), 1)} runs, {t * 1e3:.1f} ms each"}
+            "sample": f"torch F.linear fp16 {M}x{N}x{K} on CPU (the literal call of the reference's QLinearLayer.forward), "
+                      f"median of {n16} runs, {t16 * 1e3:.1f} ms each",
+            "fp32_upcast": {"value": round(ops / t32 / 1e12, 4), "unit": "TOPS",
+                            "sample": f"same operands upcast to fp32 (\"best CPU\"), median of {n32} runs, {t32 * 1e3:.1f} ms each"},
+            "act_quant": {"value": round(Mq / tq, 1), "unit": "tokens/s",
+                          "sample": f"numpy restatement of quantize_activation_wrapper (reorder + INT4/INT8 fake-quant), "
+                                    f"{Mq} tokens x hidden {K}, 1 thread, median of {nq} runs, {tq * 1e3:.1f} ms each"}}
 
 
 def max_over_ranks(values, dist, device):
@@ -126,9 +148,55 @@ def build_f6_operands(ops_, M, N, K, dev):
     by = torch.stack([(w24 >> (8 * i)) & 0xFF for i in range(3)], dim=-1).to(torch.uint8).reshape(M, G, 96)
     a6 = torch.zeros((G, aops.f6_rows(M), 104), dtype=torch.uint8, device=dev)
     a6[:, :M, :96] = by.permute(1, 0, 2)
-    a6[:, :M, 96:98] = ops_[2].reshape(G, M, 1).view(torch.uint8).reshape(G, M, 2)         # sA[g, m] rides in the row
-    b6 = aops.repack_weight_f6(ops_[1].view(torch.uint8))
+    a6[:, :M, 96:98] = ops_[2].reshape(G, M, 1).view(torch.uint8).reshape(G, M, 2)         # sA[g, m] rides in the row: fp16 ...
+    a6[:, :M, 100:104] = ops_[2].float().reshape(G, M, 1).view(torch.uint8).reshape(G, M, 4)   # ... and the same value as fp32
+    b6 = aops.repack_weight_f6(ops_[1].view(torch.uint8), ops_[3])                         # codes + float32 scales (ATOM_B_F6S)
     return a6, b6
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks the way the driver would."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_steps(step, steps, warmup, sync, dist, device):
+    """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by barrier + device synchronise on both
+    sides; HIP events on the launch stream for the kernel-only time.  Returns (wall seconds, ms per step by events) as the MAX
+    over ranks."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    cuda = device.type == "cuda"
+    if cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    if cuda:
+        e0.record()
+    for _ in range(steps):
+        step()
+    t1 = time.perf_counter()
+    if cuda:
+        e1.record()
+    sync()
+    t2 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = (e0.elapsed_time(e1) if cuda else wall * 1e3) / steps
+    timed_steps.breakdown = {"enqueue_us": round((t1 - t0) * 1e6, 1), "drain_us": round((t2 - t1) * 1e6, 1)}
+    return max_over_ranks([wall, kern_ms], dist, device)
 
 
 def main():
@@ -139,15 +207,46 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
-    ap.add_argument("--ramp", type=int, default=1500, help="untimed launches before the warm-up steps (power-state ramp)")
+    ap.add_argument("--ramp", type=int, default=1500, help="untimed launches before the warm-up steps (power-state ramp); "
+                                                           "reported in the JSON line")
     ap.add_argument("--format", choices=["f6", "packed", "wide"], default="f6",
                     help="operand format of the headline measurement (the other two are reported beside it at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="tests only: the launch / rendezvous / timing / aggregation path on CPU (gloo) with a dummy step")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    M, N, K = args.M, args.N, args.K
+
+    if args.stub_step:                                           # CPU stand-in for the kernel launch (tests/test_bench_gloo.py)
+        dev = torch.device("cpu")
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+        acc = torch.zeros(64, 64)
+        eye = torch.eye(64)
+
+        def step():
+            acc.add_(eye @ eye)
+        wall, kern_ms = timed_steps(step, args.steps, args.warmup, lambda: None, dist, dev)
+        if rank == 0:
+            agg = aggregate(world, args.steps, wall, kern_ms, M, N, K)
+            print(json.dumps({"metric": "stub", "value": agg["value"], "unit": "TOPS", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": agg["ms_per_step"], "ramp": 0, "data": "stub step on CPU",
+                              "steps_run": int(acc[0, 0].item())}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the W4A4 path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -159,7 +258,6 @@ def main():
 
     from atom_amd import _lib as L
     lib = L.lib()
-    M, N, K = args.M, args.N, args.K
     ops_ = make_operands(M, N, K, dev, seed=rank)
     D = torch.empty((M, N), dtype=torch.float16, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -174,12 +272,12 @@ def main():
                    "reference format: packed INT4 nibbles (punica.ops ABI), INT8 MFMA after in-kernel widening"),
         "wide": ([wide.data_ptr()] + ptrs[1:], L.SCALE_LAYOUT_PLAIN | L.A_WIDE,
                  "activations int8 = code*16 (ATOM_A_WIDE), weights packed INT4, INT8 MFMA"),
-        "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6,
-               "both operands BF6 group-major (ATOM_AB_F6): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, "
-               "exact integer dot products; the format the fused quantisers emit for prefill batches"),
+        "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S,
+               "both operands BF6 group-major (ATOM_AB_F6): v_mfma_f32_16x16x128_f8f6f4, exact integer dot products; the "
+               "format the fused quantisers emit for prefill batches"),
         "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
                       "reference packed format through atom_gemm_w4a4_f16_ws: both operands re-coded to BF6 in the caller's "
-                      "workspace (one launch), then the block-scaled-MFMA kernel; what atom_amd.ops does for packed operands"),
+                      "workspace (one launch), then the BF6 MFMA kernel; what atom_amd.ops does for packed operands"),
     }
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
@@ -197,39 +295,27 @@ def main():
         return step
 
     step = make_step(args.format)
-    # Power-state ramp, part of the set-up (not of the W warm-up steps, not timed): after idle the chip runs the first few
-    # hundred launches at lower clocks (500 timed steps after 100 warm-ups measure ~5 % below 2000 after 200), so bring it
-    # to its sustained state before the contract's W untimed + K timed steps.
+    sync = lambda: torch.cuda.synchronize(dev)
+    # Power-state ramp, part of the set-up (not of the W warm-up steps, not timed, reported as "ramp"): after idle the chip
+    # runs the first few hundred launches at lower clocks (500 timed steps after 100 warm-ups measure ~5 % below 2000 after
+    # 200), so bring it to its sustained state before the contract's W untimed + K timed steps.
     for _ in range(args.ramp):
         step()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1) / args.steps                  # HIP events on the launch stream
-    wall, kern_ms = max_over_ranks([wall, kern_ms], dist, dev)
+    if args.ramp:                                # ... and one dry pass through the timing apparatus itself (event creation, first
+        timed_steps(step, 2, 0, sync, dist, dev)  # synchronize / barrier of the process): 2 more untimed launches, counted in "ramp"
+    wall, kern_ms = timed_steps(step, args.steps, args.warmup, sync, dist, dev)
 
     # N=1 only: the other operand formats beside the headline, and a bit-for-bit comparison of the outputs
     others = {}
     if world == 1:
         D_head = D.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for name in variants:
             if name == args.format:
                 continue
             st2 = make_step(name)
-            for _ in range(args.warmup):
+            D.zero_()
+            for _ in range(max(args.warmup, 1)):                 # (at least one launch: the comparison below is of ITS output)
                 st2()
             torch.cuda.synchronize(dev)
             same = bool(torch.equal(D, D_head))
@@ -253,21 +339,30 @@ def main():
             "value": round(tops, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(agg["ms_per_step"], 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int4xint4 exact integer dot (BF6-coded on the block-scaled MFMA; INT8 MFMA for the keeper), fp32 dequant, fp16 out"
+            "dtype": "int4xint4 exact integer dot (BF6-coded on the f8f6f4 MFMA; INT8 MFMA for the keeper), fp32 dequant, fp16 out"
                      if args.format == "f6" else "int4xint4->int32 (i8 MFMA), fp32 dequant, fp16 out",
             "data": "synthetic",
+            "timed_region": {"wall_us": round(wall * 1e6, 1), "events_us": round(kern_ms * 1e3 * args.steps, 1),
+                             **getattr(timed_steps, "breakdown", {})},
+            "ramp": args.ramp + (2 if args.ramp else 0),
+            "ramp_note": "untimed set-up launches of the same kernel ahead of the W warm-up steps (power-state ramp after idle)",
             "config": {"workload": f"W4A4 GEMM M={M} N={N} K={K} group=128 keeper=128 (BASELINE configs[2])",
                        "M": M, "N": N, "K": K, "parallelism": f"replicas x{world}", "operand_format": args.format,
                        "operand_format_note": variants[args.format][2]},
             "gbps": round(agg["gbps"], 1),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_I8_TOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": measured_traffic(M, N, K, args.format),
+                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
+                                         "(profiles/rNN/bench_hbm_traffic_*.json), not measured in this run",
                          "kernel_us": round(kern_ms * 1e3, 2),
                          "algorithmic_bytes": algorithmic_bytes(M, N, K), "algorithmic_ops": int(ops_per_step),
                          "peak_note": "dense INT8 MFMA peak (BASELINE.md); the BF6 MFMA this format runs on peaks at ~10 POPS"},
         }
         if others:
             out["other_operand_formats"] = others
+            if "packed_ws" in others:                            # what a punica.ops caller (the reference's operand ABI) gets
+                out["abi_value"] = others["packed_ws"]["value"]
+                out["abi_value_note"] = "TOPS of the same GEMM called with the reference's packed operand format (packed_ws)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N, K)
         print(json.dumps(out), flush=True)

@@ -69,9 +69,14 @@ extern "C" {
  * INT4 code is a BF6 (E3M2) number, and v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4 with unit block scales multiply them exactly
  * at the FP4 rate.  OR ATOM_AB_F6 into `scale_layout` of atom_gemm_w4a4_f16: BOTH A4 and B4 are then
  *   uint8 [G][atom_f6_rows(rows)][104]   group-major; bytes 0..95 = the 128 codes of (row, group) as a little-endian
- *                                         stream of 6-bit BF6 fields, bytes 96..97 = the fp16 scale of (row, group) (A4
- *                                         only: the GEMM reads token scales from here, `sA` is ignored), 98..103 zero
- * with atom_f6_rows(rows) = rows rounded up to 256 (pad rows: any bytes).  sB / keeper operands and scales as before.
+ *                                         stream of 6-bit BF6 fields; A4 only: bytes 96..97 = the fp16 scale of (row,
+ *                                         group), 98..99 zero, 100..103 = the same scale as fp32 (the GEMM reads token
+ *                                         scales from the row, `sA` is ignored); B4: bytes 96..103 zero
+ * with atom_f6_rows(rows) = rows rounded up to 256 (pad rows: any bytes).  sB / keeper operands and scales as before.  OR
+ * ATOM_B_F6S in as well when the B4 buffer is followed by the weight scales as float32 [G][atom_f6_rows(N)] (pad columns
+ * zero; atom_repack_weight_f6s writes both, offline with the weight): the 256x256 kernel then streams them straight into its
+ * de-quantisation registers (no fp16 -> fp32 conversions in the K loop); `sB` (fp16) is still required -- the other tile
+ * geometries read it.
  * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
  * still written).  Weights: atom_repack_weight_f6.  Results are bit-identical to the INT8 kernels.  M, N >= 1 as usual;
  * three tile geometries (256x256, 128x128, 64x128 + split-K through atom_gemm_w4a4_f16_ws) picked by shape; ahead of the
@@ -79,6 +84,7 @@ extern "C" {
  */
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
+#define ATOM_B_F6S 0x400
 #define ATOM_F6_PITCH 104
 
 const char *atom_version(void);
@@ -291,6 +297,11 @@ size_t atom_f6_rows(int64_t rows);
 /* Packed INT4 weights B4 [N, K4/2] -> the F6 format (see ATOM_AB_F6): B_f6 uint8 [G][atom_f6_rows(N)][104], pad rows and
  * bytes 96..103 zeroed.  Offline, once per weight. */
 int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6, void *stream);
+
+/* The same + the fp16 weight scales sB [G, N] appended as float32 [G][atom_f6_rows(N)] (ATOM_B_F6S): B_f6s holds
+ * atom_f6_weight_bytes(N, K_total) = G * atom_f6_rows(N) * (104 + 4) bytes. */
+size_t atom_f6_weight_bytes(int64_t N, int64_t K_total);
+int atom_repack_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_total, void *B_f6s, void *stream);
 
 #ifdef __cplusplus
 }

@@ -107,7 +107,7 @@ _BF6_MAG = [0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18]
 
 def f6_codes(q4, scales=None):
     """int8 codes [M, K4] (+ fp16 scales [M, G]) -> the F6 operand buffer uint8 [G][round_up(M,256)][104]
-    (include/atom_hip.h, ATOM_AB_F6): 6-bit BF6 (E3M2) fields, little-endian, scale at byte 96; pad rows zero."""
+    (include/atom_hip.h, ATOM_AB_F6): 6-bit BF6 (E3M2) fields, little-endian, scale at byte 96 (fp16) and 100 (fp32); pad rows zero."""
     q = np.asarray(q4, dtype=np.int64)
     M, K4 = q.shape
     G = K4 // 128
@@ -119,8 +119,9 @@ def f6_codes(q4, scales=None):
     out = np.zeros((G, rp, 104), dtype=np.uint8)
     out[:, :M, :96] = np.transpose(b, (1, 0, 2))
     if scales is not None:
-        sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float16).T).view(np.uint8).reshape(G, M, 2)
-        out[:, :M, 96:98] = sc
+        sc16 = np.ascontiguousarray(np.asarray(scales, dtype=np.float16).T)
+        out[:, :M, 96:98] = sc16.view(np.uint8).reshape(G, M, 2)
+        out[:, :M, 100:104] = sc16.astype(np.float32).view(np.uint8).reshape(G, M, 4)      # the same scale as fp32
     return out
 
 

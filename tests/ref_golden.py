@@ -1,0 +1,86 @@
+"""ctypes view of oracle/_ref/libatom_ref.so: the reference's own CPU golden functions (run_cpu_reorder_fp16_i4,
+run_cpu_activate_fp16_i4, run_cpu_rmsnorm_fp16_i4), compiled from /root/reference by oracle/Makefile.  Checker side only.
+The library exists where the build container made it (it travels to the GPU box as a built file); available() says so."""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "_ref", "libatom_ref.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(_SO)
+        vp, i = ctypes.c_void_p, ctypes.c_int
+        L.ref_cpu_reorder_fp16_i4.restype = None
+        L.ref_cpu_reorder_fp16_i4.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp]
+        L.ref_cpu_activate_fp16_i4.restype = None
+        L.ref_cpu_activate_fp16_i4.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
+        L.ref_cpu_rmsnorm_fp16_i4.restype = None
+        L.ref_cpu_rmsnorm_fp16_i4.argtypes = [vp, vp, ctypes.c_float, i, i, i, vp, vp, vp, vp, vp]
+        L.ref_scale_index.restype = i
+        L.ref_scale_index.argtypes = [i]
+        _lib = L
+    return _lib
+
+
+def scale_size(rows: int) -> int:
+    """SCALE_SIZE_A (Reorder.cu:50)."""
+    return rows // 16 * 64 + 64 - (1 - (rows % 16) // 8) * (8 - (rows % 8)) * 8
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _run(kind, x, b=None, w=None, idx=None, eps=0.0):
+    """Returns dict(q4 int8 [M, K4] (unpacked), s4 f16 [M, G], q8 int8 [M, 128], s8 f16 [M]) read back from the reference's
+    buffers: packed PackInt4 codes (low nibble = even element) and the replicated scale layout (first replica)."""
+    x = np.ascontiguousarray(x, dtype=np.float16)
+    M, H = x.shape
+    G = H // 128 - 1
+    ld = scale_size(M)
+    o8 = np.zeros((M, 128), np.int8)
+    o4 = np.zeros((M, (H - 128) // 2), np.uint8)
+    s8 = np.zeros(ld, np.float16)
+    s4 = np.zeros(G * ld, np.float16)
+    L = lib()
+    if kind == "reorder":
+        idx = np.ascontiguousarray(idx, dtype=np.int16)
+        L.ref_cpu_reorder_fp16_i4(_p(x), 128, H, M, _p(idx), _p(o8), _p(o4), _p(s8), _p(s4))
+    elif kind == "activate":
+        b = np.ascontiguousarray(b, dtype=np.float16)
+        L.ref_cpu_activate_fp16_i4(_p(x), _p(b), 128, H, M, _p(o8), _p(o4), _p(s8), _p(s4))
+    else:
+        idx = np.ascontiguousarray(idx, dtype=np.int16)
+        w = np.ascontiguousarray(w, dtype=np.float16)
+        L.ref_cpu_rmsnorm_fp16_i4(_p(x), _p(w), float(eps), 128, H, M, _p(idx), _p(o8), _p(o4), _p(s8), _p(s4))
+    rows = np.array([L.ref_scale_index(r) for r in range(M)])
+    lo = (o4 & 0xF).astype(np.int8)
+    hi = (o4 >> 4).astype(np.int8)
+    q4 = np.stack([np.where(lo >= 8, lo - 16, lo), np.where(hi >= 8, hi - 16, hi)], axis=-1).reshape(M, H - 128).astype(np.int8)
+    s4p = s4.reshape(G, ld)[:, rows].T.copy()
+    # all four replicas of a scale must agree (rows + 2k)
+    for k in range(1, 4):
+        assert np.array_equal(s4.reshape(G, ld)[:, rows + 2 * k].T, s4p)
+    return dict(q4=q4, s4=s4p, q8=o8, s8=s8[rows].copy(), raw_s4=s4, raw_s8=s8, packed4=o4)
+
+
+def reorder(x, idx):
+    return _run("reorder", x, idx=idx)
+
+
+def activate(a, b):
+    return _run("activate", a, b=b)
+
+
+def rmsnorm(x, w, eps, idx):
+    return _run("rmsnorm", x, w=w, idx=idx, eps=eps)

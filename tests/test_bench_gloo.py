@@ -35,3 +35,26 @@ def test_algorithmic_bytes_match_baseline_md():
     import bench
     assert bench.algorithmic_bytes(4096, 4096, 4096) == 51380224
     assert bench.algorithmic_bytes(1, 4096, 4096) == 8923264           # config 2
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must itself start 2 ranks and report n_gpus = 2; the
+    launch / rendezvous / barrier / timed-region / aggregation code is the product's, only the step is a CPU stand-in."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                          "--stub-step"], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                                   # ONE JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 20 and r["warmup"] == 3
+    assert r["steps_run"] == 23                                          # W untimed + exactly K timed steps
+    assert r["ms_per_step"] > 0 and r["value"] > 0
+
+
+def test_bench_gpus_flag_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step"], capture_output=True,
+                         text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

@@ -49,6 +49,11 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> hA4((size_t)M * K4 / 2), hB4((size_t)N * K4 / 2), hA8((size_t)M * 128), hB8((size_t)N * 128);
   std::vector<half_t> hsA((size_t)G * M), hsB((size_t)G * N), hsA8(M), hsB8(N);
   fill_u8(hA4); fill_u8(hB4); fill_u8(hA8); fill_u8(hB8);
+  if (const char *dm = getenv("ATOM_DATA")) {   // power / toggle sensitivity: zero = all codes 0, const = every code 1, small = codes in [-1, 1]
+    const int mode = !strcmp(dm, "zero") ? 0 : (!strcmp(dm, "const") ? 1 : 2);
+    for (auto *v : {&hA4, &hB4, &hA8, &hB8})
+      for (auto &x : *v) x = mode == 0 ? 0 : (mode == 1 ? 0x11 : (uint8_t)(((x & 1) ? 0x01 : 0x0F) | ((x & 2) ? 0x10 : 0xF0)));
+  }
   fill_sc(hsA); fill_sc(hsB); fill_sc(hsA8); fill_sc(hsB8);
   for (int g = 0; g < G; ++g) for (int n = 0; n < N; n += 2) hsB[(size_t)g * N + n + 1] = hsB[(size_t)g * N + n];
   void *A4, *B4, *A8, *B8, *sA, *sB, *sA8, *sB8, *D;
@@ -94,14 +99,18 @@ int main(int argc, char **argv) {
             dst[bit / 8] |= (uint8_t)(c << (bit % 8));
             if (bit % 8 > 2) dst[bit / 8 + 1] |= (uint8_t)(c >> (8 - bit % 8));
           }
-          if (scales) memcpy(dst + 96, &scales[(size_t)g * rows + r], 2);
+          if (scales) { memcpy(dst + 96, &scales[(size_t)g * rows + r], 2); const float f = (float)scales[(size_t)g * rows + r]; memcpy(dst + 100, &f, 4); }
         }
       return out;
     };
-    std::vector<uint8_t> ha = conv(hA4, M, hsA.data()), hb = conv(hB4, N, nullptr);
+    std::vector<uint8_t> ha = conv(hA4, M, hsA.data());
     up(&Ain, ha.data(), ha.size());
-    up(&Bin, hb.data(), hb.size());
-    layout2 = ATOM_SCALE_LAYOUT_PLAIN | ATOM_AB_F6;
+    // weights through the library's own repack: codes + float32 scales (ATOM_B_F6S) unless ATOM_NO_F6S is set
+    const bool f6s = !getenv("ATOM_NO_F6S");
+    CK(hipMalloc(&Bin, atom_f6_weight_bytes(N, K)));
+    { int st = f6s ? atom_repack_weight_f6s(B4, sB, N, K, Bin, nullptr) : atom_repack_weight_f6(B4, N, K, Bin, nullptr);
+      if (st) { printf("repack: %s\n", atom_strerror(st)); return 1; } }
+    layout2 = ATOM_SCALE_LAYOUT_PLAIN | ATOM_AB_F6 | (f6s ? ATOM_B_F6S : 0);
   }
   size_t wsb = getenv("ATOM_WS") ? atom_gemm_w4a4_workspace_bytes(M, N, K) : 0;
   void *ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
