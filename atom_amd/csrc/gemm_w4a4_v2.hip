@@ -79,7 +79,7 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const unsigned off = int4 ? a.data[i] : a.data8[i];
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(slot + (wave * 64 + i * 16) * 64), 16, 0, 0);
+    lds_dma<16>(base + off, slot + (wave * 64 + i * 16) * 64);
   }
   const bool keeper = step >= p.G;
   const int g = min(step, p.G - 1);
@@ -87,12 +87,12 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
     // sA: one fp16 per lane.  global_load_lds_ushort writes ONE ZERO-EXTENDED DWORD per lane (measured,
     // tools/probes/glds_probe.cpp) -> LDS image sA[m] at SA_OFF + 4*m.  Handles the replicated layout's gather.
     const half_t *sb = keeper ? p.sA8 : p.sA + (int64_t)g * p.ldA;
-    __builtin_amdgcn_global_load_lds((gptr_t)(sb + a.scale), (lptr_t)(slot + SA_OFF + wave * 256), 2, 0, 0);
+    lds_dma<2>(sb + a.scale, slot + SA_OFF + wave * 256);
   } else {
     // sB: a dword (two adjacent channels) per lane, dense fp16 image.  Waves 6,7 repeat waves 4,5 (same bytes to
     // the same place) so that every wave issues the same number of DMA instructions per stage.
     const half_t *sb = keeper ? p.sB8 : p.sB + (int64_t)g * p.N;
-    __builtin_amdgcn_global_load_lds((gptr_t)(sb + a.scale), (lptr_t)(slot + SB_OFF + (wave & 1) * 256), 4, 0, 0);
+    lds_dma<4>(sb + a.scale, slot + SB_OFF + (wave & 1) * 256);
   }
 }
 

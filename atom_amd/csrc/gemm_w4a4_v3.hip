@@ -103,7 +103,7 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
     const uint8_t *base = isW ? wb : ab;
     const unsigned ja = (((gidx - C::GW) & 1) ? a.ja1 : a.ja) & kmask;
     const unsigned off = a.idx[i] * (isW ? strideW : strideA) + (isW ? a.jw : ja);
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(slot + gidx * 1024), 16, 0, 0);
+    lds_dma<16>(base + off, slot + gidx * 1024);
   }
   const bool keeper = step >= p.G;
   const int g = min(step, p.G - 1);
@@ -113,10 +113,10 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
   for (int s = 0; s < C::SPW; ++s) {
     const int sl = wave * C::SPW + s;
     if (sl < C::NSA) {   // one fp16 per lane; lands as one zero-extended dword per lane (tools/probes/glds_probe.cpp)
-      __builtin_amdgcn_global_load_lds((gptr_t)(sAb + a.scale[s]), (lptr_t)(slot + C::SA_OFF + sl * 256), 2, 0, 0);
+      lds_dma<2>(sAb + a.scale[s], slot + C::SA_OFF + sl * 256);
     } else {             // a dword = two adjacent channels per lane, dense fp16 image (padding slots repeat part 0)
       const int part = sl - C::NSA < C::NSB ? sl - C::NSA : 0;
-      __builtin_amdgcn_global_load_lds((gptr_t)(sBb + a.scale[s]), (lptr_t)(slot + C::SB_OFF + part * 256), 4, 0, 0);
+      lds_dma<4>(sBb + a.scale[s], slot + C::SB_OFF + part * 256);
     }
   }
 }

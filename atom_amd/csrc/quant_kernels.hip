@@ -223,10 +223,9 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       const int blk = i * 4 + wave;                         // 1 KiB block
       if (blk * 64 < nchunks) {
         const int c = min(blk * 64 + lane, nchunks - 1);    // tail lanes re-read the last chunk into the padding
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 16), (lptr_t)(smem + b * stage + blk * 1024), 16, 0, 0);
+        lds_dma<16>(src + c * 16, smem + b * stage + blk * 1024);
         if constexpr (ADD)
-          __builtin_amdgcn_global_load_lds((gptr_t)(src2 + c * 16), (lptr_t)(smem + b * stage + bufbytes + blk * 1024),
-                                           16, 0, 0);
+          lds_dma<16>(src2 + c * 16, smem + b * stage + bufbytes + blk * 1024);
       }
     }
   };
