@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KERNELS = {"f6": "gemm_w4a4_f6x16_kernel", "packed": "Cfg<256, 128, 3, 4, false>", "wide": "Cfg<256, 256, 3, 4, true>"}
+KERNELS = {"f6": "gemm_w4a4_f6q_kernel", "packed": "Cfg<256, 128, 3, 4, false>", "wide": "Cfg<256, 256, 3, 4, true>"}
 ALGO_BYTES = 51380224       # SURVEY 8(d), M=N=K=4096
 
 
