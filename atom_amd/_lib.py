@@ -22,6 +22,7 @@ QUANT_WIDE_CODES = 0x100   # ATOM_QUANT_WIDE_CODES
 A_WIDE = 0x100             # ATOM_A_WIDE
 QUANT_F6_CODES = 0x200     # ATOM_QUANT_F6_CODES
 AB_F6 = 0x200              # ATOM_AB_F6
+O4_REF_EXTREMA = 0x800     # ATOM_O4_REF_EXTREMA
 B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
 F6_PITCH = 104
 

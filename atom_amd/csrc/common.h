@@ -69,6 +69,7 @@ struct GemmParams {
   int a_wide;       // A4 is the wide activation format: int8 [M, K4] = code*16, even/odd de-interleaved per 32 channels
   int64_t ldA;      // halves between groups of sA
   int64_t f6_rows_a, f6_rows_b;   // F6 operand format: padded rows per group of A4 / B4 (gemm_w4a4_f6.hip)
+  int o4_ref;                     // ATOM_O4_REF_EXTREMA: the u4 epilogue with the reference code's |x| extrema and 4-bit wrap
   const float *sB32;              // ATOM_SB_F32: weight scales float32 [G][f6_rows_b] (then sB is not read by the 256x256 kernel)
 };
 
@@ -101,6 +102,23 @@ __device__ __forceinline__ void lds_dma(const void *gsrc, const void *lds_dst) {
   if constexpr (BYTES == 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
   else if constexpr (BYTES == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
   else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+}
+
+// u4 code of one value under the _o4 epilogue.  REF = the reference code's arithmetic (no clamp, low 4 bits of the int8 cast;
+// |result| beyond int8 saturates), else clamp to [0, 15] and 0 for an all-equal group.
+template <bool REF>
+__device__ __forceinline__ unsigned o4_code(float x, float zero, float rs, float scale) {
+  const float t = (x + zero) * rs;
+  float tr = truncf(t);
+  if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);     // roundf: half away from zero
+  if constexpr (REF) {
+    tr = fminf(fmaxf(tr, -128.f), 127.f);                  // (NaN for a 0 / 0 group -> fmaxf picks -128 -> code 0)
+    return (unsigned)(int)tr & 0xFu;
+  } else {
+    tr = fminf(fmaxf(tr, 0.f), 15.f);
+    if (scale == 0.f) tr = 0.f;
+    return (unsigned)(int)tr;
+  }
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -137,7 +137,8 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   if (!A4 || !B4 || !sA || !sB || !A8 || !B8 || !sA8 || !sB8) return ATOM_ERR_INVALID_ARG;
   const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
   const int f6 = (scale_layout & ATOM_AB_F6) != 0, f6s = (scale_layout & ATOM_B_F6S) != 0;
-  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S);
+  p.o4_ref = (scale_layout & ATOM_O4_REF_EXTREMA) != 0;    // (only the _o4 entry points look at it)
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA);
   if ((a_wide && f6) || (f6s && !f6)) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;

@@ -202,14 +202,15 @@ static int launch_m(const GemmParams &p, hipStream_t s) {
 // in gemm_w4a4_v2.hip): every 128-column group of a row of the FP32 sums -> scale = (max-min)/15, zero = -min,
 // q = clamp(round_half_away((x + zero) * (1/scale)), 0, 15).  Half a wave per group, 4 values per lane.
 __global__ __launch_bounds__(256) void o4_quant_kernel(const float *__restrict__ x, uint8_t *__restrict__ q, half_t *__restrict__ sz,
-                                                        int64_t groups, int gpr /* groups per row */) {
+                                                        int64_t groups, int gpr /* groups per row */, int ref_extrema) {
   const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
   const int l = threadIdx.x & 31;
   if (grp >= groups) return;
   const int64_t m = grp / gpr;
   const int g = (int)(grp % gpr);
   const v4f v = *reinterpret_cast<const v4f *>(x + (m * gpr + g) * 128 + 4 * l);
-  float lo = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), hi = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  const v4f e = ref_extrema ? v4f{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])} : v;   // ATOM_O4_REF_EXTREMA: extrema of |x|
+  float lo = fminf(fminf(e[0], e[1]), fminf(e[2], e[3])), hi = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
 #pragma unroll
   for (int k = 16; k >= 1; k >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, k));
@@ -218,14 +219,7 @@ __global__ __launch_bounds__(256) void o4_quant_kernel(const float *__restrict__
   const float scale = (hi - lo) / 15.f, zero = -lo, rs = 1.0f / scale;
   unsigned w = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float t = (v[k] + zero) * rs;
-    float tr = truncf(t);
-    if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);
-    tr = fminf(fmaxf(tr, 0.f), 15.f);
-    if (scale == 0.f) tr = 0.f;
-    w |= (unsigned)(int)tr << (4 * k);
-  }
+  for (int k = 0; k < 4; ++k) w |= (ref_extrema ? o4_code<true>(v[k], zero, rs, scale) : o4_code<false>(v[k], zero, rs, scale)) << (4 * k);
   *reinterpret_cast<unsigned short *>(q + (m * gpr + g) * 64 + 2 * l) = (unsigned short)w;
   if (l == 0) {
     half_t *d = sz + (m * gpr + g) * 2;
@@ -268,7 +262,7 @@ int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s) {
   const int gpr = p.N / 128;
   const int64_t groups = (int64_t)p.M * gpr;
   hipLaunchKernelGGL(skinny::o4_quant_kernel, dim3((unsigned)((groups * 32 + 255) / 256)), dim3(256), 0, s, p.ws, p.D4, p.Dsz,
-                     groups, gpr);
+                     groups, gpr, p.o4_ref);
   return check_launch();
 }
 

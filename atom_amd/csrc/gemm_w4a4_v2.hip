@@ -350,13 +350,14 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
     float mn[TM], mx[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      float lo = c[0][tm][0], hi = lo;
+      float lo = p.o4_ref ? fabsf(c[0][tm][0]) : c[0][tm][0], hi = lo;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          lo = fminf(lo, c[tn][tm][r]);
-          hi = fmaxf(hi, c[tn][tm][r]);
+          const float v = p.o4_ref ? fabsf(c[tn][tm][r]) : c[tn][tm][r];   // (reference code: extrema of |x|, see atom_hip.h)
+          lo = fminf(lo, v);
+          hi = fmaxf(hi, v);
         }
       lo = fminf(lo, __shfl_xor(lo, 32));                       // the other half-wave holds the other 32 features
       hi = fmaxf(hi, __shfl_xor(hi, 32));
@@ -390,14 +391,9 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
         for (int q = 0; q < 4; ++q) {
           unsigned w = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float t = (c[tn][tm][4 * q + k] + zero) * rs;
-            float tr = truncf(t);
-            if (fabsf(t - tr) >= 0.5f) tr += copysignf(1.0f, t);
-            tr = fminf(fmaxf(tr, 0.f), 15.f);
-            if (scale == 0.f) tr = 0.f;
-            w |= (unsigned)(int)tr << (4 * k);
-          }
+          for (int k = 0; k < 4; ++k)
+            w |= (p.o4_ref ? o4_code<true>(c[tn][tm][4 * q + k], zero, rs, scale) : o4_code<false>(c[tn][tm][4 * q + k], zero, rs, scale))
+                 << (4 * k);
           *reinterpret_cast<unsigned short *>(ep + (tm * 32 + l31) * 48 + (tn * 32 + 8 * q + 4 * h) / 2) = (unsigned short)w;
         }
     }

@@ -127,6 +127,8 @@ class QLinearLayer(nn.Module):
             self.weight = wq
             self._packed = (b4, b8, sb, sb8)
             self._packed_key = self._weight_key()
+            self._unpackable_key = None
+            self._f6 = None
             return
         saved = None
         if a.keeper > 0:
@@ -146,6 +148,8 @@ class QLinearLayer(nn.Module):
         if saved is not None:
             self.weight[:, -a.keeper:] = saved
         self._packed = None
+        self._unpackable_key = None
+        self._f6 = None
 
     def reorder(self, in_reorder_index, out_reorder_index=None):
         """reference qLinearLayer.py:80-86."""
@@ -154,4 +158,6 @@ class QLinearLayer(nn.Module):
             if out_reorder_index is not None:
                 self.weight = torch.index_select(self.weight, 0, out_reorder_index.to(self.weight.device))
             self._packed = None
+            self._unpackable_key = None
+            self._f6 = None
         return

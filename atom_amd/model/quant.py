@@ -50,11 +50,15 @@ def want_wide_codes(rows: int):
     return False
 
 
+MAX_HOT_HIDDEN = 16384     # the fused activation kernels take hidden sizes up to this (quant_kernels.hip launch_act_quant)
+
+
 def is_hot_act_config(args, hidden: int) -> bool:
-    """The configuration the HIP activation kernels implement (scripts/run_atom_ppl.sh:11-15)."""
+    """The configuration the HIP activation kernels implement (scripts/run_atom_ppl.sh:11-15).  Wider layers (the MLP
+    intermediate sizes 17920 / 22016 / 28672 of Llama-30B / 65B / 70B) take the reference's algorithm in torch ops instead."""
     return (args.abits == 4 and bool(args.a_sym) and args.act_group_size == GROUP and args.keeper == GROUP
             and getattr(args, "keeper_precision", 0) == 3 and getattr(args, "quant_type", "int") == "int"
-            and not getattr(args, "exponential", False) and hidden % GROUP == 0 and hidden >= 2 * GROUP)
+            and not getattr(args, "exponential", False) and hidden % GROUP == 0 and 2 * GROUP <= hidden <= MAX_HOT_HIDDEN)
 
 
 def attach_codes(t: torch.Tensor, codes: ActCodes) -> torch.Tensor:

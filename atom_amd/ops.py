@@ -202,11 +202,12 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
 
 
 def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale, *,
-                           scale_layout="ref", use_workspace=True):
+                           scale_layout="ref", use_workspace=True, ref_extrema=False):
     """Same GEMM, output asymmetric-quantised to u4 per 128-column group: (d u8[M,N/2], d_scale f16[M,N/128*2]).
     Reference: punica/ops/__init__.py:170-180 -> DenseLayerGEMM_i4_o4 (DenseLayerGEMM_i4_o4.cu:808-856).
     Decode batches (the shapes of the decode-batch GEMM) go through atom_gemm_w4a4_o4_ws with the cached workspace (weight-streaming kernel + u4
-    epilogue launch); ``use_workspace=False`` forces the tile kernel."""
+    epilogue launch); ``use_workspace=False`` forces the tile kernel.  ``ref_extrema=True``: the epilogue exactly as the reference
+    CODE computes it (extrema of |x|, 4-bit wrap instead of a clamp: ATOM_O4_REF_EXTREMA in include/atom_hip.h)."""
     m, n, k = _gemm_dims(a, b, a_keeper)
     assert n % 128 == 0
     d = torch.empty((m, n // 2), dtype=torch.uint8, device=a.device)
@@ -217,7 +218,8 @@ def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_
     st = lib.atom_gemm_w4a4_o4_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                   a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                   b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
-                                  GROUP_SIZE, _LAYOUTS[scale_layout], L.ptr(ws), ws_bytes, L.current_stream(a.device))
+                                  GROUP_SIZE, _LAYOUTS[scale_layout] | (L.O4_REF_EXTREMA if ref_extrema else 0), L.ptr(ws), ws_bytes,
+                                  L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_o4_ws")
     return d, d_scale
 

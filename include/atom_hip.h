@@ -85,6 +85,12 @@ extern "C" {
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
 #define ATOM_B_F6S 0x400
+/* atom_gemm_w4a4_o4 / _o4_ws only: the u4 epilogue exactly as the reference CODE computes it -- its local_max_min takes abs() of
+ * both extrema (DenseLayerGEMM_i4_o4.cu:73-80), so scale = (max|x| - min|x|) / 15, zero = -min|x|, and the code is
+ * (int8)round((x + zero) / scale) & 0xF (no clamp: negative results wrap, :766-771).  Wrong for any group with negative values
+ * (its consumer de-quantises code * scale - zero, flashinfer/quantization.cuh:59-84); the default implements the intended
+ * min / max.  Opt-in, for bit-comparisons against a reference run. */
+#define ATOM_O4_REF_EXTREMA 0x800
 #define ATOM_F6_PITCH 104
 
 const char *atom_version(void);

@@ -413,26 +413,34 @@ def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
     return c.astype(f16)
 
 
-def quant_o4(D32: np.ndarray):
+def quant_o4(D32: np.ndarray, ref_extrema: bool = False):
     """The _o4 epilogue (e2e/.../GEMM/DenseLayerGEMM_i4_o4.cu:704-788): asymmetric u4 per 128-col
     output group of the FP32 accumulators.  scale = (max-min)/15, zero = -min, r = 1/scale,
     q = clamp(round_half_away((x+zero)*r), 0, 15)  (fp32; the reference masks with & 0xF instead of clamping).
     We restate the *intended* min/max: the reference's local_max_min takes abs() of BOTH extrema (:73-80 of
     that file), which is wrong for any tile with negative values; its consumer de-quantises q*scale - zero
     (kernels/include/flashinfer/quantization.cuh:59-84), i.e. expects the true minimum.  See DESIGN.md.
+    ref_extrema=True restates the reference CODE instead (the opt-in ATOM_O4_REF_EXTREMA mode of the library): extrema of |x|
+    (:73-80, :732), scale = (max|x| - min|x|)/15, zero = -min|x| (:749-751), code = (int8)round((x+zero)*r) & 0xF with no clamp
+    (:766-771; the float -> int8 cast is taken as saturating).
     Returns (u8 packed [M,N/2], half2 (scale,zero) [M, N/128, 2])."""
     D32 = np.asarray(D32, dtype=f32)
     M, N = D32.shape
     g = D32.reshape(M, N // GROUP, GROUP)
-    mx = g.max(axis=-1)
-    mn = g.min(axis=-1)
+    e = np.abs(g) if ref_extrema else g
+    mx = e.max(axis=-1)
+    mn = e.min(axis=-1)
     scale = ((mx - mn) / f32(15)).astype(f32)
     zero = (-mn).astype(f32)
     with np.errstate(divide="ignore", invalid="ignore"):
         r = (f32(1.0) / scale).astype(f32)
         q = _round_half_away(((g + zero[..., None]).astype(f32) * r[..., None]).astype(f32))
-    q = np.where(scale[..., None] == 0, f32(0), q)
-    q = np.clip(q, 0, 15).astype(np.int16).reshape(M, N)
+    if ref_extrema:
+        q = np.where(np.isnan(q), f32(-128), q)
+        q = (np.clip(q, -128, 127).astype(np.int16) & 0xF).reshape(M, N)
+    else:
+        q = np.where(scale[..., None] == 0, f32(0), q)
+        q = np.clip(q, 0, 15).astype(np.int16).reshape(M, N)
     packed = ((q[:, 0::2] & 0xF) | ((q[:, 1::2] & 0xF) << 4)).astype(np.uint8)
     sz = np.stack([scale.astype(f16), zero.astype(f16)], axis=-1)
     return packed, sz

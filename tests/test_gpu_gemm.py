@@ -80,9 +80,10 @@ def test_config1_golden_end_to_end(golden_dir):
     assert np.linalg.norm(y - want) / np.linalg.norm(want) < 1e-3
 
 
+C5 = [(m, n, k) for (n, k) in ((5120, 5120), (13824, 5120), (5120, 13824)) for m in (1, 16, 64, 256, 2048)]   # config 5: all 15
 FULL = [(1, 4096, 4096),            # config 2
         (4096, 4096, 4096),         # config 3 (headline)
-        (16, 5120, 5120), (64, 13824, 5120), (256, 5120, 13824), (2048, 5120, 5120), (1, 13824, 5120),  # config 5
+        *C5,
         (2048, 11008, 4096), (1000, 4096, 11008)]                                                         # config 4 shapes
 
 
@@ -168,6 +169,36 @@ def test_gemm_o4_epilogue(M, N, K):
     deq = codes.reshape(M, N // 128, 128) * s[..., 0:1] - s[..., 1:2]
     ref = t2n(ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")).astype(np.float32).reshape(M, N // 128, 128)
     assert np.abs(deq - ref).max() <= 0.51 * s[..., 0].max() + 0.1
+
+
+@pytest.mark.parametrize("M,N,K,ws", [(40, 128, 640, False), (300, 384, 384, False), (40, 128, 640, True), (16, 4096, 1152, True)])
+def test_gemm_o4_reference_extrema_mode(M, N, K, ws):
+    """ATOM_O4_REF_EXTREMA: the u4 epilogue as the reference CODE computes it (extrema of |x|, 4-bit wrap;
+    DenseLayerGEMM_i4_o4.cu:73-80, :749-771), bit-exact against the oracle's restatement of that code -- on the tile kernel
+    and on the decode path -- and how far it is from the intended min / max epilogue (the default): identical on groups
+    without negative values, different codes on most elements otherwise, which is why the default does not follow it."""
+    from tests import c_oracle as C
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M + 5 * N + K)
+    d["qa4"][: M // 2] = np.abs(d["qa4"][: M // 2]); d["qa8"][: M // 2] = np.abs(d["qa8"][: M // 2].astype(np.int16)).clip(0, 127).astype(np.int8)
+    d["qb4"] = np.abs(d["qb4"]); d["qb8"] = np.abs(d["qb8"].astype(np.int16)).clip(0, 127).astype(np.int8)   # first half of the rows: sums >= 0
+    dev = to_device(d, "plain")
+    q_ref, sz_ref = ops.dense_layer_gemm_i4_o4(*dev, scale_layout="plain", use_workspace=ws, ref_extrema=True)
+    q_def, sz_def = ops.dense_layer_gemm_i4_o4(*dev, scale_layout="plain", use_workspace=ws)
+    if ws:
+        assert ops.decode_gemm_fits(M, N, K)
+        c32 = t2n(ops.dense_layer_gemm_i4_f32(*dev, scale_layout="plain"))
+    else:
+        c32 = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], fp32=True)
+    want_q, want_sz = O.quant_o4(c32, ref_extrema=True)
+    assert np.array_equal(bits16(t2n(sz_ref).reshape(M, N // 128, 2)), bits16(want_sz))
+    assert np.array_equal(t2n(q_ref), want_q)
+    h = M // 2
+    assert (c32[:h] >= 0).all() and (c32[h:] < 0).any()
+    assert torch.equal(q_ref[:h], q_def[:h]) and torch.equal(sz_ref[:h], sz_def[:h])       # no negative values: same epilogue
+    nib = lambda t: np.stack([t2n(t) & 0xF, t2n(t) >> 4], axis=-1).reshape(t.shape[0], -1)
+    differ = (nib(q_ref[h:]) != nib(q_def[h:])).mean()
+    assert differ > 0.5, differ                                                               # mixed signs: most codes differ
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (17, 1408, 2176), (64, 5120, 5120), (100, 256, 4096), (256, 5120, 1152)])
@@ -354,3 +385,42 @@ def test_gemm_f6_full_size_from_the_quantiser():
     out = ops.dense_layer_gemm_i4_fp16(f[1], ops.repack_weight_f6(b4), f[3], sb, f[0], b8, f[2], sb8,
                                        scale_layout="plain", a_wide="f6")
     assert torch.equal(out, ref)
+
+
+def _gemm_plain_entry(t, M, N, K, layout_flags):
+    """atom_gemm_w4a4_f16 itself (NO workspace): packed operands of prefill size run the INT8 MFMA tile kernels here, never the
+    F6 kernels (atom_amd.ops routes them through the workspace entry point, which re-codes to F6)."""
+    ops = _ops()
+    D = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    st = ops.L.lib().atom_gemm_w4a4_f16(*[x.data_ptr() for x in t], D.data_ptr(), M, N, K, 128, 128, layout_flags,
+                                        ops.L.current_stream(D.device))
+    ops.L.check(st, "atom_gemm_w4a4_f16")
+    return D
+
+
+# the 256x256 F6 kernel with appended fp32 weight scales (ATOM_B_F6S, "q" kernel): whole and ragged tiles, G = 1, 2, 4, 7, 31
+# int4 groups (every tail variant of its unrolled-by-3 K loop)
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (4096, 4096, 256), (4096, 4096, 384), (4096, 4096, 640),
+                                   (4096, 4096, 1024), (4000, 4096, 512), (4096, 4032, 768), (8192, 2048, 896)])
+def test_gemm_f6s_headline_kernel_vs_int8_kernel(M, N, K):
+    """Two different kernel families on the same operands, bit for bit: the F6 256x256 kernel (BF6 MFMA, weight scales as the
+    fp32 array atom_repack_weight_f6s appends) against the INT8 MFMA tile kernel behind the plain entry point -- and both against
+    the C restatement of the arithmetic contract on a sample of rows."""
+    from tests import c_oracle
+    from tests.helpers import f6_codes
+    ops = _ops()
+    d = rand_gemm_operands(M, N, K, seed=M + 3 * N + 7 * K)
+    t = to_device(d, "plain")
+    a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+    b6 = ops.repack_weight_f6(t[1], t[3])
+    assert getattr(b6, "atom_f6s", None) is not None
+    G = (K - 128) // 128
+    sb32 = b6.atom_f6s[b6.numel():].view(torch.float32).view(G, -1)
+    assert torch.equal(sb32[:, :N], t[3].float()) and not sb32[:, N:].any()              # appended scales: exact fp32 copies, pad zero
+    out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
+    int8 = _gemm_plain_entry(t, M, N, K, ops.L.SCALE_LAYOUT_PLAIN)
+    assert torch.equal(out, int8)
+    rows = np.r_[0:8, M // 2:M // 2 + 8, M - 8:M]
+    want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"])
+    assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
