@@ -199,6 +199,61 @@ def timed_steps(step, steps, warmup, sync, dist, device):
     return max_over_ranks([wall, kern_ms], dist, device)
 
 
+def block_workload(args, rank, world, dev):
+    """BASELINE configs[3]: one Llama-7B decoder block W4A4 (g128, keeper 128, KV INT4), batch 32 x seq 2048 = 65,536 tokens,
+    through atom_amd.model.qLlamaLayer.QLlamaDecoderLayer (the drop-in mirror of model/qLlamaLayer.py:86-127); every rank runs an
+    independent replica.  A step = one block forward; `value` = TOPS of the seven W4A4 GEMMs inside it (their share of the block
+    time is in the line), roofline = those GEMMs against the INT8 MFMA peak.  cpu_baseline: the same seven projections as the
+    reference computes them (F.linear on fp16 fake-quant operands) on the host at batch 1."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import block_bench
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    steps = min(args.steps, 10)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    r = block_bench.run(bsz=32, seq=2048, iters=steps, warmup=max(1, min(args.warmup, 3)), verbose=False)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    block_ms, gemm_ms = max_over_ranks([r["block_ms"], r["gemm_ms"]], dist, dev)
+    if rank == 0:
+        tops = world * r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12
+        out = {"metric": "effective TOPS of the seven W4A4 GEMMs inside one Llama-7B block (batch 32 x seq 2048, KV INT4)",
+               "value": round(tops, 2), "unit": "TOPS", "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 3)),
+               "ms_per_step": round(block_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int4xint4 exact integer dot, fp32 dequant, fp16 out; attention / RoPE / residuals fp16 (torch)",
+               "data": "synthetic",
+               "config": {"workload": "Llama-7B decoder block W4A4 g128 keeper 128, batch 32 x seq 2048, KV-cache INT4 fake-quant "
+                                      "(BASELINE configs[3]) through QLlamaDecoderLayer", "tokens": r["tokens"],
+                          "parallelism": f"replicas x{world}"},
+               "block_ms": round(block_ms, 3), "gemm_ms": round(gemm_ms, 3), "gemm_share": round(gemm_ms / block_ms, 4),
+               "module_ms": r["spans"],
+               "roofline": {"bound": "mfma", "achieved": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12, 2), "peak": PEAK_I8_TOPS,
+                            "unit": "TFLOP/s", "frac": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12 / PEAK_I8_TOPS, 4),
+                            "traffic": None, "algorithmic_ops": int(r["gemm_ops"])},
+               "timed_region_s": round(time.perf_counter() - t0, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            g = torch.Generator().manual_seed(0)
+            shapes = [(4096, 4096)] * 4 + [(11008, 4096)] * 2 + [(4096, 11008)]
+            xs = {k: (torch.randn(2048, k, generator=g) * 0.5).half() for k in (4096, 11008)}
+            ws = [(torch.randn(n, k, generator=g) * 0.05).half() for n, k in shapes]
+            from oracle import atom_oracle as O
+            t, n = _median_time(lambda: [O.sim_linear_torch(xs[w.shape[1]], w) for w in ws], 12.0, max_runs=3)
+            ops1 = 2.0 * 2048 * sum(n_ * k_ for n_, k_ in shapes)
+            out["cpu_baseline"] = {"value": round(ops1 / t / 1e12, 4), "unit": "TOPS", "cores": os.cpu_count(),
+                                   "threads": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"the seven projections of the block at batch 1 x seq 2048 as the reference computes them "
+                                             f"(F.linear on fp16 operands, torch CPU kernels), median of {n} runs, {t:.2f} s each"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +267,9 @@ def main():
     ap.add_argument("--format", choices=["f6", "packed", "wide"], default="f6",
                     help="operand format of the headline measurement (the other two are reported beside it at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["gemm", "block"], default="gemm",
+                    help="gemm = the headline GEMM (BASELINE configs[2]); block = one Llama-7B decoder block, batch 32 x seq 2048, "
+                         "KV INT4, through QLlamaDecoderLayer (BASELINE configs[3]; a step = one block forward; --steps 3 is plenty)")
     ap.add_argument("--stub-step", action="store_true",
                     help="tests only: the launch / rendezvous / timing / aggregation path on CPU (gloo) with a dummy step")
     args = ap.parse_args()
@@ -251,6 +309,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the W4A4 path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "block":
+        return block_workload(args, rank, world, dev)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -15,7 +15,8 @@ from atom_amd.model import qLlamaLayer, quant  # noqa: E402
 from atom_amd.model.qLinearLayer import QLinearLayer  # noqa: E402
 
 
-def main(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3):
+def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True):
+    """Returns dict(block_ms, gemm_ms, gemm_tops, spans={module: ms}) -- also what `bench.py --workload block` reports."""
     args = types.SimpleNamespace(wbits=4, abits=4, a_sym=True, w_sym=True, act_group_size=128, weight_group_size=128,
                                  weight_channel_group=2, keeper=128, keeper_precision=3, a_clip_ratio=0.9,
                                  w_clip_ratio=0.85, kv_clip_ratio=1.0, tiling=0, exponential=False, quant_type="int",
@@ -47,7 +48,8 @@ def main(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3):
         if type(mod) is QLinearLayer or name in ("input_layernorm", "post_attention_layernorm"):
             timed(name, mod)
     with torch.no_grad():
-        m(x, attention_mask=mask, position_ids=pos)            # warm-up (packs nothing: quant() already packed)
+        for _ in range(max(warmup, 1)):
+            m(x, attention_mask=mask, position_ids=pos)        # warm-up (packs nothing: quant() already packed)
         torch.cuda.synchronize()
         spans.clear()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,19 +59,25 @@ def main(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3):
         e1.record()
         torch.cuda.synchronize()
     total = e0.elapsed_time(e1) / iters
-    print(f"BLOCK batch={bsz} seq={seq} hidden={hidden} inter={inter}: {total:.2f} ms per block forward", flush=True)
+    if verbose:
+        print(f"BLOCK batch={bsz} seq={seq} hidden={hidden} inter={inter}: {total:.2f} ms per block forward", flush=True)
     gemm = 0.0
+    per = {}
     for name, evs in spans.items():
         ms = sum(a.elapsed_time(b) for a, b in evs) / iters
-        print(f"  {name:28s} {ms:8.3f} ms")
+        per[name] = round(ms, 4)
+        if verbose:
+            print(f"  {name:28s} {ms:8.3f} ms")
         if "proj" in name:
             gemm += ms
     M = bsz * seq
     ops = 2.0 * M * (4 * hidden * hidden + 3 * hidden * inter)
-    print(f"  seven W4A4 GEMMs: {gemm:.2f} ms = {ops / gemm / 1e9:.0f} TOPS; rest (attention in torch, KV fake-quant, RoPE, "
-          f"residuals): {total - gemm:.2f} ms")
+    if verbose:
+        print(f"  seven W4A4 GEMMs: {gemm:.2f} ms = {ops / gemm / 1e9:.0f} TOPS; rest (attention in torch, KV fake-quant, RoPE, "
+              f"residuals): {total - gemm:.2f} ms")
+    return {"block_ms": total, "gemm_ms": gemm, "gemm_ops": ops, "gemm_tops": ops / gemm / 1e9, "spans": per, "tokens": M}
 
 
 if __name__ == "__main__":
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    main(bsz=b)
+    run(bsz=b)
