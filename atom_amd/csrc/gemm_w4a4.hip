@@ -43,16 +43,25 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   return N * items <= 420000;
 }
 
-// Tile geometry of the F6 kernels by shape (measured: profiles/r01_f6_dispatch.txt).  256x256 (one workgroup per CU) when
-// the tiles fill whole rounds of the 256 CUs; else 128x128 (three workgroups per CU) while that yields >= 256 tiles (>= 128
-// for short K); else 64x128, which splits K when the caller passes a workspace.
+// Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt).  256x256 (one workgroup per CU, the q kernel)
+// when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles' work in
+// ~2.4x their time; else 128x128 (three workgroups per CU); 64x128 + split-K only for very few tiles with a long K.
 static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   const int force = ATOM_TUNE("ATOM_F6_CFG", -1);
   if (force >= 0) return force;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
-  if (t256 >= 256 && 5 * t256 >= 4 * ((t256 + 255) / 256) * 256) return 0;
-  if (t128 >= 256 || (t128 >= 128 && K_total <= 6144)) return 3;
+  const int64_t rounds = (t256 + 255) / 256;
+  if (t256 >= 144 && 5 * t256 >= 3 * rounds * 256) return 0;
+  if (t128 >= 128 || K_total <= 8192) return 3;
   return 2;
+}
+// K splits of the 128x128 geometry (needs the caller's workspace): two when the tiles fill at most a sixth of the 768 slots, or
+// less than a third with a long K (512x4096x11008: 78.8 -> 51.9 us, 768x...: 79.0 -> 62.3; 768x4096x4096: 32.5 vs 34.0 -> none)
+static int f6_splits_128(int64_t M, int64_t N, int64_t K_total) {
+  const int s3 = ATOM_TUNE("ATOM_F6_SPLITS3", 0);
+  if (s3 > 0) return s3;
+  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  return (t128 <= 144 || (K_total > 8192 && t128 < 256)) ? 2 : 1;
 }
 
 extern "C" {
@@ -231,11 +240,8 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.splits = choose_splits(M, N, K_total);
   if (p.f6_rows_a) {
     const int cfg = f6_pick_cfg(M, N, K_total);
-    if (cfg == 3) {   // 128x128: two K splits when the tiles fill a sixth of the 768 slots (512x4096x4096: 28.7 -> 26.3 us;
-                      // 768x4096x4096 and 256x11008x4096 gain nothing)
-      const int s3 = ATOM_TUNE("ATOM_F6_SPLITS3", 0);
-      const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
-      int sp = s3 > 0 ? s3 : (t128 <= 144 ? 2 : 1);
+    if (cfg == 3 || cfg == 4) {
+      int sp = f6_splits_128(M, N, K_total);
       if (sp > p.splits) sp = p.splits;                      // the workspace was sized for choose_splits()
       p.splits = sp;
       if (sp < 2) p.ws = nullptr;

@@ -58,9 +58,9 @@ struct Cfg {
   // The LDS-DMA instructions are issued by the first NDW waves.
   static constexpr int NDW = NW;   // (measured: NW / 2 -- only the older wave of each SIMD issuing -- is 6 % slower)
   static constexpr int GLDS = ((NPIECE > NKP ? NPIECE : NKP) + NDW - 1) / NDW;  // per issuing wave, padded with repeats
-  static constexpr int EP_BYTES = NW * 64 * 144;
+  static constexpr int EP_BYTES = NW * (WM < 64 ? WM : 64) * 144;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES > EP_BYTES ? NS * STAGE_BYTES : EP_BYTES;
-  static_assert(BN % 128 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 2 || TM == 4) && NS >= 2, "geometry");
+  static_assert(BN % 128 == 0 && BM % 64 == 0 && BM % WM == 0 && (TM == 1 || TM == 2 || TM == 4) && NS >= 2, "geometry");
   static_assert(KP_SA_OFF + BM * 4 <= SB_OFF && LDS_BYTES <= 160 * 1024, "stage layout");
 };
 
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NS = C::NS;
   constexpr int NTB = C::WM / 16;
-  static_assert(C::WM % 64 == 0 && NS >= 2, "x16: wave tiles of 64 features x 64 or 128 tokens");
+  static_assert(C::WM % 32 == 0 && NS >= 2, "x16: wave tiles of 64 features x 32, 64 or 128 tokens");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -637,14 +637,15 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
     }
     return;
   }
-  // epilogue: per wave [64 tokens][64 features] fp16 through LDS (row stride 144 B), halves of 64 tokens
+  // epilogue: per wave [HT tokens][64 features] fp16 through LDS (row stride 144 B), HT = 64 (32 for the 32-token wave tile)
   constexpr int EP_STRIDE = 144;
-  char *ep = lds + wave * (64 * EP_STRIDE);
+  constexpr int HT = C::WM < 64 ? C::WM : 64;
+  char *ep = lds + wave * (HT * EP_STRIDE);
 #pragma unroll
-  for (int half = 0; half < C::WM / 64; ++half) {
+  for (int half = 0; half < C::WM / HT; ++half) {
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      const int tb = half * 4 + t4;
+    for (int t4 = 0; t4 < HT / 16; ++t4) {
+      const int tb = half * (HT / 16) + t4;
 #pragma unroll
       for (int fb = 0; fb < 4; ++fb) {
         v2u o;
@@ -655,11 +656,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < HT / 8; ++i) {
       const int rl = i * 8 + (lane >> 3);
       const int ch = lane & 7;
       const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
-      const int m = m0 + wm * C::WM + half * 64 + rl;
+      const int m = m0 + wm * C::WM + half * HT + rl;
       const int n = n0 + wn * 64 + ch * 8;
       if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
     }
@@ -1450,6 +1451,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
   }
   if (cfg == 40) return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // tuning: 256x256, first-generation micro-tile kernel
+  if (cfg == 4) {                                                              // 128x128, 8 waves of 64 features x 32 tokens
+    if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 1, 2, 3>, true>(p, s);
+    return f6::launch_x16<f6::Cfg<128, 128, 1, 2, 3>>(p, s);
+  }
   if (cfg == 30 || !p.sB32) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);   // 256x256, pipelined across K steps (fp16 weight scales)
   return f6::launch_q<f6::Cfg<256, 256, 4, 3>>(p, s);                          // ... third generation (ATOM_B_F6S; the headline)
 }
