@@ -52,12 +52,14 @@ SIGNATURES = {
     "atom_pack_weight_w4": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "atom_f6_rows": (ctypes.c_size_t, [_i64]),
     "atom_repack_weight_f6": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "atom_repack_act_f6": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "atom_f6_weight_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "atom_repack_weight_f6s": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "atom_kv_fake_quant_f16": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "atom_kv_append_i4": (_int, [_vp] * 10 + [_i64] + [_int] * 6 + [_vp]),
     "atom_kv_quant_append_f32": (_int, [_vp] * 7 + [_int] * 6 + [_vp]),
     "atom_gemm_w4a4_f32": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
+    "atom_gemm_w4a4_silu_mul_quant_f6": (_int, [_vp] * 6 + [_i64, _i64, _i64, _int, _int, _int, _f32, _int] + [_vp] * 6),
     "atom_batch_decode_i4_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _int]),
     "atom_batch_decode_i4": (_int, [_vp] * 7 + [_int] * 6 + [_f32, _f32, _int, _vp, ctypes.c_size_t, _vp]),
 }

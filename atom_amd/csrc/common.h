@@ -52,6 +52,19 @@ __host__ __device__ __forceinline__ int64_t ref_scale_size(int64_t x) {
   return x / 16 * 64 + 64 - (1 - (x % 16) / 8) * (8 - (x % 8)) * 8;
 }
 
+// Outputs of the fused gate/up epilogue (gemm_w4a4_f6.hip, q kernel with GU != 0): quant(silu(gate) * up) per token and
+// 128-feature group, written as the next GEMM's F6 activation operand
+struct GateUpOut {
+  uint8_t *o6;       // F6 activation buffer [N_inter / 128 - 1][o6_rows][104]
+  int64_t o6_rows;   // atom_f6_rows(M)
+  int8_t *o8;        // keeper codes [M, 128]
+  half_t *s8, *s4;   // keeper scales, group scales (layout per ref_layout; ld4 halves between groups)
+  int64_t ld4;
+  half_t *xq;        // optional: the fake-quantised activation fp16 [M, N_inter]
+  float clip;
+  int ref_layout;
+};
+
 struct GemmParams {
   const uint8_t *A4, *B4;
   const half_t *sA, *sB;
@@ -70,6 +83,7 @@ struct GemmParams {
   int64_t ldA;      // halves between groups of sA
   int64_t f6_rows_a, f6_rows_b;   // F6 operand format: padded rows per group of A4 / B4 (gemm_w4a4_f6.hip)
   int o4_ref;                     // ATOM_O4_REF_EXTREMA: the u4 epilogue with the reference code's |x| extrema and 4-bit wrap
+  GateUpOut gu;                   // fused gate/up epilogue (launch_gemm_f6_gateup only)
   const float *sB32;              // ATOM_SB_F32: weight scales float32 [G][f6_rows_b] (then sB is not read by the 256x256 kernel)
 };
 
@@ -81,6 +95,7 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
+int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s);   // ... 256x256 kernel + fused SiLU x up -> quant epilogue
 
 // quant_kernels.hip: packed operand (+ scales) -> F6 buffer [G][round_up(rows, 256)][104]
 int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,

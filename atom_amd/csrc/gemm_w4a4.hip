@@ -307,4 +307,39 @@ int atom_gemm_w4a4_o4_ws(const void *A4, const void *B4, const void *sA, const v
                            stream);
 }
 
+int atom_gemm_w4a4_silu_mul_quant_f6(const void *A_f6, const void *Bgu_f6s, const void *A8, const void *Bgu8, const void *sA8,
+                                     const void *sBgu8, int64_t M, int64_t N_inter, int64_t K_total, int group, int keeper,
+                                     int quant_mode, float clip, int scale_layout, void *o_outliers, void *o_norms_f6,
+                                     void *outlier_scales, void *norm_scales, void *xq, void *stream) {
+  if (!A_f6 || !Bgu_f6s || !A8 || !Bgu8 || !sA8 || !sBgu8 || !o_outliers || !o_norms_f6 || !outlier_scales || !norm_scales)
+    return ATOM_ERR_INVALID_ARG;
+  if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
+  if (quant_mode != ATOM_QUANT_KERNEL && quant_mode != ATOM_QUANT_SIM) return ATOM_ERR_INVALID_ARG;
+  if (!(clip > 0.f) || clip > 1.f) return ATOM_ERR_INVALID_ARG;
+  if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
+  if (M < 1 || M > (1 << 24) || N_inter < 256 || (N_inter % 128) != 0 || N_inter > (1 << 23) || K_total < 256 ||
+      ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20))
+    return ATOM_ERR_SHAPE;
+  if (!aligned16(A_f6) || !aligned16(Bgu_f6s) || !aligned16(A8) || !aligned16(Bgu8) || !aligned16(o_outliers) ||
+      !aligned16(o_norms_f6) || (xq && !aligned16(xq)) || (reinterpret_cast<uintptr_t>(sBgu8) & 3u))
+    return ATOM_ERR_ALIGN;
+  GemmParams p{};
+  const int64_t N = 2 * N_inter;
+  p.A4 = (const uint8_t *)A_f6; p.B4 = (const uint8_t *)Bgu_f6s;
+  p.A8 = (const uint8_t *)A8;   p.B8 = (const uint8_t *)Bgu8;
+  p.sA8 = (const half_t *)sA8;  p.sB8 = (const half_t *)sBgu8;
+  p.splits = 1;
+  p.M = (int)M; p.N = (int)N;
+  p.K4h = (int)((K_total - kKeeper) / 2);
+  p.G = (int)((K_total - kKeeper) / kGroup);
+  p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
+  p.f6_rows_a = (M + 255) / 256 * 256;
+  p.f6_rows_b = (N + 255) / 256 * 256;                       // == N: N_inter is a multiple of 128
+  p.sB32 = reinterpret_cast<const float *>((const uint8_t *)Bgu_f6s + (size_t)p.G * (size_t)p.f6_rows_b * 104);
+  p.ldA = (int64_t)atom_scale_size(M, scale_layout);
+  p.gu = GateUpOut{(uint8_t *)o_norms_f6, p.f6_rows_a, (int8_t *)o_outliers, (half_t *)outlier_scales, (half_t *)norm_scales,
+                   p.ldA, (half_t *)xq, clip, p.ref_layout};
+  return launch_gemm_f6_gateup(p, quant_mode == ATOM_QUANT_SIM, reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

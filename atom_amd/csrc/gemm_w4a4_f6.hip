@@ -19,6 +19,7 @@
 // results are bit-identical to the INT8 kernels.
 #include <type_traits>
 #include "common.h"
+#include "quant_math.h"
 
 namespace atom {
 
@@ -1202,7 +1203,12 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
   }
 }
 
-template <class C>
+// GU != 0: the weight rows are gate_proj / up_proj interleaved per wave (32 gate features, then the same 32 up features), so a
+// lane ends the K loop with gate and up of the SAME (token, feature) pairs, and the epilogue is the reference's next two ops --
+// act_fn(gate) * up and the per-token group quantiser (model/qLlamaLayer.py:345-351; punica/models/llama.py:85-87 ->
+// Activate.cuh:67-180) -- writing the F6 activation operand of down_proj directly (GU = 1: simulated-path arithmetic, 2: the CUDA
+// kernels').  Bit-identical to fp16 GEMMs + atom_silu_mul_quant_f16; saves writing and re-reading 2 x M x N_inter fp16.
+template <class C, int GU = 0>
 __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3 && C::NW == 8, "q kernel: 256x256, 8 waves of 64 x 128");
@@ -1336,6 +1342,90 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   __builtin_amdgcn_s_barrier();
   p_keeper<C>(slot_of(G + 1), wm, wn, lane, c);
 
+  if constexpr (GU != 0) {
+    constexpr bool SIM = GU == 1;
+    // c[0..1] = gate, c[2..3] = up of features 8 kb + 2 r + (fb & 1) of this wave's 32 (of the tile's 128 = ONE quantisation group)
+    float *am = reinterpret_cast<float *>(lds + ((G + 2) % 3) * Q::STAGE);   // [8 waves][128 tokens]: a slot nobody reads any more
+#pragma unroll
+    for (int tb = 0; tb < 8; ++tb) {
+      float mx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float h = silu_mul<SIM>((float)f2h(c[k][tb][r]), (float)f2h(c[2 + k][tb][r]));   // on the fp16 GEMM outputs
+          c[k][tb][r] = h;
+          mx = fmaxf(mx, fabsf(h));
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (kb == 0) am[wave * 128 + p_row(tb) + 2 * l15] = mx;
+    }
+    __syncthreads();
+    const bool keeper_blk = bn == nbn - 1;                  // the last 128 features: INT8 keeper columns
+    const GateUpOut &o = p.gu;
+    const int N_inter = p.N >> 1;
+#pragma unroll
+    for (int tb = 0; tb < 8; ++tb) {
+      const int t = p_row(tb) + 2 * l15;
+      const float *ap = am + wm * 4 * 128 + t;
+      const float amax = fmaxf(fmaxf(ap[0], ap[128]), fmaxf(ap[256], ap[384]));
+      const GroupScale gs = group_scale<SIM>(amax, keeper_blk, o.clip);
+      float tr[8];                                          // feature 8 kb + j: j = 2 r + k
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[2 * r + k] = group_code<SIM>(c[k][tb][r], gs);
+      const int64_t m = m0 + wm * 128 + t;
+      if (m >= p.M) continue;
+      const half_t sh = f2h(gs.s_store);
+      if (keeper_blk) {
+        const float lo = __builtin_fmaf(tr[1], 256.f, tr[0] + 32896.f), hi = __builtin_fmaf(tr[3], 256.f, tr[2] + 32896.f);
+        const float lo2 = __builtin_fmaf(tr[5], 256.f, tr[4] + 32896.f), hi2 = __builtin_fmaf(tr[7], 256.f, tr[6] + 32896.f);
+        const v2u w = v2u{((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u, ((unsigned)lo2 | ((unsigned)hi2 << 16)) ^ 0x80808080u};
+        *reinterpret_cast<v2u *>(o.o8 + m * kKeeper + wn * 32 + kb * 8) = w;
+      } else {
+        typedef float v16f __attribute__((ext_vector_type(16)));
+        typedef unsigned v6u __attribute__((ext_vector_type(6)));
+        v16f ea, eb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          ea[i] = i < 4 ? tr[2 * i] : 0.f;
+          eb[i] = i < 4 ? tr[2 * i + 1] : 0.f;
+        }
+        const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);   // fields 0..7 = my 8 codes: 48 bits
+        uint8_t *dst = o.o6 + ((int64_t)bn * o.o6_rows + m) * PITCH;
+        uint8_t *d6 = dst + wn * 24 + kb * 6;               // 2-byte aligned: 4 + 2 or 2 + 4 byte stores
+        if ((kb & 1) == 0) {
+          *reinterpret_cast<unsigned *>(d6) = f[0];
+          *reinterpret_cast<unsigned short *>(d6 + 4) = (unsigned short)f[1];
+        } else {
+          *reinterpret_cast<unsigned short *>(d6) = (unsigned short)f[0];
+          *reinterpret_cast<unsigned *>(d6 + 2) = (f[0] >> 16) | (f[1] << 16);
+        }
+        if (wn == 0 && kb == 0)                             // the next GEMM reads the token scale from the row: fp16 + fp32
+          *reinterpret_cast<v2u *>(dst + 96) = v2u{(unsigned)__builtin_bit_cast(unsigned short, sh), __builtin_bit_cast(unsigned, (float)sh)};
+      }
+      if (wn == 0 && kb == 0) {
+        half_t *sd = keeper_blk ? o.s8 : (o.s4 + (int64_t)bn * o.ld4);
+        if (o.ref_layout) {
+          const int base = ref_scale_index((int)m);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sd[base + 2 * k] = sh;
+        } else {
+          sd[m] = sh;
+        }
+      }
+      if (o.xq) {                                           // code * scale, exact in FP32, one rounding (see quant_kernels.hip)
+        v4u q;
+        half_t *qv = reinterpret_cast<half_t *>(&q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (half_t)__builtin_fmaf(tr[j], gs.s_dq, 0.0f);
+        *reinterpret_cast<v4u *>(o.xq + m * N_inter + bn * 128 + wn * 32 + kb * 8) = q;
+      }
+    }
+    return;
+  }
   // epilogue: a lane holds 8 consecutive features per token and feature-block pair -> one 16-byte store each
 #pragma unroll
   for (int tb = 0; tb < 8; ++tb) {
@@ -1357,12 +1447,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   }
 }
 
-template <class C>
+template <class C, int GU = 0>
 static int launch_q(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C, GU>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C, GU>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
   return check_launch();
 }
 
@@ -1406,6 +1496,10 @@ static int launch(const GemmParams &p, hipStream_t s) {
 }
 
 }  // namespace f6
+
+int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s) {
+  return sim ? f6::launch_q<f6::Cfg<256, 256, 4, 3>, 1>(p, s) : f6::launch_q<f6::Cfg<256, 256, 4, 3>, 2>(p, s);
+}
 
 // cfg: 0 = 256x256 (8 waves, the pipelined kernel) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA
 // micro-tiles, 2 = 64x128 (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128,

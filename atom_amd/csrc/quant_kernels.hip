@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "quant_math.h"
 
 namespace atom {
 
@@ -75,49 +76,11 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
 #pragma unroll
   for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
   amax = max8(amax);
-  const float qmax = keeper ? 127.f : 7.f, qlo = keeper ? -128.f : -8.f;
-  const float c = keeper ? 1.0f : p.clip;
+  const GroupScale gs = group_scale<SIM>(amax, keeper, p.clip);
   float tr[16];
-  float s_store, s_dq;
-  if constexpr (SIM) {
-    amax = fmaxf(amax, (float)(half_t)1e-5f);               // quant.py:141-142
-    if (c < 1.0f) amax = round_h(amax * c);                 // :168-169
-    // amax / qmax and w / scales: correctly rounded FP32 quotients from  q1 = fma(fma(-q0,d,n), r, q0), q0 = n*r,
-    // r = RN(1/d) -- exact for every finite fp16 n and positive fp16 d (tools/probes/div_probe.cpp; 7 and 127 are fp16)
-    const float rq = keeper ? (1.0f / 127.0f) : (1.0f / 7.0f);
-    const float a0 = opaque(amax);
-    const float d0 = a0 * rq;
-    const float s = round_h(__builtin_fmaf(__builtin_fmaf(-d0, qmax, a0), rq, d0));   // :170
-    const float so = opaque(s);
-    // RN(1/s) from v_rcp_f32 + one Newton step: equal to the IEEE quotient for every positive fp16 s (round_probe.cpp)
-    const float r0 = __builtin_amdgcn_rcpf(so);
-    const float rs = __builtin_fmaf(__builtin_fmaf(-r0, so, 1.0f), r0, r0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float q0 = v[i] * rs;
-      const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, so, v[i]), rs, q0);
-      // :181 clamp(round(w / scales)): clamp first (bounds are integers), then round half-to-even
-      tr[i] = rintf(__builtin_amdgcn_fmed3f(round_h(q1), qlo, qmax));
-    }
-    s_store = s;
-    s_dq = s;
-  } else {
-    // Reorder.cuh:137-178
-    if (c < 1.0f) amax = amax * c;
-    const float sf = amax / qmax;
-    const float rr = sf != 0.f ? 1.0f / sf : 0.f;           // all-zero group: codes 0 (0*inf = NaN in the reference)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float t = __builtin_amdgcn_fmed3f(v[i] * rr, qlo, qmax);
-      // round half away from zero (CUDA round()) = sign(t) * floor(|t| + 0.5): v_cvt_rpi_i32_f32 computes
-      // floor(x + 0.5) exactly (checked for every fp32 in [0, 300), tools/probes/round_probe.cpp)
-      int ri;
-      asm("v_cvt_rpi_i32_f32 %0, |%1|" : "=v"(ri) : "v"(t));
-      tr[i] = __builtin_copysignf((float)ri, t);
-    }
-    s_store = sf;
-    s_dq = round_h(sf);
-  }
+  for (int i = 0; i < 16; ++i) tr[i] = group_code<SIM>(v[i], gs);
+  const float s_store = gs.s_store, s_dq = gs.s_dq;
 
   if (keeper) {
     unsigned w[4];
@@ -374,16 +337,7 @@ __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
     float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const float a = (float)av[k];
-      // Activate.cuh:28  x / (1 + expf(-x)) with the hardware exp2 / rcp (1 ulp each): 5 instructions instead of ~20;
-      // expf differs by ulps between libraries anyway (the parity tests allow codes +-1 on < 0.2 % of the elements)
-      const float e = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
-      const float s = a * __builtin_amdgcn_rcpf(1.0f + e);
-      if constexpr (SIM) {
-        v[k] = round_h(round_h(s) * (float)bv[k]);          // act_fn(gate) * up, both in half
-      } else {
-        v[k] = s * (float)bv[k];                            // kept in FP32 (Activate.cuh:103-106)
-      }
+      v[k] = silu_mul<SIM>((float)av[k], (float)bv[k]);
     }
     const int g = slot >> 3;
     quant_slot<SIM, DQ>(v, p, r, g, tid & 7, e0, g == Gt - 1, K4h);
@@ -926,6 +880,16 @@ int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6
   if (!aligned16(B4) || !aligned16(B_f6)) return ATOM_ERR_ALIGN;
   return launch_repack_f6((const uint8_t *)B4, N, (int)((K_total - kKeeper) / 2), (int)((K_total - kKeeper) / kGroup), nullptr, 0,
                           0, (uint8_t *)B_f6, reinterpret_cast<hipStream_t>(stream));
+}
+
+int atom_repack_act_f6(const void *A4, const void *sA, int64_t M, int64_t K_total, int scale_layout, void *A_f6, void *stream) {
+  if (!A4 || !sA || !A_f6) return ATOM_ERR_INVALID_ARG;
+  if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
+  if (M < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if (!aligned16(A4) || !aligned16(A_f6)) return ATOM_ERR_ALIGN;
+  return launch_repack_f6((const uint8_t *)A4, M, (int)((K_total - kKeeper) / 2), (int)((K_total - kKeeper) / kGroup), (const half_t *)sA,
+                          (int64_t)atom_scale_size(M, scale_layout), scale_layout == ATOM_SCALE_LAYOUT_REF, (uint8_t *)A_f6,
+                          reinterpret_cast<hipStream_t>(stream));
 }
 
 size_t atom_f6_weight_bytes(int64_t N, int64_t K_total) {

@@ -54,8 +54,26 @@ class LinearInt4(nn.Module):
         self.scale_int8.data = s8
         return self
 
+    def packed(self):
+        """(b4, b8, sb [G, N], sb8 [N]) views of the parameters (the scale parameters are over-allocated like the reference's)."""
+        n, g = self.out_features, self.in_features // GROUP - 1
+        return (self.weight_int4.data, self.weight_int8.data, self.scale_int4.data.reshape(-1)[: g * n].view(g, n),
+                self.scale_int8.data.reshape(-1)[:n])
+
+    def weight_f6s(self):
+        """The weight in the F6 format with appended fp32 scales, made once per packed weight (prefill batches in the F6 format)."""
+        key = (self.weight_int4.data_ptr(), self.weight_int4._version, self.scale_int4.data_ptr(), self.scale_int4._version)
+        if getattr(self, "_f6s", None) is None or self._f6s[0] != key:
+            b4, _, sb, _ = self.packed()
+            self._f6s = (key, ops.repack_weight_f6(b4, sb.contiguous()))
+        return self._f6s[1]
+
     def forward(self, input):
         outlier, norms, outlier_scales, norm_scales = input
+        if norms.dim() == 3:                                  # the F6 activation operand [G][rows_pad][104] (fp16 output only)
+            assert self.out_dtype == "fp16"
+            return ops.dense_layer_gemm_i4_fp16(norms, self.weight_f6s(), norm_scales, self.scale_int4, outlier, self.weight_int8,
+                                                outlier_scales, self.scale_int8, a_wide="f6")
         f = {"int4": ops.dense_layer_gemm_i4_o4, "fp16": ops.dense_layer_gemm_i4_fp16}[self.out_dtype]
         return f(norms, self.weight_int4, norm_scales, self.scale_int4, outlier, self.weight_int8, outlier_scales,
                  self.scale_int8)
@@ -97,7 +115,23 @@ class LlamaMLP(nn.Module):
         self.up_proj = LinearInt4(self.hidden_size, self.intermediate_size, out_dtype="fp16", bias=False)
         self.down_proj = LinearInt4(self.intermediate_size, self.hidden_size, out_dtype="fp16", bias=False)
 
+    FUSED_MIN_ROWS = 512          # the fused launch always runs the 256x256 geometry
+
+    def _fused_gate_up(self):
+        key = tuple(t.data_ptr() for t in (self.gate_proj.weight_int4, self.up_proj.weight_int4)) + \
+            tuple(t._version for t in (self.gate_proj.weight_int4, self.up_proj.weight_int4, self.gate_proj.scale_int4, self.up_proj.scale_int4))
+        if getattr(self, "_fused", None) is None or self._fused[0] != key:
+            self._fused = (key, ops.fuse_gate_up_weights(self.gate_proj.packed(), self.up_proj.packed()))
+        return self._fused[1]
+
     def forward(self, x):
+        outlier, norms, outlier_scales, norm_scales = x
+        if outlier.size(0) >= self.FUSED_MIN_ROWS and self.intermediate_size % GROUP == 0:
+            # prefill batches: gate_proj + up_proj + activate_fp16_i4 in ONE launch, bit-identical to the three
+            # launches below; the activation is re-coded to the F6 operand once (the two GEMMs would each do it in their workspace)
+            a6 = norms if norms.dim() == 3 else ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
+            act = ops.gate_up_silu_quant_f6(a6, outlier, outlier_scales, self._fused_gate_up())
+            return self.down_proj(act)
         return self.down_proj(ops.activate_fp16_i4(self.gate_proj(x), self.up_proj(x)))
 
 

@@ -21,7 +21,7 @@ from torch import nn
 
 from .. import ops as _ops
 from .qLinearLayer import QLinearLayer
-from .quant import (ActCodes, Quantizer, _reorder_index_i16, attach_codes, hip_act_quant,  # noqa: F401
+from .quant import (ActCodes, Quantizer, _reorder_index_i16, attach_codes, get_codes, hip_act_quant,  # noqa: F401
                     want_wide_codes)
 
 
@@ -269,8 +269,34 @@ class QLlamaMLP(nn.Module):
         f = self.act_fn
         return isinstance(f, nn.SiLU) or type(f).__name__ in ("SiLUActivation", "SiLU") or f is nn.functional.silu
 
+    FUSED_MIN_ROWS = 512          # the fused launch always runs the 256x256 geometry
+
+    def _fused_gate_up(self):
+        """The interleaved gate/up weight operand of gate_up_silu_quant_f6, cached per packed form of the two layers."""
+        pg, pu = self.gate_proj.packed_weight(), self.up_proj.packed_weight()
+        if pg is None or pu is None or self.gate_proj.bias is not None or self.up_proj.bias is not None:
+            return None
+        key = (self.gate_proj._packed_key, self.up_proj._packed_key)
+        if getattr(self, "_fused", None) is None or self._fused[0] != key:
+            self._fused = (key, _ops.fuse_gate_up_weights(pg, pu))
+        return self._fused[1]
+
     @torch.no_grad()
     def forward(self, x):
+        inter = self.gate_proj.weight.shape[0]
+        hot = self.act_quant.hot_args(inter)
+        codes = get_codes(x)
+        if (hot is not None and codes is not None and codes.wide == "f6" and codes.rows >= self.FUSED_MIN_ROWS and x.is_cuda
+                and self._act_is_silu() and codes.hidden == self.gate_proj.weight.shape[1] and inter % 128 == 0):
+            fused = self._fused_gate_up()
+            if fused is not None:
+                # gate_proj, up_proj, act_fn(gate) * up and the quantiser in one launch (SURVEY 8(f) N4): bit-identical to the path below
+                o8, o6, s8, s4, xq = _ops.gate_up_silu_quant_f6(codes.o4, codes.o8, codes.s8, fused, quant_mode="sim",
+                                                                clip=float(hot.a_clip_ratio), scale_layout=codes.layout,
+                                                                return_dequant=True)
+                act = attach_codes(xq.view(*x.shape[:-1], inter), ActCodes(o8, o6, s8, s4, codes.rows, inter, layout=codes.layout,
+                                                                          wide="f6"))
+                return self.down_proj(act)
         gate = self.gate_proj(x)
         up = self.up_proj(x)
         inter = gate.shape[-1]

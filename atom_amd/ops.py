@@ -395,3 +395,54 @@ def repack_weight_f6(b4: torch.Tensor, b_scale: torch.Tensor = None) -> torch.Te
                                         L.current_stream(b4.device))
     L.check(st, "atom_repack_weight_f6")
     return out
+
+
+def repack_act_f6(a4: torch.Tensor, a_scale: torch.Tensor, *, scale_layout="ref") -> torch.Tensor:
+    """Packed INT4 activations [M, K4/2] + scales -> the F6 activation operand [G][f6_rows(M)][104] (atom_repack_act_f6)."""
+    if not a4.is_cuda:
+        raise L.AtomHipError("repack_act_f6 needs a GPU tensor: no CPU fallback")
+    m, k4h = a4.shape
+    out = torch.empty((k4h // 64, f6_rows(m), L.F6_PITCH), dtype=torch.uint8, device=a4.device)
+    st = L.lib().atom_repack_act_f6(a4.data_ptr(), a_scale.data_ptr(), m, k4h * 2 + GROUP_SIZE, _LAYOUTS[scale_layout], out.data_ptr(),
+                                    L.current_stream(a4.device))
+    L.check(st, "atom_repack_act_f6")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- fused gate / up (SURVEY 8(f) N4)
+def fuse_gate_up_weights(gate, up):
+    """(b4 u8 [N, K4/2], b8 i8 [N, 128], sb f16 [G, N], sb8 f16 [N]) of gate_proj and of up_proj -> the fused weight operand of
+    gate_up_silu_quant_f6: rows interleaved per 128-feature block and 32-feature quarter (32 gate rows, then the same 32 up rows),
+    codes + float32 scales in the F6 format (atom_repack_weight_f6s).  Offline, once per layer.  Returns a dict."""
+    b4g, b8g, sbg, sb8g = gate
+    b4u, b8u, sbu, sb8u = up
+    n = b4g.shape[0]
+    assert b4u.shape == b4g.shape and n % GROUP_SIZE == 0 and n >= 2 * GROUP_SIZE
+    dev = b4g.device
+    q = torch.arange(n, device=dev).view(n // 128, 4, 32)                                   # [block, quarter, 32 features]
+    idx = torch.stack([q, q + n], dim=2).reshape(-1)                                        # gate rows, then the same up rows
+    b4 = torch.cat([b4g.view(torch.uint8), b4u.view(torch.uint8)], 0).index_select(0, idx).contiguous()
+    b8 = torch.cat([b8g, b8u], 0).index_select(0, idx).contiguous()
+    g = sbg.numel() // n
+    sb = torch.cat([sbg.reshape(g, n), sbu.reshape(g, n)], 1).index_select(1, idx).contiguous()
+    sb8 = torch.cat([sb8g.reshape(-1), sb8u.reshape(-1)], 0).index_select(0, idx).contiguous()
+    return {"b6s": repack_weight_f6(b4, sb), "b8": b8, "sb8": sb8, "n_inter": n, "k": b4g.shape[1] * 2 + GROUP_SIZE}
+
+
+def gate_up_silu_quant_f6(a6, a_keeper, a_keeper_scale, fused, *, quant_mode="kernel", clip=1.0, scale_layout="ref",
+                          return_dequant=False):
+    """quant(silu(x Wg^T) * (x Wu^T)) in one launch, from the F6 activation operand of x straight to the F6 activation operand of
+    down_proj: the reference's gate_proj, up_proj and activate_fp16_i4 (punica/models/llama.py:85-87) -- same return tuple as
+    activate_fp16_i4(..., wide_codes="f6"), bit-identical to it on the fp16 GEMM outputs."""
+    m = a_keeper.size(0)
+    n, k = fused["n_inter"], fused["k"]
+    assert a6.shape == (k // GROUP_SIZE - 1, f6_rows(m), L.F6_PITCH)
+    outs = _alloc_act_outputs(m, n, a6.device, scale_layout, return_dequant, "f6")
+    b6s = fused["b6s"]
+    st = L.lib().atom_gemm_w4a4_silu_mul_quant_f6(a6.data_ptr(), b6s.atom_f6s.data_ptr(), a_keeper.data_ptr(), fused["b8"].data_ptr(),
+                                                  a_keeper_scale.data_ptr(), fused["sb8"].data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
+                                                  _MODES[quant_mode], float(clip), _LAYOUTS[scale_layout], outs[0].data_ptr(),
+                                                  outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
+                                                  L.current_stream(a6.device))
+    L.check(st, "atom_gemm_w4a4_silu_mul_quant_f6")
+    return _ret(*outs)

@@ -202,8 +202,8 @@ def timed_steps(step, steps, warmup, sync, dist, device):
 def block_workload(args, rank, world, dev):
     """BASELINE configs[3]: one Llama-7B decoder block W4A4 (g128, keeper 128, KV INT4), batch 32 x seq 2048 = 65,536 tokens,
     through atom_amd.model.qLlamaLayer.QLlamaDecoderLayer (the drop-in mirror of model/qLlamaLayer.py:86-127); every rank runs an
-    independent replica.  A step = one block forward; `value` = TOPS of the seven W4A4 GEMMs inside it (their share of the block
-    time is in the line), roofline = those GEMMs against the INT8 MFMA peak.  cpu_baseline: the same seven projections as the
+    independent replica.  A step = one block forward; `value` = TOPS of the seven W4A4 GEMMs inside it (timed as the four attention
+    projections + the MLP module, whose gate / up / SiLU x up / quantiser are one launch; their share of the block time is in the line), roofline = those GEMMs against the INT8 MFMA peak.  cpu_baseline: the same seven projections as the
     reference computes them (F.linear on fp16 fake-quant operands) on the host at batch 1."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import block_bench

@@ -304,10 +304,33 @@ size_t atom_f6_rows(int64_t rows);
  * bytes 96..103 zeroed.  Offline, once per weight. */
 int atom_repack_weight_f6(const void *B4, int64_t N, int64_t K_total, void *B_f6, void *stream);
 
+/* Packed INT4 activations A4 [M, K4/2] + their scales sA (per `scale_layout`) -> the F6 activation operand [G][atom_f6_rows(M)][104]
+ * with the token scales in the rows (what ATOM_QUANT_F6_CODES makes the quantisers emit directly; this is for callers that hold the
+ * reference's packed format, e.g. ahead of atom_gemm_w4a4_silu_mul_quant_f6).  One bandwidth-bound launch. */
+int atom_repack_act_f6(const void *A4, const void *sA, int64_t M, int64_t K_total, int scale_layout, void *A_f6, void *stream);
+
 /* The same + the fp16 weight scales sB [G, N] appended as float32 [G][atom_f6_rows(N)] (ATOM_B_F6S): B_f6s holds
  * atom_f6_weight_bytes(N, K_total) = G * atom_f6_rows(N) * (104 + 4) bytes. */
 size_t atom_f6_weight_bytes(int64_t N, int64_t K_total);
 int atom_repack_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_total, void *B_f6s, void *stream);
+
+/*
+ * gate_proj + up_proj + act_fn(gate) * up + the per-token group quantiser in ONE launch: what the reference runs as
+ * two dense_layer_gemm_i4_fp16 calls and activate_fp16_i4 (punica/models/llama.py:85-87; model/qLlamaLayer.py:345-351).  A_f6 is the
+ * F6 activation operand [G][atom_f6_rows(M)][104]; Bgu_f6s is the F6 weight buffer WITH appended fp32 scales
+ * (atom_repack_weight_f6s) of the 2 * N_inter fused rows: per block j of 128 features and quarter w = 0..3, gate rows
+ * 128 j + 32 w .. + 31 followed by the same 32 up rows; Bgu8 int8 [2 N_inter, 128] and sBgu8 fp16 [2 N_inter] in the same row
+ * order.  Outputs = atom_silu_mul_quant_f16's with ATOM_QUANT_F6_CODES, for hidden N_inter: o_outliers int8 [M, 128], o_norms_f6
+ * uint8 [N_inter / 128 - 1][atom_f6_rows(M)][104] (the F6 activation operand of down_proj), outlier_scales / norm_scales per
+ * `scale_layout`, optional xq fp16 [M, N_inter] (NULL: not written).  quant_mode ATOM_QUANT_SIM / ATOM_QUANT_KERNEL, clip as there.
+ * Bit-identical to the three launches it replaces (fp16 GEMM outputs are formed in registers and go through the same arithmetic);
+ * saves writing and re-reading 2 * M * N_inter fp16.  Always the 256x256 geometry: meant for prefill batches (M >= 512).
+ * N_inter % 128 == 0, N_inter >= 256; K_total as atom_gemm_w4a4_f16.
+ */
+int atom_gemm_w4a4_silu_mul_quant_f6(const void *A_f6, const void *Bgu_f6s, const void *A8, const void *Bgu8, const void *sA8,
+                                     const void *sBgu8, int64_t M, int64_t N_inter, int64_t K_total, int group, int keeper,
+                                     int quant_mode, float clip, int scale_layout, void *o_outliers, void *o_norms_f6,
+                                     void *outlier_scales, void *norm_scales, void *xq, void *stream);
 
 #ifdef __cplusplus
 }
