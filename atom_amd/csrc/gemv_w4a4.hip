@@ -113,6 +113,116 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
   }
 }
 
+// M = 1 (BASELINE config 2), second version: no LDS, no barrier.  The staged version above is a chain of three dependent round trips
+// (activation row -> LDS, barrier, then the weight row, its scales last); with one token every lane can ask for everything it will
+// ever need in its first instructions -- its weight chunks (HBM), the matching activation chunks and the group's two scales (L2:
+// every wave reads the same 2 KB row) -- so the launch is ONE memory round trip deep.  Same per-lane arithmetic and summation
+// order as gemv_w4a4_kernel<1> (bit-identical output).  UNR chunks per lane are in flight per batch (K = 4096: one batch).
+template <int UNR, int ROWS>
+__global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h;
+  const int nchunks = K4h >> 4;
+  const bool leader = (lane & 3) == 0;
+  const int nwaves = gridDim.x * 4;
+  // ROWS output features per wave are in flight together (rows n, n + nwaves, ...): with more rows than resident waves the second
+  // row's round trip would otherwise start only when the first one's result is stored
+  for (int n0 = blockIdx.x * 4 + wave; n0 < p.N; n0 += nwaves * ROWS) {
+    v4i w8[ROWS], a8 = {0, 0, 0, 0};
+    half_t sb8h[ROWS];
+    if (lane < 8) a8 = *reinterpret_cast<const v4i *>(p.A8 + lane * 16);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = min(n0 + r * nwaves, p.N - 1);
+      w8[r] = v4i{0, 0, 0, 0};
+      if (lane < 8) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + lane * 16);
+      sb8h[r] = p.sB8[n];
+    }
+    const half_t sa8h = p.sA8[0];
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64 * UNR) {
+      v4i w[ROWS][UNR], a[UNR];
+      half_t sbh[ROWS][UNR], sah[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64 + lane;
+        const bool ok = c < nchunks;
+        a[u] = v4i{0, 0, 0, 0};
+        sah[u] = (half_t)0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const int n = min(n0 + r * nwaves, p.N - 1);
+          w[r][u] = v4i{0, 0, 0, 0};
+          sbh[r][u] = (half_t)0;
+          if (ok) {
+            w[r][u] = *reinterpret_cast<const v4i *>(p.B4 + (int64_t)n * K4h + c * 16);
+            if (leader) sbh[r][u] = p.sB[(int64_t)(c >> 2) * p.N + n];
+          }
+        }
+        if (ok) {
+          a[u] = *reinterpret_cast<const v4i *>(p.A4 + c * 16);
+          if (leader) sah[u] = p.sA[(int64_t)(c >> 2) * p.ldA];            // token 0: index 0 in either scale layout
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          int d = 0;
+          d = __builtin_amdgcn_sdot8(a[u][0], w[r][u][0], d, false);
+          d = __builtin_amdgcn_sdot8(a[u][1], w[r][u][1], d, false);
+          d = __builtin_amdgcn_sdot8(a[u][2], w[r][u][2], d, false);
+          d = __builtin_amdgcn_sdot8(a[u][3], w[r][u][3], d, false);
+          d = quad_sum(d);                                  // exact: the group's 128-element integer dot
+          if (leader && c0 + u * 64 + lane < nchunks) {
+            const float t = (float)d * (float)sah[u];
+            acc[r] = __builtin_fmaf(t, (float)sbh[r][u], acc[r]);
+          }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r * nwaves;
+      int d = 0;
+      d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false);
+      d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
+      d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false);
+      d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
+      d = quad_sum(d);
+      d += __shfl_xor(d, 4);
+      float s = acc[r];
+#pragma unroll
+      for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k);
+      if (lane == 0 && n < p.N) {
+        const float t = (float)d * (float)sa8h;
+        p.D[n] = f2h(__builtin_fmaf(t, (float)sb8h[r], s));
+      }
+    }
+  }
+}
+
+static int launch_gemv1(const GemmParams &p, hipStream_t s) {
+  // one wave per output feature, at most 2048 workgroups (the resident set: 8 per CU); beyond that a wave walks its features one
+  // after the other.  (Measured, profiles/r02_decode.txt: more workgroups, or two features in flight per wave (ROWS = 2, tuning
+  // only), are not faster.)
+  const int nb = (p.N + 3) / 4;
+  const int rows2 = ATOM_TUNE("ATOM_GEMV1_ROWS2", 0);
+  int blocks = rows2 ? (nb + 1) / 2 : nb;
+  if (blocks > 2048) blocks = 2048;
+  const bool k2 = p.K4h <= 2 * 64 * 16;
+  if (rows2) {
+    if (k2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemv1_w4a4_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  } else {
+    if (k2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemv1_w4a4_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  }
+  return check_launch();
+}
+
 template <int MB>
 static int launch_gemv_mb(const GemmParams &p, hipStream_t s) {
   const size_t lds = (size_t)((MB * (p.K4h + kKeeper) + 15) & ~15) + (size_t)MB * (p.G + 1) * 4;
@@ -127,7 +237,7 @@ static int launch_gemv_mb(const GemmParams &p, hipStream_t s) {
 
 // M <= 16.  Returns ATOM_ERR_SHAPE when the activations do not fit LDS (caller falls back to the tile kernel).
 int launch_gemv(const GemmParams &p, hipStream_t s) {
-  if (p.M <= 1) return launch_gemv_mb<1>(p, s);
+  if (p.M <= 1) return ATOM_TUNE("ATOM_GEMV1_STAGED", 0) ? launch_gemv_mb<1>(p, s) : launch_gemv1(p, s);
   if (p.M <= 2) return launch_gemv_mb<2>(p, s);
   if (p.M <= 4) return launch_gemv_mb<4>(p, s);
   if (p.M <= 8) return launch_gemv_mb<8>(p, s);

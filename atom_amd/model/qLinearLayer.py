@@ -40,6 +40,26 @@ def _is_hot_weight_config(args, n, k) -> bool:
 
 
 class QLinearLayer(nn.Module):
+    # Weight memory beside the reference's fp16 fake-quant `weight` (2 B per weight, part of its contract: GPTQ and the evaluation
+    # flow read and rewrite it): packed nibbles 0.5 B (+ scales ~0.02) for the decode kernels, and from the first batch of >= 256
+    # rows the F6 form 0.8125 B + 0.03 B of fp32 scales for the prefill kernels.  keep_packed_with_f6 = False releases the packed
+    # INT4 codes once the F6 form exists (a layer that only sees prefill batches then holds 6.75 bit per weight instead of 10.9);
+    # a later decode-size batch re-packs them from `weight` (one atom_pack_weight_w4 launch).
+    keep_packed_with_f6 = True
+
+    def weight_bytes(self):
+        """Bytes currently held for this layer's weight, by form."""
+        d = {"fp16_fake_quant": self.weight.numel() * self.weight.element_size(), "packed_int4": 0, "keeper_and_scales": 0, "f6": 0}
+        if self._packed is not None:
+            b4, b8, sb, sb8 = self._packed
+            d["packed_int4"] = 0 if b4 is None else b4.numel() * b4.element_size()
+            d["keeper_and_scales"] = sum(t.numel() * t.element_size() for t in (b8, sb, sb8))
+        if self._f6 is not None:
+            t = self._f6[1]
+            buf = getattr(t, "atom_f6s", t)
+            d["f6"] = buf.numel() * buf.element_size()
+        return d
+
     def __init__(self, originalLayer: nn.Linear, args, enable_quant: bool = True):
         super().__init__()
         self.args = args
@@ -59,14 +79,14 @@ class QLinearLayer(nn.Module):
         w = self.weight
         return (w.data_ptr(), w._version, tuple(w.shape), w.device)
 
-    def packed_weight(self):
+    def packed_weight(self, need_codes: bool = True):
         """Packed operands if they are current for ``self.weight``, else None.  A weight that was rewritten since the
         last packing (GPTQ: ``layer.weight.data = Q``, gptq.py:331 -- ``quant()`` is never called on that path,
         modelutils_llama.py:224-258) is packed lazily, once per weight version, by recovering its codes and scales
         (atom_pack_weight_w4); a weight that is not on the INT4-g128 / INT8 grid (e.g. still unquantised while GPTQ
         collects its Hessian) is remembered as such and served by ``F.linear``."""
         key = self._weight_key()
-        if self._packed is not None and self._packed_key == key:
+        if self._packed is not None and self._packed_key == key and (need_codes is False or self._packed[0] is not None):
             return self._packed
         if self._unpackable_key == key:
             return None
@@ -85,12 +105,16 @@ class QLinearLayer(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         codes = get_codes(x)
-        packed = self.packed_weight() if codes is not None else None
+        packed = self.packed_weight(need_codes=codes.wide != "f6" or self._f6 is None) if codes is not None else None
         if packed is not None and codes.hidden == self.weight.shape[1] and x.is_cuda:
             b4, b8, sb, sb8 = packed
             if codes.wide == "f6":                        # BF6 operands: the weight is repacked once per packed form
-                if self._f6 is None or self._f6[0] is not b4:
-                    self._f6 = (b4, _ops.repack_weight_f6(b4, sb))
+                if self._f6 is None or self._f6[0] != self._packed_key:
+                    if b4 is None:
+                        b4 = self.packed_weight(need_codes=True)[0]
+                    self._f6 = (self._packed_key, _ops.repack_weight_f6(b4, sb))
+                    if not self.keep_packed_with_f6:      # release the INT4 codes (see the class comment)
+                        self._packed = (None, b8, sb, sb8)
                 b4 = self._f6[1]
             y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
                                               scale_layout=codes.layout, a_wide=codes.wide)

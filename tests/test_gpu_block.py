@@ -186,3 +186,29 @@ def test_llama7b_projection_teacher_forced(name, N, K, feeder):
     nb = torch.stack([qb[1] & 0xF, qb[1] >> 4], -1)
     flips = (na != nb).float().mean().item()
     assert flips <= 5e-3, (name, flips)                         # measured 1-3e-3 (profiles/r02_block_llama7b.txt)
+
+
+def test_qlinear_weight_memory_policy():
+    """keep_packed_with_f6 = False: after the first prefill batch the layer holds the F6 form (6.75 bit per weight incl. its fp32
+    scales) and no packed INT4 codes; a decode-size batch afterwards re-packs them from the fp16 weight; results are those of a layer
+    that keeps both forms."""
+    from atom_amd.model import quant
+    from atom_amd.model.qLinearLayer import QLinearLayer
+    args = _args()
+    torch.manual_seed(2)
+    N, K = 1024, 2176
+    mk = lambda: QLinearLayer(torch.nn.Linear(K, N, bias=False).half().cuda(), args)
+    a, b = mk(), mk()
+    b.weight = a.weight.clone()
+    b.keep_packed_with_f6 = False
+    a.quant(); b.quant()
+    big = quant.hip_act_quant((torch.randn(300, K, device="cuda") * 1.5).half(), args)
+    small = quant.hip_act_quant((torch.randn(5, K, device="cuda") * 1.5).half(), args)
+    assert torch.equal(a(big), b(big))
+    wa, wb = a.weight_bytes(), b.weight_bytes()
+    assert wa["packed_int4"] == N * (K - 128) // 2 and wb["packed_int4"] == 0
+    assert wb["f6"] == wa["f6"] == (K // 128 - 1) * N * 108
+    assert 8.0 * (wb["f6"] + wb["keeper_and_scales"]) / (N * K) < 7.8      # bits per weight without the packed codes (keeper incl.)
+    assert torch.equal(a(small), b(small))                                  # re-packed on demand
+    assert b.weight_bytes()["packed_int4"] == wa["packed_int4"]
+    assert torch.equal(a(big), b(big))
