@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   constexpr bool ADD = OP == OP_ADD_RMSNORM, NORM = OP == OP_RMSNORM || ADD;
   const int bufbytes = ((H * 2 + 1023) & ~1023);            // DMA blocks are 1 KiB (64 lanes x 16 B)
   const int stage = ADD ? 2 * bufbytes : bufbytes;          // ADD stages two rows: x, then the residual
-  double *red = reinterpret_cast<double *>(smem + 2 * stage);      // [2][4] partial sums of squares
+  float *red = reinterpret_cast<float *>(smem + 2 * stage);        // [2][4] partial sums of squares
   const int j = tid & 7;
 
   auto issue_row = [&](int64_t r, int b) {                  // DMA row r into buffer b
@@ -230,7 +230,11 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
     if (rn < p.M) issue_row(rn, b ^ 1);
     char *row = smem + b * stage;
 
-    double ss = 0.0;
+    // Sum of squares: a FIXED-SHAPE FP32 tree over the row in memory order (not over the gathered channels, so the reorder index
+    // does not enter): 16-byte chunk c belongs to thread (wave (c / 64) % 4, lane c % 64); a thread folds its chunks in order with
+    // s = fma(x, x, s); lanes combine by the butterfly xor 32, 16, .., 1; the four waves as ((w0 + w1) + w2) + w3.  Deterministic,
+    // restated step by step in oracle/ (r01 used an FP64 sum rounded once: two half-rate instructions per element).
+    float ss = 0.f;
     if constexpr (ADD) {
       // x + residual (one fp16 add per element, as torch's half add), written back to the residual stream and kept in
       // LDS for the gather; the sum of squares is taken here, on the linear data
@@ -245,16 +249,28 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
           *reinterpret_cast<h8 *>(row + c * 16) = sum;
           *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.res_out + r * (int64_t)H) + c * 16) = sum;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const double d = (double)(float)sum[k];
-            ss = __builtin_fma(d, d, ss);
-          }
+          for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)sum[k], (float)sum[k], ss);
         }
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
       if (lane == 0) red[b * 4 + wave] = ss;
       __syncthreads();                                      // sums visible to the gather, partial sums to everyone
+    } else if constexpr (NORM) {
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < 2 * NP; ++i) {
+        const int c = (i * 4 + wave) * 64 + lane;
+        if (c < nchunks) {
+          const h8 a = *reinterpret_cast<const h8 *>(row + c * 16);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)a[k], (float)a[k], ss);
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      if (lane == 0) red[b * 4 + wave] = ss;
+      __syncthreads();
     }
 
     float x[NP][16];
@@ -273,25 +289,9 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       }
     }
     if constexpr (NORM) {
-      if constexpr (!ADD) {
-        // sum of squares in FP64 (fp16 squares are exact), rounded to FP32 once -> order-independent
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-          if (ps * 256 + tid < nslots) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-              const double d = (double)x[ps][k];
-              ss = __builtin_fma(d, d, ss);                 // d*d is exact in FP64: same value as ss + d*d
-            }
-          }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-        if (lane == 0) red[b * 4 + wave] = ss;
-        __syncthreads();
-      }
-      const double tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
-      const float var = (float)(tot / (double)H);
-      const float rinv = 1.0f / sqrtf(var + p.eps);         // correctly rounded sqrt and divide
+      const float tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
+      const float var = tot / (float)H;                     // correctly rounded divide, sqrt and divide (hipcc default)
+      const float rinv = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
 #pragma unroll

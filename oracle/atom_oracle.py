@@ -18,9 +18,11 @@ This is a numpy restatement of the reference algorithms (file:line relative to
   ``kernels/include/Reorder/Reorder.cuh:64-190``, ``RMSNorm/RMSNorm.cuh:66-238``,
   ``Activate/Activate.cuh:67-180`` and their CPU goldens
   ``e2e/punica-atom/punica/ops/csrc/Reorder/test_Reorder.cu:41-112`` etc.
-  The reference holds no stored vectors for these (its self-check is tolerance
-  based, ints +-1 / scales 1e-3, on rand() data) -> "parity unpinned" beyond the
-  tolerance test we restate in tests/.
+  The reference holds no stored vectors for these, but its unit tests carry CPU golden
+  FUNCTIONS: PINNED against those, compiled from /root/reference into oracle/_ref
+  (oracle/Makefile, oracle/ref/), in tests/test_oracle_ref.py -- scales bit-equal (one fp16
+  ulp where expf / the FP32-vs-half normalisation enters), codes +-1 on a stated fraction
+  (x * (1/s) vs x / s at rounding ties), tighter than the reference's own acceptance.
 * the GEMM -- ``kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:404-434`` (dequant),
   ``:713-727`` (operand doc), A-scale layout ``Reorder.cuh:39-50``.
   GEMM numerics are pinned by NO reference test ("parity unpinned"): the
@@ -211,21 +213,43 @@ def reorder_quant(x16: np.ndarray, reorder_index, mode: str = "sim", clip: float
     return _quant_row_tail(y, mode, clip)
 
 
+def sumsq_tree(x16) -> np.ndarray:
+    """Sum of squares of each row as the HIP RMSNorm kernels take it (quant_kernels.hip): a fixed-shape FP32 tree over the row in
+    memory order.  16-byte chunk c (8 halves) belongs to thread (wave (c // 64) % 4, lane c % 64); a thread folds its chunks in
+    order with s = fma(x, x, s); the 64 lanes of a wave combine by the butterfly xor 32, 16, 8, 4, 2, 1; the four waves as
+    ((w0 + w1) + w2) + w3.  (fma: exact product and sum in float64, rounded to float32 once.)"""
+    x = np.asarray(x16, dtype=f16).astype(np.float64)
+    M, H = x.shape
+    assert H % 8 == 0
+    it = -(-(H // 8) // 256)
+    xp = np.zeros((M, it * 256 * 8), dtype=np.float64)
+    xp[:, :H] = x
+    v = xp.reshape(M, it, 4, 64, 8)
+    s = np.zeros((M, 4, 64), dtype=f32)
+    for i in range(it):
+        for k in range(8):
+            s = (s.astype(np.float64) + v[:, i, :, :, k] ** 2).astype(f32)
+    lanes = np.arange(64)
+    for m in (32, 16, 8, 4, 2, 1):
+        s = (s + s[:, :, lanes ^ m]).astype(f32)
+    w = s[:, :, 0]
+    return (((w[:, 0] + w[:, 1]).astype(f32) + w[:, 2]).astype(f32) + w[:, 3]).astype(f32)
+
+
 def rmsnorm_f16(x16, w16, eps: float, mode: str) -> np.ndarray:
     """RMSNorm producing the FP16 tensor that is then quantised.
 
     sim   : HF LlamaRMSNorm (transformers 4.39 modeling_llama.py, called at qLlamaLayer.py:143):
             var = mean(float(x)^2); y = half(float(x) * rsqrt(var+eps)); out = half(w * y).
     kernel: RMSNorm.cuh:112-151: out = half(float(x) * float(w) * r).
-    Sum of squares is accumulated in float64 and rounded to float32 once (fp16 squares are exact in
-    fp32, so this equals the exactly-rounded sum up to ~1e-16); r = 1/sqrt(var+eps) with correctly
-    rounded fp32 sqrt and divide -- a deterministic spec the HIP kernel follows to the bit.
+    Sum of squares: the fixed-shape FP32 tree of sumsq_tree() (any order is within the reference golden's tolerance -- the
+    reference itself sums with torch's reduction order; this one is specified so that the HIP kernel can be followed to the bit);
+    var = ss / H and r = 1/sqrt(var+eps) with correctly rounded fp32 divide and sqrt.
     """
     x16 = np.asarray(x16, dtype=f16)
     w16 = np.asarray(w16, dtype=f16)
     H = x16.shape[-1]
-    ss = (x16.astype(np.float64) ** 2).sum(axis=-1)
-    var = (ss / np.float64(H)).astype(f32)
+    var = (sumsq_tree(x16.reshape(-1, H)).reshape(x16.shape[:-1]) / f32(H)).astype(f32)
     r = (f32(1.0) / np.sqrt((var + f32(eps)).astype(f32))).astype(f32)
     xf = x16.astype(f32)
     if mode == "sim":
@@ -483,8 +507,10 @@ def kv_fake_quant_sim(x16: np.ndarray, n_bits: int = 4, clip: float = 1.0) -> np
 
 
 # --------------------------------------------------------------------------- INT4 paged KV cache
-# Parity unpinned: the reference holds no golden vector for these (tests/test_batch_decode_int4.py only checks that the
-# CUDA kernel runs) and its kernels cannot run here; the restatement follows the CUDA sources line by line instead.
+# The reference holds no golden VECTOR for these (tests/test_batch_decode_int4.py only checks that the CUDA kernel runs) and its
+# kernels cannot run here, but it ships CPU implementations of both operations as its own test oracle
+# (kernels/src/flashinfer/cpu_reference.h: append_paged_kv_cache, single_quantize_mha).  PINNED against those, compiled from
+# /root/reference into oracle/_ref: tests/test_oracle_ref.py (append byte for byte, decode to FP32 accuracy).
 def kv_seq_len(indptr, last_page_offset, page_size, b):
     """page.cuh:170-172 / decode.cuh:510-512."""
     return (int(indptr[b + 1]) - int(indptr[b]) - 1) * page_size + int(last_page_offset[b])

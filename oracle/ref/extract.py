@@ -14,6 +14,8 @@ import re
 import sys
 
 CSRC = "e2e/punica-atom/punica/ops/csrc"
+KINC = "kernels/include/flashinfer"
+KSRC = "kernels/src/flashinfer"
 # generated file -> [(reference file, first-line regex, kind)]
 SPEC = {
     "reorder.inc": [
@@ -41,6 +43,28 @@ SPEC = {
         ("Norm/RMSNorm.cu", r"^#define SCALE_SIZE_A\(", "line"),
         ("Norm/test_RMSNorm.cu", r"^void run_cpu_rmsnorm_fp16_i4\(", "block"),
     ],
+    # the reference's CPU implementations of the INT4 paged KV cache append and of quantised attention (its own test oracle,
+    # kernels/src/flashinfer/cpu_reference.h) with the few definitions they use (paths relative to the reference root), one file
+    # per namespace they live in
+    "kvquant.inc": [                                         # namespace flashinfer::quant
+        ("/" + KINC + "/quantization.cuh", r"^\s+struct __precision__s4\{\};", "line"),
+        ("/" + KINC + "/quantization.cuh", r"^\s+FLASHINFER_INLINE constexpr float size_of_type\(\)\{", "iblock"),
+        ("/" + KINC + "/quantization.cuh", r"^\s+FLASHINFER_INLINE T\* get_ptr\(T\* ptr, const size_t offset\)\{", "iblock"),
+    ],
+    "kvtypes.inc": [                                         # namespace flashinfer
+        ("/" + KINC + "/layout.cuh", r"^enum class QKVLayout \{", "block"),
+        ("/" + KINC + "/layout.cuh", r"^__host__ __device__ __forceinline__ size_t get_elem_offset_impl\(", "block"),
+        ("/" + KINC + "/layout.cuh", r"^struct tensor_info_t \{", "block"),
+        ("/" + KINC + "/rope.cuh", r"^enum class RotaryMode \{", "block"),
+        ("/" + KINC + "/utils.cuh", r"^#define SWITCH_LAYOUT\(", "macro"),
+        ("/" + KINC + "/page.cuh", r"^struct paged_kv_t \{", "block"),
+    ],
+    "kvcpu.inc": [                                           # namespace cpu_reference
+        ("/" + KSRC + "/cpu_reference.h", r"^inline std::vector<float> apply_llama_rope\(", "block"),
+        ("/" + KSRC + "/cpu_reference.h", r"^std::vector<dtype_out> single_mha\(", "block"),
+        ("/" + KSRC + "/cpu_reference.h", r"^void append_paged_kv_cache\(", "block"),
+        ("/" + KSRC + "/cpu_reference.h", r"^std::vector<OType> single_quantize_mha\(", "block"),
+    ],
 }
 
 
@@ -51,7 +75,22 @@ def cut(lines, pattern, kind, where):
     i = hits[0]
     if kind == "line":
         return i, i + 1
-    j = i
+    if kind == "iblock":                                     # an indented definition: ends at `}` of the same indentation
+        ind = len(lines[i]) - len(lines[i].lstrip())
+        j = i
+        while not re.match(r"^\s{%d}\};?\s*$" % ind, lines[j]):
+            j += 1
+        while i > 0 and re.match(r"^\s*template\s*<", lines[i - 1]):
+            i -= 1
+        return i, j + 1
+    if kind == "macro":                                      # a #define with line continuations
+        j = i
+        while lines[j].rstrip().endswith("\\"):
+            j += 1
+        return i, j + 1
+    while i > 0 and re.match(r"^template\s*<", lines[i - 1]):   # a template header belongs to the definition
+        i -= 1
+    j = hits[0]
     while not re.match(r"^\};?\s*$", lines[j]):
         j += 1
         if j >= len(lines):
@@ -64,7 +103,7 @@ def main(ref_root, out_dir):
     for name, items in SPEC.items():
         parts = [f"// GENERATED by oracle/ref/extract.py from {ref_root}/{CSRC} -- do not commit\n"]
         for rel, pattern, kind in items:
-            path = os.path.join(ref_root, CSRC, rel)
+            path = ref_root + rel if rel.startswith("/") else os.path.join(ref_root, CSRC, rel)
             lines = open(path).read().splitlines(keepends=True)
             a, b = cut(lines, pattern, kind, rel)
             parts.append(f"// ---- {rel}:{a + 1}-{b}\n")

@@ -50,3 +50,16 @@ static_assert(sizeof(half) == 2, "half must be 2 bytes");
 #define HOST_DEVICE inline
 using std::max;
 using std::min;
+
+// ---- for the flashinfer CPU reference (kernels/src/flashinfer/cpu_reference.h and the definitions it uses)
+#include <cassert>
+#include <iostream>
+#include <string>
+#include <type_traits>
+#include <vector>
+struct half2 { half x, y; };
+inline float __half2float(half h) { return (float)h; }
+#define __host__
+#define __device__
+#define __forceinline__ inline
+#define FLASHINFER_INLINE inline

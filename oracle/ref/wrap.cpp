@@ -20,7 +20,62 @@ namespace ref_rmsnorm {
 #undef SCALE_SIZE_A
 }
 
+// The reference's CPU restatements of the INT4 paged KV cache (kernels/src/flashinfer/cpu_reference.h:115-234: append_paged_kv_cache,
+// single_quantize_mha -> single_mha, apply_llama_rope) -- what its own tests check append_kv_i4 / batch_decode_i4 against
+// (kernels/src/flashinfer/bench_batch_decode.cu) -- in the namespaces they are written for.
+namespace ref_kv {
+namespace flashinfer {
+namespace quant {
+#include "../_ref/kvquant.inc"
+}
+#include "../_ref/kvtypes.inc"
+}  // namespace flashinfer
+namespace cpu_reference {
+using namespace flashinfer;
+#include "../_ref/kvcpu.inc"
+}  // namespace cpu_reference
+}  // namespace ref_kv
+
 extern "C" {
+
+// Append: cache u8 [pages, L, 2, N, P, D/2] / param half2 [pages, L, 2, N, P] (punica/utils/kvcache.py:17-26); k, v u8 [T, N, D/2] and
+// k_param, v_param half2 [T, N] hold the new tokens of all sequences back to back (append_indptr int32 [B + 1])
+void ref_cpu_append_paged_kv_i4(uint8_t *data, void *param, int32_t *indptr, int32_t *indices, int32_t *last_page_offset,
+                                int num_layers, int layer, int num_heads, int page_size, int head_dim, int batch,
+                                const uint8_t *k, const uint8_t *v, const void *k_param, const void *v_param,
+                                const int32_t *append_indptr) {
+  using namespace ref_kv;
+  using s4 = flashinfer::quant::__precision__s4;
+  flashinfer::paged_kv_t<s4, int32_t> pg(num_layers, layer, num_heads, page_size, head_dim, batch, reinterpret_cast<s4 *>(data),
+                                         reinterpret_cast<half2 *>(param), indptr, indices, last_page_offset);
+  std::vector<std::vector<uint8_t>> ks(batch), vs(batch);
+  std::vector<std::vector<half2>> kp(batch), vp(batch);
+  const size_t tok = (size_t)num_heads * head_dim / 2;
+  for (int b = 0; b < batch; ++b) {
+    const size_t t0 = append_indptr[b], n = append_indptr[b + 1] - append_indptr[b];
+    ks[b].assign(k + t0 * tok, k + (t0 + n) * tok);
+    vs[b].assign(v + t0 * tok, v + (t0 + n) * tok);
+    kp[b].assign((const half2 *)k_param + t0 * num_heads, (const half2 *)k_param + (t0 + n) * num_heads);
+    vp[b].assign((const half2 *)v_param + t0 * num_heads, (const half2 *)v_param + (t0 + n) * num_heads);
+  }
+  std::vector<int32_t> ai(append_indptr, append_indptr + batch + 1);
+  cpu_reference::append_paged_kv_cache<s4, int32_t>(pg, ks, vs, kp, vp, ai);
+}
+
+// One query token against kv_len quantised tokens, layout NHD: q half [N, D]; k, v u8 [kv_len, N, D/2]; params half2 [kv_len, N];
+// llama RoPE on q (at position kv_len - 1) and on every key at its own position; out float [N, D]
+void ref_cpu_single_decode_i4(const void *q, const uint8_t *k, const uint8_t *v, const void *k_param, const void *v_param, int kv_len,
+                              int num_heads, int head_dim, float rope_scale, float rope_theta, float *out) {
+  using namespace ref_kv;
+  const size_t nq = (size_t)num_heads * head_dim, nk = (size_t)kv_len * num_heads * head_dim / 2, np = (size_t)kv_len * num_heads;
+  std::vector<half> qv((const half *)q, (const half *)q + nq);
+  std::vector<uint8_t> kv(k, k + nk), vv(v, v + nk);
+  std::vector<half2> kp((const half2 *)k_param, (const half2 *)k_param + np), vp((const half2 *)v_param, (const half2 *)v_param + np);
+  std::vector<float> o = cpu_reference::single_quantize_mha<half, uint8_t, float>(
+      qv, kv, vv, kp, vp, 1, kv_len, num_heads, head_dim, false, flashinfer::QKVLayout::kNHD, flashinfer::RotaryMode::kLlama, rope_scale,
+      rope_theta);
+  for (size_t i = 0; i < nq; ++i) out[i] = o[i];
+}
 
 // x fp16 [seq_len, hidden]; reorder_index int16 [hidden]; o_outliers int8 [seq_len, group]; o_norms packed int4
 // [seq_len, (hidden - group) / 2]; scales in the reference's replicated layout (outlier: scale_size(seq_len) halves,

@@ -26,6 +26,10 @@ def lib():
         L.ref_cpu_activate_fp16_i4.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
         L.ref_cpu_rmsnorm_fp16_i4.restype = None
         L.ref_cpu_rmsnorm_fp16_i4.argtypes = [vp, vp, ctypes.c_float, i, i, i, vp, vp, vp, vp, vp]
+        L.ref_cpu_append_paged_kv_i4.restype = None
+        L.ref_cpu_append_paged_kv_i4.argtypes = [vp] * 5 + [i] * 6 + [vp] * 5
+        L.ref_cpu_single_decode_i4.restype = None
+        L.ref_cpu_single_decode_i4.argtypes = [vp] * 5 + [i, i, i, ctypes.c_float, ctypes.c_float, vp]
         L.ref_scale_index.restype = i
         L.ref_scale_index.argtypes = [i]
         _lib = L
@@ -84,3 +88,27 @@ def activate(a, b):
 
 def rmsnorm(x, w, eps, idx):
     return _run("rmsnorm", x, w=w, idx=idx, eps=eps)
+
+
+# ---- INT4 paged KV cache: the reference's CPU restatements (kernels/src/flashinfer/cpu_reference.h)
+def append_paged_kv_i4(data, param, indptr, indices, last_page_offset, k, v, k_param, v_param, layer, append_indptr):
+    """In place on data u8 [pages, L, 2, N, P, D/2] / param f16 [pages, L, 2, N, P, 2]; k, v u8 [T, N, D/2]; k_param, v_param f16 [T, N, 2]."""
+    assert data.flags.c_contiguous and param.flags.c_contiguous and data.dtype == np.uint8 and param.dtype == np.float16
+    pages, Lr, _, N, P, Dh = data.shape
+    c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    ip, ix, lp, ap = c32(indptr), c32(indices), c32(last_page_offset), c32(append_indptr)
+    k, v = np.ascontiguousarray(k, np.uint8), np.ascontiguousarray(v, np.uint8)
+    kp, vpm = np.ascontiguousarray(k_param, np.float16), np.ascontiguousarray(v_param, np.float16)
+    lib().ref_cpu_append_paged_kv_i4(_p(data), _p(param), _p(ip), _p(ix), _p(lp), Lr, int(layer), N, P, Dh * 2, len(lp), _p(k), _p(v),
+                                     _p(kp), _p(vpm), _p(ap))
+
+
+def single_decode_i4(q16, k, v, k_param, v_param, theta=1e4):
+    """q f16 [N, D]; k, v u8 [S, N, D/2]; k_param, v_param f16 [S, N, 2] -> float32 [N, D] (llama RoPE on q at S - 1 and on every key)."""
+    q16 = np.ascontiguousarray(q16, np.float16)
+    k, v = np.ascontiguousarray(k, np.uint8), np.ascontiguousarray(v, np.uint8)
+    kp, vpm = np.ascontiguousarray(k_param, np.float16), np.ascontiguousarray(v_param, np.float16)
+    S, N, Dh = k.shape
+    out = np.empty((N, Dh * 2), np.float32)
+    lib().ref_cpu_single_decode_i4(_p(q16), _p(k), _p(v), _p(kp), _p(vpm), S, N, Dh * 2, 1.0, float(theta), _p(out))
+    return out

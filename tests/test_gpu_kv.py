@@ -1,5 +1,7 @@
 """GPU tests of the INT4 paged-KV ops (atom_kv_append_i4, atom_batch_decode_i4) against the numpy restatement of the
-reference CUDA kernels (oracle.kv_append_i4 / batch_decode_i4; parity unpinned -- the reference has no golden vectors)."""
+reference CUDA kernels (oracle.kv_append_i4 / batch_decode_i4) AND against the reference's own CPU implementations of the same
+two operations (cpu_reference::append_paged_kv_cache / single_quantize_mha, kernels/src/flashinfer/cpu_reference.h, compiled from
+/root/reference into oracle/_ref/libatom_ref.so; tests/test_oracle_ref.py pins the restatement against them on the CPU)."""
 import numpy as np
 import pytest
 import torch
@@ -174,3 +176,35 @@ def test_fused_quant_append_equals_o4_gemm_plus_append(seqlens, heads, block):
         assert changed.sum().item() <= 2 * heads * B
         pools.append(pool)
     assert torch.equal(pools[0].buf, pools[1].buf) and torch.equal(pools[0].param, pools[1].param)
+
+
+@pytest.mark.parametrize("seqlens,heads,block", [([37, 5, 16], 4, 16), ([100, 33, 64, 2, 17], 8, 32)])
+def test_append_and_decode_vs_reference_cpu_implementation(seqlens, heads, block):
+    """The HIP ops directly against the reference's CPU code: the cache after atom_kv_append_i4 equals the cache after
+    cpu_reference::append_paged_kv_cache byte for byte; atom_batch_decode_i4 is within 2e-3 of cpu_reference::single_quantize_mha
+    (FP32, std::exp / std::cos) on the gathered keys and values of every sequence."""
+    from tests import ref_golden as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libatom_ref.so not built (needs /root/reference)")
+    from atom_amd import ops
+    pool, cs, kv, g = _setup(seqlens, heads=heads, block=block, seed=7)
+    T = sum(seqlens)
+    k = torch.randint(0, 256, (T, heads, 64), device="cuda", generator=g, dtype=torch.uint8)
+    v = torch.randint(0, 256, (T, heads, 64), device="cuda", generator=g, dtype=torch.uint8)
+    kp = (torch.rand((T, heads, 2), device="cuda", generator=g) * 0.2 + 0.01).half()
+    vp = (torch.rand((T, heads, 2), device="cuda", generator=g) * 0.2 + 0.01).half()
+    ind = torch.tensor(np.cumsum([0] + seqlens), dtype=torch.int32, device="cuda")
+    data, param = t2n(pool.buf).copy(), t2n(pool.param).copy()
+    layer = 1
+    ops.init_kv_i4(kv, k, v, kp, vp, ind, layer)
+    indptr, indices, last = _np_tables(kv)
+    R.append_paged_kv_i4(data, param, indptr, indices, last, t2n(k), t2n(v), t2n(kp), t2n(vp), layer, t2n(ind))
+    assert np.array_equal(t2n(pool.buf), data) and np.array_equal(t2n(pool.param).view(np.uint16), param.view(np.uint16))
+    q = torch.randn((len(seqlens), heads, 128), device="cuda", generator=g).half()
+    o = t2n(ops.batch_decode_i4(q, kv, layer)).astype(np.float64)
+    for b, S in enumerate(seqlens):
+        pages = indices[indptr[b]:indptr[b + 1]]
+        gather = lambda a, which: np.concatenate([a[pg, layer, which].transpose(1, 0, 2) for pg in pages], axis=0)[:S]
+        want = R.single_decode_i4(t2n(q)[b], gather(data, 0), gather(data, 1), gather(param, 0), gather(param, 1))
+        err = np.abs(o[b] - want).max()
+        assert err <= 2e-3 * np.abs(want).max() + 1e-3, (b, err)

@@ -162,7 +162,7 @@ def test_pack_is_exact_on_rtn_weights_and_flags_off_grid(golden_dir):
 
 
 def test_kv_oracle_self_consistency():
-    """The INT4 paged-KV restatement (parity unpinned: the reference has no vectors) against an independent dense
+    """The INT4 paged-KV restatement (pinned against the reference's CPU implementations in tests/test_oracle_ref.py) against an independent dense
     evaluation: append through the page tables, then decode == plain softmax attention over the de-quantised, RoPE'd
     rows gathered straight from the inputs."""
     g = np.random.default_rng(0)

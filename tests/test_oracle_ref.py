@@ -62,3 +62,53 @@ def test_rmsnorm_kernel_mode_vs_reference_cpu_golden(M, H):
     # the golden keeps the normalised row in FP32 (test_RMSNorm.cu:140-143), the CUDA kernel and the restatement round it
     # to half first (RMSNorm.cuh:112-151): codes +-1 on < 0.2 %, scales within one fp16 ulp
     _cmp(R.rmsnorm(x, w, 1e-5, idx), O.rmsnorm_reorder_quant(x, w, 1e-5, idx, "kernel", 1.0), max_flip=2e-3, scale_ulps=1)
+
+
+# ---- INT4 paged KV cache: the oracle's restatements against the reference's own CPU implementations
+def _paged_state(rng, B, N, P, L, lens, extra_pages=3):
+    npages = [-(-s // P) for s in lens]
+    total = sum(npages) + extra_pages
+    perm = rng.permutation(total)
+    indptr = np.concatenate([[0], np.cumsum(npages)]).astype(np.int32)
+    indices = perm[: indptr[-1]].astype(np.int32)
+    last = np.array([s - (n - 1) * P for s, n in zip(lens, npages)], np.int32)
+    data = rng.integers(0, 256, size=(total, L, 2, N, P, 64), dtype=np.uint8)
+    param = (rng.uniform(0.01, 0.2, size=(total, L, 2, N, P, 2))).astype(np.float16)
+    return data, param, indptr, indices, last
+
+
+def test_kv_append_matches_reference_cpu_implementation():
+    """oracle.kv_append_i4 (the restatement the HIP append kernel is checked against) == cpu_reference::append_paged_kv_cache
+    (kernels/src/flashinfer/cpu_reference.h:115-169), byte for byte, prefill-style (several tokens per sequence) and decode-style."""
+    rng = np.random.default_rng(3)
+    B, N, P, L, layer = 4, 8, 16, 3, 1
+    lens = [37, 16, 1, 50]
+    for appends in ([5, 16, 1, 33], [1, 1, 1, 1]):
+        data, param, indptr, indices, last = _paged_state(rng, B, N, P, L, lens)
+        ai = np.concatenate([[0], np.cumsum(appends)]).astype(np.int32)
+        T = int(ai[-1])
+        k, v = rng.integers(0, 256, size=(T, N, 64), dtype=np.uint8), rng.integers(0, 256, size=(T, N, 64), dtype=np.uint8)
+        kp, vp = rng.uniform(0.01, 0.2, size=(T, N, 2)).astype(np.float16), rng.uniform(0.01, 0.2, size=(T, N, 2)).astype(np.float16)
+        d1, p1, d2, p2 = data.copy(), param.copy(), data.copy(), param.copy()
+        O.kv_append_i4(d1, p1, indptr, indices, last, k, v, kp, vp, layer, append_indptr=ai)
+        R.append_paged_kv_i4(d2, p2, indptr, indices, last, k, v, kp, vp, layer, ai)
+        assert np.array_equal(d1, d2) and np.array_equal(p1.view(np.uint16), p2.view(np.uint16))
+        assert not np.array_equal(d1, data)
+
+
+def test_batch_decode_matches_reference_cpu_implementation():
+    """oracle.batch_decode_i4 (FP64) vs cpu_reference::single_quantize_mha (FP32; :171-234 -> single_mha :30-108 with llama RoPE,
+    :11-28), per sequence on the keys / values gathered from the pages: the two agree to FP32 accuracy."""
+    rng = np.random.default_rng(4)
+    B, N, P, L, layer = 3, 4, 16, 2, 1
+    lens = [45, 16, 3]
+    data, param, indptr, indices, last = _paged_state(rng, B, N, P, L, lens)
+    q = rng.standard_normal((B, N, 128)).astype(np.float16)
+    got = O.batch_decode_i4(q, data, param, indptr, indices, last, layer)
+    for b in range(B):
+        S = lens[b]
+        pages = indices[indptr[b]:indptr[b + 1]]
+        gather = lambda a, kv: np.concatenate([a[pg, layer, kv].transpose(1, 0, 2) for pg in pages], axis=0)[:S]   # [S, N, .]
+        want = R.single_decode_i4(q[b], gather(data, 0), gather(data, 1), gather(param, 0), gather(param, 1))
+        scale = np.abs(want).max()
+        assert np.abs(got[b] - want).max() <= 2e-5 * scale + 1e-6, (b, np.abs(got[b] - want).max(), scale)
