@@ -91,15 +91,18 @@ def quantize_tensor(w: torch.Tensor, n_bits, group_size, tiling, sym, clip_ratio
     """Uniform fake quantisation of rows (reference :118-183), all arithmetic in w's dtype like the reference."""
     if tiling > 0:
         raise AssertionError("16x16 block-wise quantization is abandoned in the reference")
-    if exponential or quant_type != "int":
-        raise NotImplementedError("only uniform integer quantisation is implemented (the Atom configuration)")
     assert n_bits < 16
+    assert quant_type in ("int", "fp"), "Options should be in [int, fp]"
     shape = w.shape
     w = w.squeeze()
     if group_size > 0:
         assert w.shape[-1] % group_size == 0
         w = w.reshape(-1, group_size)
     assert w.dim() == 2, "expected [num_groups, group_size]"
+    if quant_type == "fp":
+        return _fake_quant_fp4(w, n_bits).reshape(shape)
+    if exponential:
+        return _fake_quant_exponent(w, n_bits, sym).reshape(shape)
     if sym:
         hi, lo = 2 ** (n_bits - 1) - 1, -(2 ** (n_bits - 1))
         amax = w.abs().amax(dim=-1, keepdim=True).clamp(min=1e-5)
@@ -116,6 +119,44 @@ def quantize_tensor(w: torch.Tensor, n_bits, group_size, tiling, sym, clip_ratio
         zero = torch.round(-vmin / scale).clamp_(min=lo, max=hi)
         out = (torch.clamp(torch.round(w / scale) + zero, lo, hi) - zero) * scale
     return out.reshape(shape)
+
+
+_FP4_LEVELS = (0.0, 0.0625, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0)     # bitsandbytes "fp4" magnitudes (x / 12 after absmax scaling)
+
+
+def _fake_quant_fp4(w: torch.Tensor, n_bits) -> torch.Tensor:
+    """quant_type="fp" (reference :134-138: bitsandbytes quantize_fp4 / dequantize_fp4 with blocksize = the group): every row is
+    scaled by its absmax and each value replaced by the nearest of the 16 FP4 levels {+-0, +-1/192, +-1/6, +-1/4, +-1/3, +-1/2,
+    +-2/3, +-1} x absmax.  Not part of Atom's configuration (the hot path is INT4); bitsandbytes is not installed here, so this
+    branch is a restatement of its published data type, unpinned (ties between two levels may round differently)."""
+    assert n_bits == 4, "Only support FP4 quantization. You can add more by using bnb library."
+    f = w.float()
+    amax = f.abs().amax(dim=-1, keepdim=True)
+    x = torch.where(amax > 0, f / amax, torch.zeros_like(f))
+    lv = torch.tensor(_FP4_LEVELS, dtype=torch.float32, device=w.device) / 12.0
+    idx = (x.abs().unsqueeze(-1) - lv).abs().argmin(dim=-1)
+    return (torch.sign(x) * lv[idx] * amax).to(w.dtype)
+
+
+def _fake_quant_exponent(w: torch.Tensor, n_bits, sym) -> torch.Tensor:
+    """exponential=True (reference :146-164): an exponent-only format -- magnitudes become scales * 2^e, e in [0, 2^(n_bits-1) - 1],
+    with e = floor(log2(|w| / scales)) rounded up where the mantissa exceeds 1.5; asymmetric: around the mid-point of the range.
+    "not used in Atom" (reference :115); arithmetic in w's dtype like the reference."""
+    q_max = 2 ** (2 ** (n_bits - 1) - 1)
+    if sym:
+        scales = w.abs().amax(dim=-1, keepdim=True).clamp(min=1e-5)
+        base = torch.zeros_like(scales)
+    else:
+        hi, lo = w.amax(dim=-1, keepdim=True), w.amin(dim=-1, keepdim=True)
+        scales = (hi - lo) * torch.tensor(0.5)
+        base = (hi + lo) * torch.tensor(0.5)
+    scales = scales / q_max
+    c = w - base
+    sign = torch.sign(c)
+    lg = torch.log2((torch.abs(c) / scales).clamp(min=1, max=q_max))
+    e = torch.floor(lg)
+    e = e + (lg - e > torch.log2(torch.tensor(1.5))).int()
+    return (2 ** e) * sign * scales + base
 
 
 @torch.no_grad()
@@ -233,7 +274,20 @@ class Quantizer(nn.Module):
     def forward(self, hidden_states):
         if self.args.static is False or self.scales is None:
             return self.act_quant(hidden_states)
-        raise NotImplementedError("static activation quantisation is not part of Atom's path")
+        # static scales (reference :274-290; "Atom is dynamic quantization", so only non-Atom configurations get here): the columns
+        # behind the first `keeper` ones are rounded onto pre-computed per-group scales, in place like the reference
+        a = self.args
+        shape = hidden_states.shape
+        assert a.a_sym is True, "Only support statically symmetric quantization"
+        assert a.act_group_size == 0 or (shape[-1] - a.keeper) % a.act_group_size == 0
+        hs = hidden_states.view(-1, shape[-1])
+        sel = hs[:, a.keeper:].clone()
+        if a.act_group_size > 0:
+            sel = sel.reshape(-1, a.act_group_size)
+        assert self.scales.numel() == sel.shape[-2], "Scales and selected states must have the same dimension"
+        sel = torch.clamp(torch.round(sel / self.scales), self.q_min, self.q_max) * self.scales
+        hs[:, a.keeper:] = sel.reshape(-1, shape[-1] - a.keeper)
+        return hs.view(shape)
 
     def to(self, *args, **kwargs):
         super().to(*args, **kwargs)
