@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   const int h = blockIdx.x % N, b = blockIdx.x / N, sp = blockIdx.y;
   const int pg0 = p.kv.indptr[b];
   const int seq_len = (p.kv.indptr[b + 1] - pg0 - 1) * P + p.kv.last_page_offset[b];
-  const int ntiles = (seq_len + 15) >> 4;
+  const int ntiles = (max(seq_len, 0) + 15) >> 4;       // (an empty sequence: no tiles, no page-table read, output zeros)
   const int chunk = (ntiles + p.splits - 1) / p.splits;
   const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
   const int tpp = P >> 4;                               // 16-token tiles per page
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     tb.lv = t * 64 + 16 * u;
     tb.lq = t * 2;
   }
-  auto page_of = [&](int tile) { return (int64_t)p.kv.indices[pg0 + min(tile, ntiles - 1) / tpp]; };
+  auto page_of = [&](int tile) { return ntiles > 0 ? (int64_t)p.kv.indices[pg0 + min(tile, ntiles - 1) / tpp] : (int64_t)0; };
   TileRegs cur, nxt;
   if (tile0 < tile1) cur = load_tile(tb, page_of(tile0), tile0 % tpp);
   if (tile0 + 1 < tile1) nxt = load_tile(tb, page_of(tile0 + 1), (tile0 + 1) % tpp);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   }
   if (t != 0) return;
   if (p.splits == 1) {
-    const float rd = 1.0f / d;
+    const float rd = d > 0.f ? 1.0f / d : 0.f;
     half_t *op = p.o + ((int64_t)b * N + h) * kHeadDim + 32 * u;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float *ws, half
     acc = __builtin_fmaf(wp[s * (kHeadDim + 2) + dim], w, acc);
     den = __builtin_fmaf(wp[s * (kHeadDim + 2) + kHeadDim + 1], w, den);
   }
-  o[bh * kHeadDim + dim] = (half_t)(acc / den);
+  o[bh * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
 }
 
 static int check_kv(const void *kv_data, const void *kv_param, const int32_t *indptr, const int32_t *indices,

@@ -157,11 +157,17 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """Per-device scratch for split-K partial sums, grown on demand (same-stream reuse is ordered by the stream)."""
-    t = _WS.get(device)
+    """Scratch for split-K partial sums / re-coded operands / decode partials, per (device, stream): calls on one stream reuse it
+    in stream order; calls on different streams never share a buffer.  Grown on demand in steps (the old buffer is returned to the
+    caching allocator, which keeps it alive for work already queued on its stream); during HIP-graph capture a buffer is never
+    re-allocated from under earlier captured launches -- size it with a warm-up call before capturing."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _WS.get(key)
     if t is None or t.numel() < nbytes:
+        if t is not None and torch.cuda.is_current_stream_capturing():
+            raise L.AtomHipError("workspace would have to grow during graph capture: run the op once before capturing")
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _WS[device] = t
+        _WS[key] = t
     return t
 
 

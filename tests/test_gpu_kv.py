@@ -208,3 +208,23 @@ def test_append_and_decode_vs_reference_cpu_implementation(seqlens, heads, block
         want = R.single_decode_i4(t2n(q)[b], gather(data, 0), gather(data, 1), gather(param, 0), gather(param, 1))
         err = np.abs(o[b] - want).max()
         assert err <= 2e-3 * np.abs(want).max() + 1e-3, (b, err)
+
+
+@pytest.mark.parametrize("max_pages", [0, 64])
+def test_batch_decode_empty_sequence_gives_zeros(max_pages):
+    """A sequence with no tokens (indptr[b+1] == indptr[b]) attends to nothing: its output rows are zeros -- not NaN from 0 / 0 and
+    no page-table read past its (empty) page list -- and the other sequences of the batch are unaffected; both the single-pass
+    kernel and the KV-split + merge path."""
+    import types
+    from atom_amd import ops
+    pool, cs, kv, g = _setup([20, 33], heads=4, block=16, seed=11)
+    q = torch.randn((3, 4, 128), device="cuda", generator=g).half()
+    want = ops.batch_decode_i4(q[[0, 2]].contiguous(), kv, 1)
+    indptr = t2n(kv.indptr)
+    ip3 = torch.tensor([indptr[0], indptr[1], indptr[1], indptr[2]], dtype=torch.int32, device="cuda")   # sequence 1 is empty
+    lpo = t2n(kv.last_page_offset)
+    lp3 = torch.tensor([lpo[0], 0, lpo[1]], dtype=torch.int32, device="cuda")
+    kv3 = types.SimpleNamespace(data=kv.data, param=kv.param, indptr=ip3, indicies=kv.indicies, last_page_offset=lp3, max_pages=max_pages)
+    o = ops.batch_decode_i4(q, kv3, 1)
+    assert torch.isfinite(o).all() and not o[1].any()
+    assert torch.allclose(o[[0, 2]].float(), want.float(), atol=2e-3 * float(want.float().abs().max()), rtol=0)
