@@ -1113,29 +1113,30 @@ __device__ __forceinline__ void q_load_sb(const char *lds, QRegs<C> &R, int h, i
   for (int k = 0; k < 4; ++k) { R.sb[h][k] = lo[k]; R.sb[h][4 + k] = hi[k]; }
 }
 
-// LDS-DMA piece through SGPR base + lane offset + instruction offset (which also moves the LDS destination)
-template <int OFF>
+// LDS-DMA through SGPR base + lane offset + instruction offset (which also moves the LDS destination): three consecutive 1 KiB
+// pieces share one M0 and one address; a single piece for the wave's extra one
+__device__ __forceinline__ void q_dma16x3(unsigned m0v, unsigned voff, const void *sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void q_dma16(unsigned m0v, unsigned voff, const void *sbase) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
 }
 struct QDma {            // per wave, loop invariant
   unsigned voffW, voffA, voffX;   // lane offsets (bytes) from the stage's weight / activation / extra base
   int m0W, m0A, m0X;              // LDS offsets of the wave's first piece inside a stage
-  int xkind;                      // extra piece: 0 none, 1 weight rows, 2 activation rows, 3 weight scales
-};
-// piece i (0..6) of this wave for the stage whose global bases are wsrc / asrc / sbsrc, into stage slot DS
+  int xkind;                      // extra piece: 1 weight rows, 2 activation rows, 3 weight scales (waves 5-7 repeat the scales piece:
+};                                //              same bytes to the same place, and no wave-dependent branch in the K loop)
+// DMA group i of this wave (0: its three weight pieces, 3: its three activation pieces, 6: the extra piece; other i: nothing) for
+// the stage whose global bases are wsrc / asrc / sbsrc, into stage slot DS
 template <class C, int DS>
 __device__ __forceinline__ void q_piece(const QDma &d, const uint8_t *wsrc, const uint8_t *asrc, const float *sbsrc, int i) {
   constexpr int base = DS * QC<C>::STAGE;
-  if (i == 0) q_dma16<0>(base + d.m0W, d.voffW, wsrc);
-  else if (i == 1) q_dma16<1024>(base + d.m0W, d.voffW, wsrc);
-  else if (i == 2) q_dma16<2048>(base + d.m0W, d.voffW, wsrc);
-  else if (i == 3) q_dma16<0>(base + d.m0A, d.voffA, asrc);
-  else if (i == 4) q_dma16<1024>(base + d.m0A, d.voffA, asrc);
-  else if (i == 5) q_dma16<2048>(base + d.m0A, d.voffA, asrc);
-  else if (i == 6 && d.xkind) {
+  if (i == 0) q_dma16x3(base + d.m0W, d.voffW, wsrc);
+  else if (i == 3) q_dma16x3(base + d.m0A, d.voffA, asrc);
+  else if (i == 6) {
     const void *xb = d.xkind == 1 ? (const void *)wsrc : (d.xkind == 2 ? (const void *)asrc : (const void *)sbsrc);
-    q_dma16<0>(base + d.m0X, d.voffX, xb);
+    q_dma16(base + d.m0X, d.voffX, xb);
   }
 }
 
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   d.voffW = d.voffA = (unsigned)(wave * 3072 + lane * 16);
   d.m0W = wave * 3072;
   d.m0A = C::A_OFF + wave * 3072;
-  d.xkind = wave < 2 ? 1 : (wave < 4 ? 2 : (wave == 4 ? 3 : 0));
+  d.xkind = wave < 2 ? 1 : (wave < 4 ? 2 : 3);
   d.voffX = (unsigned)((wave < 4 ? (24 + (wave & 1)) * 1024 : 0) + lane * 16);
   d.m0X = wave < 2 ? (24 + wave) * 1024 : (wave < 4 ? C::A_OFF + (24 + (wave & 1)) * 1024 : Q::SB_OFF);
   const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
