@@ -52,6 +52,7 @@ struct ActQuantParams {
   half_t *s8;
   half_t *s4;
   half_t *xq;             // optional
+  int w_lds;              // rmsnorm kernels: 1 = the weight vector is staged in LDS (set by the launcher when it fits)
 };
 
 typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -198,6 +199,22 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   int64_t r = blockIdx.x;
   int b = 0;
   if (r < p.M) issue_row(r, 0);
+  // RMSNorm weights: the whole vector rides into LDS with the first row (one more LDS-DMA stream); the per-channel gather below then
+  // runs out of LDS instead of issuing 16 * NP scattered 2-byte global loads per thread behind the index loads (round 1: a second
+  // dependent memory round trip before the first row could be touched -- most of the kernel at M <= 4096)
+  char *wbuf = smem + 2 * stage + 1024;
+  if constexpr (NORM) {
+    if (p.w_lds) {
+#pragma unroll
+      for (int i = 0; i < 2 * NP; ++i) {
+        const int blk = i * 4 + wave;
+        if (blk * 64 < nchunks) {
+          const int c = min(blk * 64 + lane, nchunks - 1);
+          lds_dma<16>(reinterpret_cast<const char *>(p.b) + c * 16, wbuf + blk * 1024);
+        }
+      }
+    }
+  }
 
   // loop-invariant per-thread state: LDS byte offsets of my channels, gathered RMSNorm weights
   int off[NP][16];
@@ -217,9 +234,20 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) off[ps][k] = (e0 + k) * 2;
     }
-    if constexpr (NORM) {
+  }
+  if constexpr (NORM) {
+    if (p.w_lds) {
+      __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0): the weight vector (and row 0) have landed
+      __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 16; ++k) wg[ps][k] = (float)p.b[off[ps][k] >> 1];
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wg[ps][k] = (float)*reinterpret_cast<const half_t *>(wbuf + off[ps][k]);
+    } else {                                                // (hidden 16384 with the fused residual add: LDS is full)
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wg[ps][k] = (float)p.b[off[ps][k] >> 1];
     }
   }
 
@@ -356,8 +384,13 @@ static int resident_blocks(K kernel, size_t lds) {           // persistent grid:
 }
 
 template <int OP, bool SIM, bool DQ, int NP>
-static void launch_act_quant2_np(const ActQuantParams &p, hipStream_t s) {
-  const size_t lds = (OP == OP_ADD_RMSNORM ? 4 : 2) * (size_t)((p.H * 2 + 1023) & ~1023) + 64;
+static void launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
+  ActQuantParams p = p0;
+  const size_t rowb = (size_t)((p.H * 2 + 1023) & ~1023);
+  constexpr bool NORMOP = OP == OP_RMSNORM || OP == OP_ADD_RMSNORM;
+  const size_t base = (OP == OP_ADD_RMSNORM ? 4 : 2) * rowb + 1024;
+  p.w_lds = NORMOP && base + rowb <= 160 * 1024;
+  const size_t lds = base + (p.w_lds ? rowb : 0);
   // occupancy depends on the LDS size, i.e. on H; cache the last answer (benign race: same inputs, same value)
   static size_t cached_lds = 0;
   static int resident = 0;
