@@ -756,7 +756,7 @@ __device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char
                                        float (&c)[4][8][4], FS sync, FD mid, FT stamp) {
   const int l15 = lane & 15, kb = lane >> 4;
   const bool older = wm == 0;                               // waves 0-3 (the first wave of each SIMD)
-  const char *pw = slot + wn * 64 * PITCH, *pa = slot + C::A_OFF + wm * 128 * PITCH;
+  const char *pa = slot + C::A_OFF + wm * 128 * PITCH;
   const char *npw = nslot + wn * 64 * PITCH, *npa = nslot + C::A_OFF + wm * 128 * PITCH;
   const char *psa = pa + l15 * (2 * PITCH) + 96, *npsa = npa + l15 * (2 * PITCH) + 96;
   // ABL & 256 (tools): the same LDS reads into the same registers, but issued through inline asm the compiler does not track, so

@@ -1,7 +1,7 @@
 # Samples clocks and power while the headline GEMM runs back to back (is the chip power-limited?).
 # usage: tools/clock_probe.sh [env...]   (run on the GPU box through gpurun)
 R=$GRAFT_REPO_ROOT
-env "$@" $R/build/gemm_bench 4096 4096 4096 20000 0 > /tmp/gb.log 2>&1 &
+env "$@" $R/build/tools/gemm_bench 4096 4096 4096 20000 0 > /tmp/gb.log 2>&1 &
 PID=$!
 sleep 2
 for i in 1 2 3 4; do

@@ -1,6 +1,6 @@
 // Native tuning harness for libatom_hip.so (no Python): correctness against a naive GPU kernel + hipEvent timing.
-//   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -o build/gemm_bench -Latom_amd -latom_hip -Wl,-rpath,$PWD/atom_amd
-//   build/gemm_bench M N K iters [check_rows]
+//   make -C atom_amd/csrc tools   (builds build/tools/gemm_bench against the -DATOM_TOOLS library, which reads ATOM_F6_CFG etc.)
+//   build/tools/gemm_bench M N K iters [check_rows]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

@@ -8,7 +8,7 @@ cd /tmp
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   n=$(echo $set | cut -d' ' -f1)
-  env "$@" rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$n -o g -- $R/build/gemm_bench 4096 4096 4096 40 0 > $OUT/$n.log 2>&1
+  env "$@" rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$n -o g -- $R/build/tools/gemm_bench 4096 4096 4096 40 0 > $OUT/$n.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections

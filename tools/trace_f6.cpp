@@ -1,5 +1,5 @@
-// Dump s_memtime stamps of workgroup 0 of the F6 prefill kernel (ablation build of the library: -DATOM_F6_ABLATE,
-// ATOM_F6_CFG=116).  build/abl/trace_f6
+// Dump s_memtime stamps of workgroup 0 of the F6 prefill kernel (tools build of the library: make -C atom_amd/csrc tools,
+// ATOM_F6_CFG=116; first-generation 32x32x64 kernel).  build/tools/trace_f6
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
