@@ -54,6 +54,7 @@ SIGNATURES = {
     "atom_repack_weight_f6": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "atom_repack_act_f6": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "atom_f6_weight_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "atom_gemm_w4a4_f6_order": (ctypes.c_int, [_i64, _i64, _i64]),
     "atom_repack_weight_f6s": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "atom_kv_fake_quant_f16": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "atom_kv_append_i4": (_int, [_vp] * 10 + [_i64] + [_int] * 6 + [_vp]),

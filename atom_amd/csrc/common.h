@@ -8,10 +8,10 @@
 
 // Tuning overrides.  The product library takes NO behaviour from the environment (include/atom_hip.h: "no global state"):
 // ATOM_TUNE(name, default) is the default, and the string does not even reach the binary.  The tools build (make tools,
-// -DATOM_TOOLS) reads the override from the environment variable `name` once.
+// -DATOM_TOOLS) reads the override from the environment variable `name` at every call (a probe may change it between launches).
 #ifdef ATOM_TOOLS
 #include <cstdlib>
-#define ATOM_TUNE(name, dflt) ([]() -> int { static const int v = [] { const char *e = getenv(name); return e ? atoi(e) : (dflt); }(); return v; }())
+#define ATOM_TUNE(name, dflt) ([]() -> int { const char *e = getenv(name); return e ? atoi(e) : (dflt); }())
 #else
 #define ATOM_TUNE(name, dflt) (dflt)
 #endif

@@ -46,25 +46,28 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
 // Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt).  256x256 (one workgroup per CU, the q kernel)
 // when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles' work in
 // ~2.4x their time; else 128x128 (three workgroups per CU); 64x128 + split-K only for very few tiles with a long K.
-static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
+static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total, bool in_order = false) {
   const int force = ATOM_TUNE("ATOM_F6_CFG", -1);
   if (force >= 0) return force;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const int64_t rounds = (t256 + 255) / 256;
+  const int64_t t64 = ((M + 63) / 64) * ((N + 127) / 128);
+  const int64_t rounds = (t256 + 255) / 256, steps = (K_total - kKeeper) / kGroup + 2;
   if (t256 >= 144 && 5 * t256 >= 3 * rounds * 256) return 0;
-  if (t128 >= 128 || K_total <= 8192) return 3;
-  return 2;
-}
-// K splits of the 128x128 geometry (needs the caller's workspace): two when the tiles fill at most a sixth of the 768 slots, or
-// less than a third with a long K (512x4096x11008: 78.8 -> 51.9 us, 768x...: 79.0 -> 62.3; 768x4096x4096: 32.5 vs 34.0 -> none)
-static int f6_splits_128(int64_t M, int64_t N, int64_t K_total) {
-  const int s3 = ATOM_TUNE("ATOM_F6_SPLITS3", 0);
-  if (s3 > 0) return s3;
-  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
-  return (t128 <= 144 || (K_total > 8192 && t128 < 256)) ? 2 : 1;
+  // at most one tile per CU: a lone 4-wave workgroup is latency-bound (barrier, fragment loads: ~1 us per K step), so two
+  // groups of 4 waves share the tile and its K steps (profiles/r02_mid_m.txt: 1024x4096x4096 33.1 -> 23.4 us, 512x..: 26.3 ->
+  // 18.4).  The result is the sum of two ordered halves of the K steps (atom_gemm_w4a4_f6_order).
+  if (!in_order && steps >= 8 && t64 <= 256) return 9;
+  if (!in_order && steps >= 8 && t128 <= 256) return 6;
+  return 3;
 }
 
 extern "C" {
+
+int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total) {
+  if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  const int cfg = f6_pick_cfg(M, N, K_total);
+  return (cfg == 5 || cfg == 6 || cfg == 9) ? 2 : 1;
+}
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }
 
@@ -230,7 +233,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
     p.f6_rows_a = (M + 255) / 256 * 256;
     p.f6_rows_b = (N + 255) / 256 * 256;
     p.sB32 = sb32;
-    return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);
+    return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total, true), hs);   // packed callers: the INT8 kernels' summation order
   }
   if (p.a_wide || p.f6_rows_a) {                                      // native formats: no workspace route for these sizes
     if (choose_splits(M, N, K_total) <= 1)
@@ -238,14 +241,11 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   }
   p.ws = (float *)workspace;
   p.splits = choose_splits(M, N, K_total);
-  if (p.f6_rows_a) {
+  if (p.f6_rows_a) {                                                  // the F6 kernels need no workspace (tools: ATOM_F6_SPLITS3)
     const int cfg = f6_pick_cfg(M, N, K_total);
-    if (cfg == 3 || cfg == 4) {
-      int sp = f6_splits_128(M, N, K_total);
-      if (sp > p.splits) sp = p.splits;                      // the workspace was sized for choose_splits()
-      p.splits = sp;
-      if (sp < 2) p.ws = nullptr;
-    } else if (cfg != 2) { p.ws = nullptr; p.splits = 1; }
+    const int sp = ATOM_TUNE("ATOM_F6_SPLITS3", 0);
+    if ((cfg == 3 || cfg == 4) && sp > 1 && sp <= p.splits) p.splits = sp;
+    else { p.ws = nullptr; p.splits = 1; }
     return launch_gemm_f6(p, cfg, reinterpret_cast<hipStream_t>(stream));
   }
   return launch_gemm_v3(p, p.a_wide ? 25 : 5, reinterpret_cast<hipStream_t>(stream));

@@ -40,8 +40,9 @@ constexpr int kMagicBits = 0x4B400000;
 // Tile geometry.  Three instances: 256x256 (8 waves, one workgroup per CU) once the shape yields ~200 of them,
 // 256x128 (4 waves, two workgroups per CU, two stages), and 64x128 (2 waves, several workgroups per CU, split-K) for
 // skinny M.
-template <int BM_, int BN_, int TM_, int NS_, int OCC_ = 2>
+template <int BM_, int BN_, int TM_, int NS_, int OCC_ = 2, int FS_ = 0>
 struct Cfg {
+  static constexpr int FS = FS_;                                       // 1: float32 weight scales staged per int4 step (ATOM_B_F6S)
   static constexpr int OCC = OCC_;                                     // waves per SIMD the register budget is set for
   static constexpr int BM = BM_, BN = BN_, TM = TM_, NS = NS_;
   static constexpr int WM = 32 * TM, WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
@@ -49,13 +50,14 @@ struct Cfg {
   static constexpr int NBW = W_BYTES / 1024;                           // whole 1 KiB DMA blocks of the weight rows
   static constexpr int NBA = (A_BYTES + 1023) / 1024;                  // activation rows: the last block may be partial
   static constexpr int A_TAIL = (A_BYTES % 1024) / 16;                 // lanes of that partial block (0 = it is whole)
-  static constexpr int NSB = BN / 128;                                 // weight-scale pieces (128 fp16 = 64 dwords each)
+  static constexpr int NSB8 = BN / 128;                                // weight-scale pieces (128 fp16 = 64 dwords each)
+  static constexpr int NSB = FS ? BN / 64 : NSB8;                      // ... of an int4 step (float32: 64 per piece)
   static constexpr int A_OFF = W_BYTES;
   static constexpr int SB_OFF = W_BYTES + NBA * 1024;                  // BN fp16 weight scales (int4 steps and keeper)
-  static constexpr int STAGE_BYTES = SB_OFF + BN * 2;
+  static constexpr int STAGE_BYTES = SB_OFF + BN * (FS ? 4 : 2);
   static constexpr int KP_SA_OFF = (BN + BM) * 64;                     // keeper half-steps: rows of 64 B, then BM dwords sA8
   static constexpr int NPIECE = NBW + NBA + NSB;                       // DMA instructions per int4 stage
-  static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB;           // ... per keeper half-step
+  static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB8;          // ... per keeper half-step
   // The LDS-DMA instructions are issued by the first NDW waves.
   static constexpr int NDW = NW;   // (measured: NW / 2 -- only the older wave of each SIMD issuing -- is 6 % slower)
   static constexpr int GLDS = ((NPIECE > NKP ? NPIECE : NKP) + NDW - 1) / NDW;  // per issuing wave, padded with repeats
@@ -71,7 +73,7 @@ __device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, cha
   const uint8_t *wsrc = p.B4 + ((int64_t)g * p.f6_rows_b + n0) * PITCH;
   const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - C::W_BYTES;   // block j >= NBW is asrc + j*1024
   int j = i * C::NDW + wave;                               // piece j: NBW weight blocks, NBA activation blocks, NSB scales
-  j = j < C::NPIECE ? j : j - C::NSB;                      // padding repeats a scale piece (same bytes, same place)
+  j = j < C::NPIECE ? j : C::NPIECE - C::NSB + (j - C::NPIECE) % C::NSB;   // padding repeats a scale piece (same bytes, same place)
   if (i * C::NDW + C::NDW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {              // compile time: whole data blocks only
     const uint8_t *base = (i * C::NDW + C::NDW <= C::NBW || j < C::NBW) ? wsrc : asrc;
     lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
@@ -80,6 +82,9 @@ __device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, cha
     // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
     if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
       lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
+  } else if constexpr (C::FS) {                            // 64 float32 weight scales per piece (rows padded: no clamp)
+    const int part = j - (C::NBW + C::NBA);
+    lds_dma<4>(p.sB32 + (int64_t)g * p.f6_rows_b + n0 + part * 64 + lane, slot + C::SB_OFF + part * 256);
   } else {                                                 // 128 weight scales per piece, a dword (2 channels) per lane
     const int part = j - (C::NBW + C::NBA);
     const half_t *sBb = p.sB + (int64_t)g * p.N;
@@ -103,7 +108,7 @@ __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char
 #pragma unroll
   for (int i = 0; i < C::GLDS; ++i) {
     int j = i * C::NDW + wave;
-    j = j < C::NKP ? j : ND + NSA + (j % C::NSB);          // padding repeats a weight-scale piece
+    j = j < C::NKP ? j : ND + NSA + (j % C::NSB8);         // padding repeats a weight-scale piece
     if (i * C::NDW + C::NDW <= ND || j < ND) {               // (first half: known at compile time)
       const int row = j * 16 + (lane >> 2);
       const unsigned idx = (unsigned)(j < C::BN / 16 ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
@@ -444,25 +449,32 @@ __device__ __forceinline__ void dequant4x(const v4f_t &acc, float sa, const v2u 
   }
 }
 
-template <class C, class F = NoDma>
+// PH: a workgroup barrier in the middle of the step (the two K groups of a workgroup run half a step apart: one group's
+// fragment loads behind its step-start barrier meet the other group's second half of MFMAs instead of its loads)
+template <class C, class F = NoDma, bool PRIO = (C::NW >= 8), bool PH = false>
 __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4], F dma = F(),
-                                                 bool older = false) {
+                                                 bool older = false, unsigned *tp = nullptr) {
   const int l15 = lane & 15, kb = lane >> 4;
   const char *pw = slot + (wn * 64 + l15) * PITCH + kb * 24;                  // + fb*16*PITCH
   constexpr int NTB = C::WM / 16;                                             // token blocks of the wave tile
   const char *pa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + kb * 24;    // + tb*16*PITCH
   const char *psa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + 96;        // + tb*16*PITCH
-  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;                // + fb*32
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * (C::FS ? 4 : 2);  // + fb*32 (float32: fb*64)
   v8i af[4], bf[2];
-  v2u sb[4];
+  // scales: float32 straight into the de-quantisation (C::FS: the record's float32 token scale, the staged float32 weight
+  // scales) or fp16 converted per use
+  using sa_t = typename std::conditional<C::FS != 0, float, half_t>::type;
+  using sb_t = typename std::conditional<C::FS != 0, v4f_t, v2u>::type;
+  constexpr int SA_AT = C::FS ? 4 : 0;
+  sb_t sb[4];
   // fragment loads in the order the MFMAs consume them (all 8 waves hit the LDS at once behind the barrier)
   bf[0] = frag24(pa);
   af[0] = frag24(pw);
-  half_t sah = *reinterpret_cast<const half_t *>(psa);
+  sa_t sah = *reinterpret_cast<const sa_t *>(psa + SA_AT);
 #pragma unroll
   for (int fb = 1; fb < 4; ++fb) af[fb] = frag24(pw + fb * 16 * PITCH);
 #pragma unroll
-  for (int fb = 0; fb < 4; ++fb) sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
+  for (int fb = 0; fb < 4; ++fb) sb[fb] = *reinterpret_cast<const sb_t *>(psb + fb * (C::FS ? 64 : 32));
   // tiles in pairs (fb 0,1 / 2,3 of a token block): a pair's MFMAs are issued one pair ahead of its 16 VALU instructions
   // (8 multiplies, then 8 FMAs: no dependent back-to-back issue)
   constexpr int GS = 2, NG = 4 * NTB / GS, GPB = 4 / GS, DEPTH = 1;
@@ -472,23 +484,35 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
 #pragma unroll
     for (int k = 0; k < GS; ++k) {
       acc[g % (DEPTH + 1)][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
-      acc[g % (DEPTH + 1)][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[f0 + k], bf[tb & 1], acc[g % (DEPTH + 1)][k], 3, 3, 0, 127, 0, 127);
+      if constexpr (C::FS)   // scale operands 0, 0 select the unscaled v_mfma_f32_16x16x128_f8f6f4 (8 % shorter issue)
+        acc[g % (DEPTH + 1)][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[f0 + k], bf[tb & 1], acc[g % (DEPTH + 1)][k], 3, 3, 0, 0, 0, 0);
+      else
+        acc[g % (DEPTH + 1)][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[f0 + k], bf[tb & 1], acc[g % (DEPTH + 1)][k], 3, 3, 0, 127, 0, 127);
     }
   };
   mma(0);
+#ifdef ATOM_TOOLS
+  if (tp) { __builtin_amdgcn_sched_barrier(0); tp[0] = (unsigned)__builtin_amdgcn_s_memtime(); }   // first MFMAs issued: fragments arrived
+#endif
   float sa = 0.f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int tb = g / GPB, f0 = (g % GPB) * GS;
     __builtin_amdgcn_sched_barrier(0);
+#ifdef ATOM_TOOLS
+    if (tp && g == NG / 2) tp[1] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     if (g % GPB == 0) {
       sa = (float)sah;
       if (tb + 1 < NTB) {
         bf[(tb + 1) & 1] = frag24(pa + (tb + 1) * 16 * PITCH);
-        sah = *reinterpret_cast<const half_t *>(psa + (tb + 1) * 16 * PITCH);
+        sah = *reinterpret_cast<const sa_t *>(psa + SA_AT + (tb + 1) * 16 * PITCH);
       }
       // the two waves of a SIMD swap priority mid-step (see compute_int4)
-      if constexpr (C::NW >= 8) {
+      if constexpr (PH) {
+        if (tb == NTB / 2) __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (PRIO) {
         if (tb == 0) { if (older) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
         if (tb == NTB / 2) { if (older) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
       }
@@ -507,10 +531,12 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
         for (int r = 0; r < 4; ++r) t[4 * k + r] = acc[g % (DEPTH + 1)][k][r] * sa;
 #pragma unroll
       for (int k = 0; k < GS; ++k) {
-        const half_t *hv = reinterpret_cast<const half_t *>(&sb[f0 + k]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          c[f0 + k][tb][r] = __builtin_fmaf(t[4 * k + r], (float)hv[r], c[f0 + k][tb][r]);
+          float w;
+          if constexpr (C::FS) w = sb[f0 + k][r];
+          else w = (float)reinterpret_cast<const half_t *>(&sb[f0 + k])[r];
+          c[f0 + k][tb][r] = __builtin_fmaf(t[4 * k + r], w, c[f0 + k][tb][r]);
           asm volatile("" : "+v"(c[f0 + k][tb][r]));
         }
       }
@@ -519,7 +545,7 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
 }
 
 // keeper half-step on v_mfma_i32_16x16x64_i8, same tile layout; each half de-quantised on its own (the contract)
-template <class C>
+template <class C, bool PH = false>
 __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4]) {
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 2) & 3;
@@ -537,6 +563,9 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
   }
 #pragma unroll
   for (int tb = 0; tb < NTB; ++tb) {
+    if constexpr (PH) {
+      if (tb == NTB / 2) __builtin_amdgcn_s_barrier();
+    }
     const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + tb * 1024));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + tb * 64);
 #pragma unroll
@@ -549,16 +578,25 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
   }
 }
 
-template <class C, bool SK = false>
-__global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+// KG = 2: two groups of C::NW waves share the tile and split its K steps in halves (each group with its own LDS ring); the
+// halves are added through the LDS at the end, lower K range first -- the arithmetic of the split-K route with two splits,
+// without its FP32 round trip through HBM.  For shapes with at most one 128x128 tile per CU: the second wave per SIMD hides the
+// barrier and fragment-load latency of the first.
+template <class C, bool SK = false, int KG = 1, bool PH = false, bool TR = false>
+__global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
   constexpr int NS = C::NS;
   constexpr int NTB = C::WM / 16;
   static_assert(C::WM % 32 == 0 && NS >= 2, "x16: wave tiles of 64 features x 32, 64 or 128 tokens");
+  static_assert(KG == 1 || (KG == 2 && !SK && NTB % 2 == 0), "K groups: two, without the global split");
+  static_assert(!PH || KG == 2, "the half-step phase shift is between two K groups");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave_all >= 0 && wave_all < C::NW * KG);
+  const int kg = KG > 1 ? wave_all / C::NW : 0;
+  const int wave = KG > 1 ? wave_all % C::NW : wave_all;
+  char *lds = lds_all + kg * (NS * C::STAGE_BYTES);
   const int wm = wave / C::WGN, wn = wave % C::WGN;
   const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
   const int nwg = nbm * nbn;
@@ -583,8 +621,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
 
   // split-K (SK): blockIdx.y owns the K steps [s_begin, nsteps) and writes FP32 partial sums to p.ws
   const int total_steps = p.G + 2;
-  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
-  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;
+  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : (KG > 1 ? total_steps * kg / KG : 0);
+  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : (KG > 1 ? total_steps * (kg + 1) / KG : total_steps);
   auto issue = [&](int step) {
     char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
@@ -593,23 +631,48 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
   };
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s_begin + s);
-  const bool older = wave < C::NW / 2;
+  const bool older = KG > 1 ? kg == 0 : wave < C::NW / 2;
+  constexpr bool PRIO = KG > 1 || C::NW >= 8;
+  // tools build, TR: s_memtime stamps of workgroup 0, 64 dwords per wave in the LDS behind the stages, copied to p.Dsz at the
+  // end: [0] entry, [1] first stages issued, [2 + 6 j + k] step j < 10 of the wave's range: k = 0 loop top, 1 stage landed
+  // (vmcnt), 2 behind the barrier, 3 first MFMAs issued, 4 half of the tiles done, 5 step done; [62] loop done, [63] end
+  unsigned *trl = nullptr;
+  if constexpr (TR) {
+    if (blockIdx.x == 0) trl = reinterpret_cast<unsigned *>(lds_all + KG * NS * C::STAGE_BYTES) + wave_all * 64;
+  }
+  auto stamp = [&](int k) {
+    if constexpr (TR) {
+      if (trl) { __builtin_amdgcn_sched_barrier(0); const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) trl[k] = t; __builtin_amdgcn_sched_barrier(0); }
+    }
+  };
+  stamp(1);
+  if constexpr (PH) {
+    if (kg == 1) __builtin_amdgcn_s_barrier();             // the second group runs half a step behind
+  }
   int step = s_begin;
   for (; step + NS - 1 < min(p.G, nsteps); ++step) {
+    const bool tr_on = TR && trl && step - s_begin < 10;
+    const int tb_ = 2 + 6 * (step - s_begin);
+    if (tr_on) stamp(tb_);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
+    if (tr_on) stamp(tb_ + 1);
     __builtin_amdgcn_s_barrier();
+    if (tr_on) stamp(tb_ + 2);
     char *nslot = lds + ((step + NS - 1) % NS) * C::STAGE_BYTES;
     const int g = step + NS - 1;
     auto dma = [&](int i) { issue_int4_piece<C>(p, g, nslot, wave, lane, m0, n0, i); };
     __builtin_amdgcn_sched_barrier(0);
-    compute_int4_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, older);
+    unsigned tmp2[2] = {0, 0};
+    compute_int4_x16<C, decltype(dma), PRIO, PH>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, dma, older, tr_on ? tmp2 : nullptr);
+    if (tr_on) { if (lane == 0) { trl[tb_ + 3] = tmp2[0]; trl[tb_ + 4] = tmp2[1]; } stamp(tb_ + 5); }
   }
+  stamp(62);
   for (; step < min(p.G, nsteps); ++step) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     issue(step + NS - 1);
     __builtin_amdgcn_sched_barrier(0);
-    compute_int4_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), older);
+    compute_int4_x16<C, NoDma, PRIO, PH>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), older);
   }
   __builtin_amdgcn_s_setprio(0);
   for (; step < nsteps; ++step) {
@@ -617,12 +680,71 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
     __builtin_amdgcn_s_barrier();
     issue(step + NS - 1);
     __builtin_amdgcn_sched_barrier(0);
-    compute_keeper_x16<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);
+    compute_keeper_x16<C, PH>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const int l15 = lane & 15, kb = lane >> 4;
+  constexpr int EP_STRIDE = 144;
+  if constexpr (PH) {
+    if (kg == 0) __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (KG > 1) {
+    // one barrier per K step above: the group with the shorter range catches up
+    for (int i = (nsteps - s_begin) * (PH ? 2 : 1); i < (total_steps + KG - 1) / KG * (PH ? 2 : 1); ++i) __builtin_amdgcn_s_barrier();
+    // each group finishes half of the token blocks: it hands the other half of its sums over and adds the partner's
+    constexpr int HB = NTB / 2, XF = HB * 16;             // floats per lane handed over
+    float *xw = reinterpret_cast<float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + (kg * C::NW + wave) * XF * 64 + lane;
+    const float *xr = reinterpret_cast<const float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + ((1 - kg) * C::NW + wave) * XF * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (h != kg) {
+#pragma unroll
+        for (int t = 0; t < HB; ++t)
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xw[((t * 4 + fb) * 4 + r) * 64] = c[fb][h * HB + t][r];
+      }
+    __builtin_amdgcn_s_barrier();
+    char *ep = lds_all + wave_all * (HB * 16 * EP_STRIDE);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (h == kg) {
+#pragma unroll
+        for (int t = 0; t < HB; ++t)
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb) {
+            v2u o;
+            half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float other = xr[((t * 4 + fb) * 4 + r) * 64];
+              ov[r] = f2h(kg == 0 ? c[fb][h * HB + t][r] + other : other + c[fb][h * HB + t][r]);
+            }
+            *reinterpret_cast<v2u *>(ep + (t * 16 + l15) * EP_STRIDE + (fb * 16 + 4 * kb) * 2) = o;
+          }
+      }
+#pragma unroll
+    for (int i = 0; i < HB * 2; ++i) {
+      const int rl = i * 8 + (lane >> 3);
+      const int ch = lane & 7;
+      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
+      const int m = m0 + wm * C::WM + kg * (HB * 16) + rl;
+      const int n = n0 + wn * 64 + ch * 8;
+      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+    }
+    if constexpr (TR) {
+      if (trl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(63);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        reinterpret_cast<unsigned *>(p.Dsz)[wave_all * 64 + lane] = trl[lane];
+      }
+    }
+    return;
+  }
   if constexpr (SK) {                                     // FP32 partial tile: 4 consecutive features per lane and micro-tile
     float *wsp = p.ws + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -639,7 +761,6 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6x16_kernel(GemmPara
     return;
   }
   // epilogue: per wave [HT tokens][64 features] fp16 through LDS (row stride 144 B), HT = 64 (32 for the 32-token wave tile)
-  constexpr int EP_STRIDE = 144;
   constexpr int HT = C::WM < 64 ? C::WM : 64;
   char *ep = lds + wave * (HT * EP_STRIDE);
 #pragma unroll
@@ -1468,13 +1589,16 @@ static int launch_p(const GemmParams &p, hipStream_t s) {
   return check_launch();
 }
 
-template <class C, bool SK = false>
+template <class C, bool SK = false, int KG = 1, bool PH = false, bool TR = false>
 static int launch_x16(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  constexpr int XCH = C::NW * KG * (C::WM / 2) * (144 + 64 * 4);      // K groups: epilogue rows + the sums handed over
+  constexpr int LDS = (KG > 1 ? (KG * C::NS * C::STAGE_BYTES > XCH ? KG * C::NS * C::STAGE_BYTES : XCH) : C::LDS_BYTES) + (TR ? 2048 : 0);
+  static_assert(LDS <= 160 * 1024, "LDS");
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK, KG, PH, TR>), LDS, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C, SK>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT),
-                     C::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6x16_kernel<C, SK, KG, PH, TR>), dim3((unsigned)(nbm * nbn), (unsigned)(SK ? p.splits : 1)), dim3(C::NT * KG),
+                     LDS, s, p);
   if (SK) {
     const int64_t MN = (int64_t)p.M * p.N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.ws, p.D, MN, p.splits);
@@ -1519,6 +1643,14 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(6) ATOM_ABL(7) ATOM_ABL(8) ATOM_ABL(10) ATOM_ABL(14) ATOM_ABL(15) ATOM_ABL(32)
 #undef ATOM_ABL
   }
+  if (cfg == 1005 || cfg == 1009) {   // traced run of the two-K-group kernels (tools/trace_f6kg.cpp)
+    const char *e = getenv("ATOM_TRACE_PTR");
+    if (!e || !p.sB32) return ATOM_ERR_INVALID_ARG;
+    GemmParams q = p;
+    q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+    if (cfg == 1005) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2, false, true>(q, s);
+    return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, false, true>(q, s);
+  }
   if (cfg == 1016) {   // traced run of the pipelined kernel (tools/trace_f6.cpp)
     const char *e = getenv("ATOM_TRACE_PTR");
     if (!e) return ATOM_ERR_INVALID_ARG;
@@ -1542,9 +1674,24 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
   if (cfg == 3) {                                                              // 4 waves, three workgroups per CU
+    if (p.sB32) {                                                              // float32 weight scales (ATOM_B_F6S)
+      if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, true>(p, s);
+      return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);
+    }
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, true>(p, s);
     return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
   }
+  // two K groups of 4 waves per workgroup: for shapes that put at most one tile on a CU (f6_pick_cfg)
+  if (cfg == 5 || cfg == 6) {                                                  // 128x128; 2 (tuning) / 3 stages per group
+    if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
+                                : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
+    return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3>, false, 2>(p, s);
+  }
+  if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
+    if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
+    return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3>, false, 2, true>(p, s);
+  }
+  if (cfg == 53) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);            // tuning: cfg 3 with fp16 weight scales
   if (cfg == 40) return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // tuning: 256x256, first-generation micro-tile kernel
   if (cfg == 4) {                                                              // 128x128, 8 waves of 64 features x 32 tokens
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 1, 2, 3>, true>(p, s);

@@ -78,12 +78,17 @@ extern "C" {
  * de-quantisation registers (no fp16 -> fp32 conversions in the K loop); `sB` (fp16) is still required -- the other tile
  * geometries read it.
  * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
- * still written).  Weights: atom_repack_weight_f6.  Results are bit-identical to the INT8 kernels.  M, N >= 1 as usual;
- * three tile geometries (256x256, 128x128, 64x128 + split-K through atom_gemm_w4a4_f16_ws) picked by shape; ahead of the
- * INT8 kernels from 256 rows up (1.3-1.4x at 1-2k rows, 1.35x at 4096^3).
+ * still written).  Weights: atom_repack_weight_f6.  M, N >= 1 as usual; tile geometries picked by shape: 256x256 and
+ * 128x128 (4 waves) -- results bit-identical to the INT8 kernels -- and, for shapes of at most 256 tiles (one per CU: mid-size
+ * prefill batches, 256..1024 rows at Llama widths), 128x128 / 64x128 tiles shared by two groups of 4 waves that split the
+ * K steps (the G int4 groups, then the two keeper halves) at (G + 2) / 2: each half is summed in order from 0 and
+ * D = half(first + second) -- deterministic, same tolerance, 1.4x faster there (1024x4096x4096: 33 -> 23 us).
+ * atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in order, 2 = two halves (0 = unsupported shape).
+ * Ahead of the INT8 kernels from 256 rows up (1.5x at 512-1024 rows, 1.35x at 4096^3).
  */
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
+int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
 #define ATOM_B_F6S 0x400
 /* atom_gemm_w4a4_o4 / _o4_ws only: the u4 epilogue exactly as the reference CODE computes it -- its local_max_min takes abs() of
  * both extrema (DenseLayerGEMM_i4_o4.cu:73-80), so scale = (max|x| - min|x|) / 15, zero = -min|x|, and the code is

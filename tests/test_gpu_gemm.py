@@ -359,8 +359,51 @@ def test_gemm_f6_operands_bit_identical(M, N, K):
     assert np.array_equal(t2n(b6), f6_codes(d["qb4"]))
     out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
     assert_gemm_close(t2n(out), _exact(d), f"f6 {M}x{N}x{K}")
-    if M > 256 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+    order = ops.L.lib().atom_gemm_w4a4_f6_order(M, N, K)
+    if order == 2:                                        # two K groups per tile: first half + second half of the K steps
+        from tests import c_oracle
+        want = c_oracle.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"].T), d["sB"],
+                             d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=-2)
+        assert np.array_equal(bits16(t2n(out)), bits16(want))
+    elif M > 256 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
+        assert order == 1
         assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"))
+
+
+# mid-size prefill batches (at most one tile per CU): 64x128 / 128x128 tiles shared by two groups of 4 waves that split the K
+# steps.  Whole and ragged tiles in both dimensions, odd and even step counts, with and without the appended fp32 weight scales.
+@pytest.mark.parametrize("M,N,K,want_cfg", [(1024, 4096, 4096, "128x128"), (512, 4096, 4096, "64x128"), (300, 1088, 1152, "64x128"),
+                                            (700, 2112, 2176, "64x128"), (1000, 3136, 1408, "128x128"), (257, 10880, 1024, "128x128"),
+                                            (2048, 2048, 1152, "128x128")])
+@pytest.mark.parametrize("f6s", [True, False])
+def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
+    """Bit for bit against the C restatement with the K steps summed in two ordered halves (oracle gemm_core, nsplit = -2), on
+    rows from the first, a middle and the last tile; the whole output against the exact value."""
+    from tests import c_oracle
+    from tests.helpers import f6_codes
+    ops = _ops()
+    lib = ops.L.lib()
+    t64, t128 = -(-M // 64) * -(-N // 128), -(-M // 128) * -(-N // 128)
+    assert (t64 <= 256) == (want_cfg == "64x128") and t128 <= 256                       # the dispatch rule this case is meant to hit
+    assert lib.atom_gemm_w4a4_f6_order(M, N, K) == 2
+    d = rand_gemm_operands(M, N, K, seed=5 * M + N + 3 * K)
+    t = to_device(d, "plain")
+    a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+    b6 = ops.repack_weight_f6(t[1], t[3]) if f6s else ops.repack_weight_f6(t[1])
+    out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
+    assert_gemm_close(t2n(out), _exact(d), f"f6 two K groups {M}x{N}x{K}")
+    rows = np.unique(np.r_[0:6, M // 2 - 3:M // 2 + 3, M - 6:M])
+    want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-2)
+    assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
+    # the plain entry point takes the same route (no workspace involved)
+    D = torch.empty_like(out)
+    flags = ops.L.SCALE_LAYOUT_PLAIN | ops.L.AB_F6 | (ops.L.B_F6S if f6s else 0)
+    bbuf = b6.atom_f6s if f6s else b6
+    st = lib.atom_gemm_w4a4_f16(a6.data_ptr(), bbuf.data_ptr(), *[x.data_ptr() for x in t[2:]], D.data_ptr(), M, N, K, 128, 128, flags,
+                                ops.L.current_stream(D.device))
+    ops.L.check(st, "atom_gemm_w4a4_f16")
+    assert torch.equal(D, out)
 
 
 def test_gemm_f6_full_size_from_the_quantiser():
