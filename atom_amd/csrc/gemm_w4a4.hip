@@ -46,7 +46,7 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
 // Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt).  256x256 (one workgroup per CU, the q kernel)
 // when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles' work in
 // ~2.4x their time; else 128x128 (three workgroups per CU); 64x128 + split-K only for very few tiles with a long K.
-static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total, bool in_order = false) {
+static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   const int force = ATOM_TUNE("ATOM_F6_CFG", -1);
   if (force >= 0) return force;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
@@ -56,8 +56,8 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total, bool in_order = fa
   // at most one tile per CU: a lone 4-wave workgroup is latency-bound (barrier, fragment loads: ~1 us per K step), so two
   // groups of 4 waves share the tile and its K steps (profiles/r02_mid_m.txt: 1024x4096x4096 33.1 -> 23.4 us, 512x..: 26.3 ->
   // 18.4).  The result is the sum of two ordered halves of the K steps (atom_gemm_w4a4_f6_order).
-  if (!in_order && steps >= 8 && t64 <= 256) return 9;
-  if (!in_order && steps >= 8 && t128 <= 256) return 6;
+  if (steps >= 8 && t64 <= 256) return 9;
+  if (steps >= 8 && t128 <= 256) return 6;
   return 3;
 }
 
@@ -193,12 +193,13 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
   return s < 2 ? 1 : (int)s;
 }
 
-// Packed operands of prefill size: re-code both into the F6 format (two bandwidth-bound launches, ~10 us at 4096^3) and run
-// the block-scaled-MFMA kernels -- 80 instead of 88 us at 4096^3, bit-identical.  From 2048 rows (1024x4096x4096: 47 vs 43 us
-// once the re-coding is paid).
+// Packed operands of prefill size: re-code both into the F6 format (one bandwidth-bound launch, ~8 us at 1024x4096x4096, ~12 us
+// at 4096^3) and run the block-scaled-MFMA kernels: 70-75 instead of 92 us at 4096^3.  From ATOM_F6_ROUTE_MIN_M = 512 rows since
+// the two-K-group kernels (1024x4096x4096: 45 us on the INT8 kernels, 24 + 8 here; 512x..: 31 vs 18 + 8); below, the decode-batch
+// kernel and the INT8 tile kernels win.
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
   const int off = ATOM_TUNE("ATOM_NO_F6_ROUTE", 0);
-  return !off && M >= 2048 && N >= 2048 && K_total >= 1024;
+  return !off && M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 512) && N >= 2048 && K_total >= 1024;
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;
@@ -233,7 +234,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
     p.f6_rows_a = (M + 255) / 256 * 256;
     p.f6_rows_b = (N + 255) / 256 * 256;
     p.sB32 = sb32;
-    return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total, true), hs);   // packed callers: the INT8 kernels' summation order
+    return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);
   }
   if (p.a_wide || p.f6_rows_a) {                                      // native formats: no workspace route for these sizes
     if (choose_splits(M, N, K_total) <= 1)

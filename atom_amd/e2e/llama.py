@@ -70,10 +70,11 @@ class LinearInt4(nn.Module):
 
     def forward(self, input):
         outlier, norms, outlier_scales, norm_scales = input
-        if (norms.dim() == 2 and self.out_dtype == "fp16" and outlier.size(0) >= 2048 and self.out_features >= 2048
+        if (norms.dim() == 2 and self.out_dtype == "fp16" and outlier.size(0) >= 512 and self.out_features >= 2048
                 and self.in_features >= 1024):
-            # prefill batch in the reference's packed format: the GEMM would re-code BOTH operands to F6 in its workspace on every
-            # call; re-code the activation here and use the layer's cached F6 weight instead (same kernel, same bits)
+            # prefill batch in the reference's packed format (from 512 rows, the threshold of atom_gemm_w4a4_f16_ws): the GEMM would
+            # re-code BOTH operands to F6 in its workspace on every call; re-code the activation here and use the layer's cached F6
+            # weight instead (same kernel, same bits)
             norms = ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
         if norms.dim() == 3:                                  # the F6 activation operand [G][rows_pad][104] (fp16 output only)
             assert self.out_dtype == "fp16"

@@ -100,7 +100,8 @@ def test_gemm_full_size_vs_fp64(M, N, K):
 def test_gemm_properties_full_size():
     """Size-independent exact properties at the headline shape (no oracle needed):
        * doubling every activation scale doubles D exactly (powers of two commute with every rounding);
-       * rows are independent: computing only the first 1000 tokens reproduces those rows bit-for-bit;
+       * rows are independent: computing only the first tokens reproduces those rows bit-for-bit (among batch sizes that get
+         the same summation order, atom_gemm_w4a4_f6_order);
        * the replicated and the plain A-scale layouts give identical bits."""
     ops = _ops()
     M, N, K = 4096, 4096, 4096
@@ -112,11 +113,14 @@ def test_gemm_properties_full_size():
     normal = base.abs() >= 2.0 ** -13           # fp16 subnormal results carry fewer bits: 2*round(c) != round(2c)
     assert torch.equal(dbl[normal], (base * 2)[normal])
     assert (dbl.float() - 2 * base.float()).abs().max() <= 2.0 ** -23
-    Mh = 1000
-    sub = ops.dense_layer_gemm_i4_fp16(a[0][:Mh].contiguous(), a[1], a[2][:, :Mh].contiguous(), a[3],
-                                       a[4][:Mh].contiguous(), a[5], a[6][:Mh].contiguous(), a[7],
-                                       scale_layout="plain")
-    assert torch.equal(sub, base[:Mh])
+    rows = lambda Mh: ops.dense_layer_gemm_i4_fp16(a[0][:Mh].contiguous(), a[1], a[2][:, :Mh].contiguous(), a[3],
+                                                   a[4][:Mh].contiguous(), a[5], a[6][:Mh].contiguous(), a[7], scale_layout="plain")
+    order = ops.L.lib().atom_gemm_w4a4_f6_order
+    assert order(M, N, K) == order(2500, N, K) == 1 and order(1000, N, K) == order(600, N, K) == 2
+    assert torch.equal(rows(2500), base[:2500])                 # same summation order (K steps in order): same bits
+    sub = rows(1000)                                            # mid-size batches: two ordered halves of the K steps
+    assert torch.equal(rows(600), sub[:600])
+    assert_gemm_close(t2n(sub), t2n(base[:1000]).astype(np.float64), "rows 0..999 in the other summation order")
     r = to_device(d, "ref")
     assert torch.equal(ops.dense_layer_gemm_i4_fp16(*r, scale_layout="ref"), base)
 
