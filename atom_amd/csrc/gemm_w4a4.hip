@@ -193,13 +193,13 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
   return s < 2 ? 1 : (int)s;
 }
 
-// Packed operands of prefill size: re-code both into the F6 format (one bandwidth-bound launch, ~8 us at 1024x4096x4096, ~12 us
-// at 4096^3) and run the block-scaled-MFMA kernels: 70-75 instead of 92 us at 4096^3.  From ATOM_F6_ROUTE_MIN_M = 512 rows since
-// the two-K-group kernels (1024x4096x4096: 45 us on the INT8 kernels, 24 + 8 here; 512x..: 31 vs 18 + 8); below, the decode-batch
-// kernel and the INT8 tile kernels win.
+// Packed operands of prefill size: re-code both into the F6 format (one bandwidth-bound launch, ~12 us with its launch gap at
+// N = K = 4096) and run the block-scaled-MFMA kernels: 70-75 instead of 92 us at 4096^3.  From 768 rows since the two-K-group
+// kernels (tools/r02/packed_route_probe.py: 1024x4096x4096 36.6 us against 44.9 on the INT8 tile kernels, 768x..: 35.6 / 42.7;
+// 512x..: 31.6 against 31.1 for the INT8 kernel with split-K -- break-even, left there).
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
   const int off = ATOM_TUNE("ATOM_NO_F6_ROUTE", 0);
-  return !off && M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 512) && N >= 2048 && K_total >= 1024;
+  return !off && M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 768) && N >= 2048 && K_total >= 1024;
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;

@@ -72,7 +72,7 @@ class LinearInt4(nn.Module):
         outlier, norms, outlier_scales, norm_scales = input
         if (norms.dim() == 2 and self.out_dtype == "fp16" and outlier.size(0) >= 512 and self.out_features >= 2048
                 and self.in_features >= 1024):
-            # prefill batch in the reference's packed format (from 512 rows, the threshold of atom_gemm_w4a4_f16_ws): the GEMM would
+            # prefill batch in the reference's packed format (from 512 rows: with the cached weight the F6 kernels win from there): the GEMM would
             # re-code BOTH operands to F6 in its workspace on every call; re-code the activation here and use the layer's cached F6
             # weight instead (same kernel, same bits)
             norms = ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
