@@ -196,9 +196,21 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 
   // the first row is on its way before anything else: with one row per workgroup (decode batches) the kernel is a chain
   // of memory round trips, and the index / weight gathers below are two of them
-  int64_t r = blockIdx.x;
+  // Rows by XCD.  Neighbouring rows share cache lines in the outputs (F6 records 104 B apart, per-group scales 2 B apart) and every
+  // XCD has its own L2, so rows interleaved over all workgroups leave eight L2s as partial lines.  Workgroup i runs on XCD i % 8
+  // (round-robin dispatch): each XCD takes a contiguous eighth of the rows and its workgroups walk it side by side, so that
+  // neighbours meet in ONE L2 within a row time (65,536 x 4096 in the F6 format: reorder 240 -> 215 us, RMSNorm 250 -> 218, and
+  // SiLU x up below 313 -> 247; blocks of up to 16 consecutive rows per workgroup on top of this changed nothing).
+  int64_t r = blockIdx.x, rstep = gridDim.x, rend = p.M;
+  if (gridDim.x >= 64) {
+    const int xcd = blockIdx.x & 7;
+    const int64_t cm = (p.M + 7) >> 3;
+    r = xcd * cm + (blockIdx.x >> 3);
+    rstep = (gridDim.x - xcd + 7) >> 3;
+    rend = min((int64_t)p.M, (xcd + 1) * cm);
+  }
   int b = 0;
-  if (r < p.M) issue_row(r, 0);
+  if (r < rend) issue_row(r, 0);
   // RMSNorm weights: the whole vector rides into LDS with the first row (one more LDS-DMA stream); the per-channel gather below then
   // runs out of LDS instead of issuing 16 * NP scattered 2-byte global loads per thread behind the index loads (round 1: a second
   // dependent memory round trip before the first row could be touched -- most of the kernel at M <= 4096)
@@ -251,11 +263,11 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
     }
   }
 
-  for (; r < p.M; r += gridDim.x, b ^= 1) {
+  for (; r < rend; r += rstep, b ^= 1) {
     __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0): my DMA writes have landed
     __syncthreads();
-    const int64_t rn = r + gridDim.x;
-    if (rn < p.M) issue_row(rn, b ^ 1);
+    const int64_t rn = r + rstep;
+    if (rn < rend) issue_row(rn, b ^ 1);
     char *row = smem + b * stage;
 
     // Sum of squares: a FIXED-SHAPE FP32 tree over the row in memory order (not over the gathered channels, so the reorder index
@@ -347,7 +359,10 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 template <bool SIM, bool DQ>
 __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
   const int tid = threadIdx.x;
-  const int64_t r = blockIdx.x;
+  // rows by XCD (see act_quant2_kernel): the grid is 8 * ceil(M / 8); XCD x takes rows [x * cm, (x + 1) * cm)
+  const int64_t cm = (p.M + 7) >> 3;
+  const int64_t r = (blockIdx.x & 7) * cm + (blockIdx.x >> 3);
+  if (r >= p.M) return;
   const int H = p.H;
   const int nslots = H >> 4;
   const int Gt = H >> 7;
@@ -407,7 +422,7 @@ static void launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
 template <int OP, bool SIM, bool DQ>
 static void launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
   if constexpr (OP == OP_SILU_MUL) {
-    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)p.M), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)(((p.M + 7) >> 3) << 3)), dim3(256), 0, s, p);
   } else {
     const int np = ((p.H >> 4) + 255) >> 8;
     if (np == 1) launch_act_quant2_np<OP, SIM, DQ, 1>(p, s);
