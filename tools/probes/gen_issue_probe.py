@@ -41,9 +41,20 @@ def I(n, start=0):   # n independent fma on v112..v119
     return ["v_fma_f32 v%d, v%d, v77, v78" % (112 + (start + j) % 8, 112 + (start + j) % 8) for j in range(n)]
 
 
-def deq(kind, i, mix=False):   # de-quantisation of accumulator i: n multiplies, then n fma into v120.. (round-robin)
+def I_pk(n):   # n independent packed fma on the pairs v[112:113] .. v[118:119]
+    return ["v_pk_fma_f32 v[%d:%d], v[%d:%d], v[78:79], v[120:121]" % (112 + 2 * (j % 4), 113 + 2 * (j % 4), 112 + 2 * (j % 4), 113 + 2 * (j % 4))
+            for j in range(n)]
+
+
+def deq(kind, i, mix=False, pk=False):   # de-quantisation of accumulator i: n multiplies, then n fma into v120.. (round-robin)
     b, _ = acc(kind, i)
     n = MF[kind][1]
+    if pk:   # packed FP32: two elements per instruction; the token scale v77 is broadcast to both halves by op_sel_hi
+        out = ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[76:77] op_sel:[0,1] op_sel_hi:[1,1]" % (b + r, b + r + 1, b + r, b + r + 1) for r in range(0, n, 2)]
+        for r in range(0, n, 2):
+            s_ = 120 + (r % 8)
+            out.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[78:79], v[%d:%d]" % (s_, s_ + 1, b + r, b + r + 1, s_, s_ + 1))
+        return out
     out = ["v_mul_f32 v%d, v%d, v77" % (b + r, b + r) for r in range(n)]
     for r in range(n):
         s = 120 + (r % 8)
@@ -82,6 +93,21 @@ def patterns(kind):
             body += [M(kind, i + 1)] + deq(kind, i, mix=True)
         P["M(t+1),deq_mix(t)"] = (body, 8, 64)
         body = []
+        for i in range(8):   # the same with packed FP32 de-quantisation: 2 v_pk_mul_f32 + 2 v_pk_fma_f32 per tile
+            body += [M(kind, i + 1)] + deq(kind, i, pk=True)
+        P["M(t+1),deq_pk(t)"] = (body, 8, 32)
+        for la in (2, 3):
+            body = []
+            for i in range(8):
+                body += [M(kind, i + la)] + deq(kind, i, pk=True)
+            P["M(t+%d),deq_pk(t)" % la] = (body, 8, 32)
+        body = []
+        for i in range(4):
+            body += [M(kind, 2 * i + 2), M(kind, 2 * i + 3)]
+            d0, d1 = deq(kind, 2 * i, pk=True), deq(kind, 2 * i + 1, pk=True)
+            body += d0[:2] + d1[:2] + d0[2:] + d1[2:]
+        P["2M(p+1),deq_pk(p)"] = (body, 8, 32)
+        body = []
         for i in range(4):   # pairs, one pair ahead (the r01 product kernel): accs {0,1} / {2,3}
             body += [M(kind, 2 * i + 2), M(kind, 2 * i + 3)]
             d0, d1 = deq(kind, 2 * i), deq(kind, 2 * i + 1)
@@ -109,6 +135,7 @@ def patterns(kind):
                 body += [M(kind, i + 1, "0"), M(kind, i + 1, "acc")] + deq(kind, i)
             P["2Mchain(t+1),deq(t)"] = (body, 4, 64)
     P["VALU_only"] = (I(64), 0, 64)
+    P["PK_only"] = (I_pk(64), 0, 64)
     return P
 
 
@@ -122,7 +149,7 @@ def main():
   "v_mov_b32 v64, 0x0c30c30c\n v_mov_b32 v65, 0x30c30c30\n v_mov_b32 v66, 0xc30c30c3\n v_mov_b32 v67, 0x0c30c30c\n" \
   "v_mov_b32 v68, 0x30c30c30\n v_mov_b32 v69, 0xc30c30c3\n v_mov_b32 v70, 0x0c30c30c\n v_mov_b32 v71, 0x30c30c30\n" \
   "v_mov_b32 v72, 0xc30c30c3\n v_mov_b32 v73, 0x0c30c30c\n v_mov_b32 v74, 0x30c30c30\n v_mov_b32 v75, 0xc30c30c3\n" \
-  "v_mov_b32 v76, 127\n v_mov_b32 v77, 0x3f800347\n v_mov_b32 v78, 0x3f000000\n" \
+  "v_mov_b32 v76, 127\n v_mov_b32 v77, 0x3f800347\n v_mov_b32 v78, 0x3f000000\n v_mov_b32 v79, 0x3f000000\n" \
   "v_mov_b32 v80, 0\n v_mov_b32 v81, 0\n v_mov_b32 v82, 0\n v_mov_b32 v83, 0\n v_mov_b32 v84, 0\n v_mov_b32 v85, 0\n v_mov_b32 v86, 0\n v_mov_b32 v87, 0\n" \
   "v_mov_b32 v88, 0\n v_mov_b32 v89, 0\n v_mov_b32 v90, 0\n v_mov_b32 v91, 0\n v_mov_b32 v92, 0\n v_mov_b32 v93, 0\n v_mov_b32 v94, 0\n v_mov_b32 v95, 0\n" \
   "v_mov_b32 v96, 0\n v_mov_b32 v97, 0\n v_mov_b32 v98, 0\n v_mov_b32 v99, 0\n v_mov_b32 v100, 0\n v_mov_b32 v101, 0\n v_mov_b32 v102, 0\n v_mov_b32 v103, 0\n" \
@@ -148,7 +175,7 @@ extern __shared__ char dyn_lds[];
     kid = 0
     for kind in MF:
         for name, (body, nm, nv) in patterns(kind).items():
-            if name == "VALU_only" and kind != "bf6s16":
+            if name in ("VALU_only", "PK_only") and kind != "bf6s16":
                 continue
             fn = "k%d" % kid
             kid += 1
