@@ -116,10 +116,10 @@ def test_gemm_properties_full_size():
     rows = lambda Mh: ops.dense_layer_gemm_i4_fp16(a[0][:Mh].contiguous(), a[1], a[2][:, :Mh].contiguous(), a[3],
                                                    a[4][:Mh].contiguous(), a[5], a[6][:Mh].contiguous(), a[7], scale_layout="plain")
     order = ops.L.lib().atom_gemm_w4a4_f6_order
-    assert order(M, N, K) == order(2500, N, K) == 1 and order(1000, N, K) == order(600, N, K) == 2
+    assert order(M, N, K) == order(2500, N, K) == 1 and order(1000, N, K) == order(900, N, K) == 2
     assert torch.equal(rows(2500), base[:2500])                 # same summation order (K steps in order): same bits
-    sub = rows(1000)                                            # mid-size batches: two ordered halves of the K steps
-    assert torch.equal(rows(600), sub[:600])
+    sub = rows(1000)                                            # mid-size batches (packed operands are re-coded to F6 from 768
+    assert torch.equal(rows(900), sub[:900])                    # rows): two ordered halves of the K steps
     assert_gemm_close(t2n(sub), t2n(base[:1000]).astype(np.float64), "rows 0..999 in the other summation order")
     r = to_device(d, "ref")
     assert torch.equal(ops.dense_layer_gemm_i4_fp16(*r, scale_layout="ref"), base)
