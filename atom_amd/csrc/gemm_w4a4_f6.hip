@@ -578,6 +578,57 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
   }
 }
 
+// Two K groups of a workgroup (KG = 2): each group finishes half of the token blocks -- it hands the other half of its FP32 sums to
+// its partner wave through LDS, adds the partner's (first half of the K steps + second half) and writes its rows as fp16.
+template <class C, int KG>
+__device__ __forceinline__ void kg_exchange_store(const GemmParams &p, char *lds_all, float (&c)[4][C::WM / 16][4], int kg, int wave, int wm,
+                                                  int wn, int lane, int m0, int n0) {
+  constexpr int NTB = C::WM / 16, EP_STRIDE = 144;
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int wave_all = kg * C::NW + wave;
+  constexpr int HB = NTB / 2, XF = HB * 16;             // floats per lane handed over
+  float *xw = reinterpret_cast<float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + (kg * C::NW + wave) * XF * 64 + lane;
+  const float *xr = reinterpret_cast<const float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + ((1 - kg) * C::NW + wave) * XF * 64 + lane;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (h != kg) {
+#pragma unroll
+      for (int t = 0; t < HB; ++t)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xw[((t * 4 + fb) * 4 + r) * 64] = c[fb][h * HB + t][r];
+    }
+  __builtin_amdgcn_s_barrier();
+  char *ep = lds_all + wave_all * (HB * 16 * EP_STRIDE);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (h == kg) {
+#pragma unroll
+      for (int t = 0; t < HB; ++t)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+          v2u o;
+          half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float other = xr[((t * 4 + fb) * 4 + r) * 64];
+            ov[r] = f2h(kg == 0 ? c[fb][h * HB + t][r] + other : other + c[fb][h * HB + t][r]);
+          }
+          *reinterpret_cast<v2u *>(ep + (t * 16 + l15) * EP_STRIDE + (fb * 16 + 4 * kb) * 2) = o;
+        }
+    }
+#pragma unroll
+  for (int i = 0; i < HB * 2; ++i) {
+    const int rl = i * 8 + (lane >> 3);
+    const int ch = lane & 7;
+    const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
+    const int m = m0 + wm * C::WM + kg * (HB * 16) + rl;
+    const int n = n0 + wn * 64 + ch * 8;
+    if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+  }
+}
+
 // KG = 2: two groups of C::NW waves share the tile and split its K steps in halves (each group with its own LDS ring); the
 // halves are added through the LDS at the end, lower K range first -- the arithmetic of the split-K route with two splits,
 // without its FP32 round trip through HBM.  For shapes with at most one 128x128 tile per CU: the second wave per SIMD hides the
@@ -693,48 +744,7 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
   if constexpr (KG > 1) {
     // one barrier per K step above: the group with the shorter range catches up
     for (int i = (nsteps - s_begin) * (PH ? 2 : 1); i < (total_steps + KG - 1) / KG * (PH ? 2 : 1); ++i) __builtin_amdgcn_s_barrier();
-    // each group finishes half of the token blocks: it hands the other half of its sums over and adds the partner's
-    constexpr int HB = NTB / 2, XF = HB * 16;             // floats per lane handed over
-    float *xw = reinterpret_cast<float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + (kg * C::NW + wave) * XF * 64 + lane;
-    const float *xr = reinterpret_cast<const float *>(lds_all + C::NW * KG * (HB * 16 * EP_STRIDE)) + ((1 - kg) * C::NW + wave) * XF * 64 + lane;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (h != kg) {
-#pragma unroll
-        for (int t = 0; t < HB; ++t)
-#pragma unroll
-          for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xw[((t * 4 + fb) * 4 + r) * 64] = c[fb][h * HB + t][r];
-      }
-    __builtin_amdgcn_s_barrier();
-    char *ep = lds_all + wave_all * (HB * 16 * EP_STRIDE);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (h == kg) {
-#pragma unroll
-        for (int t = 0; t < HB; ++t)
-#pragma unroll
-          for (int fb = 0; fb < 4; ++fb) {
-            v2u o;
-            half_t *ov = reinterpret_cast<half_t *>(&o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float other = xr[((t * 4 + fb) * 4 + r) * 64];
-              ov[r] = f2h(kg == 0 ? c[fb][h * HB + t][r] + other : other + c[fb][h * HB + t][r]);
-            }
-            *reinterpret_cast<v2u *>(ep + (t * 16 + l15) * EP_STRIDE + (fb * 16 + 4 * kb) * 2) = o;
-          }
-      }
-#pragma unroll
-    for (int i = 0; i < HB * 2; ++i) {
-      const int rl = i * 8 + (lane >> 3);
-      const int ch = lane & 7;
-      const v4u v = *reinterpret_cast<const v4u *>(ep + rl * EP_STRIDE + ch * 16);
-      const int m = m0 + wm * C::WM + kg * (HB * 16) + rl;
-      const int n = n0 + wn * 64 + ch * 8;
-      if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
-    }
+    kg_exchange_store<C, KG>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
     if constexpr (TR) {
       if (trl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
