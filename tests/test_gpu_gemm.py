@@ -471,3 +471,35 @@ def test_gemm_f6s_headline_kernel_vs_int8_kernel(M, N, K):
     want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
                          d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"])
     assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
+
+
+def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
+    """40 seeded random shapes through the F6 route (every tile geometry, ragged tiles, 1..40 int4 groups, weights with and without the
+    appended fp32 scales): bit for bit against the C restatement in the summation order atom_gemm_w4a4_f6_order names, on a sample
+    of rows; the whole output against the exact value."""
+    from tests import c_oracle
+    from tests.helpers import f6_codes
+    ops = _ops()
+    lib = ops.L.lib()
+    rng = np.random.default_rng(2024)
+    seen = set()
+    for it in range(40):
+        M = int(rng.choice([rng.integers(1, 64), rng.integers(64, 400), rng.integers(400, 1300), rng.integers(1300, 2600),
+                            rng.integers(2600, 4200)]))
+        N = 64 * int(rng.integers(1, 80))
+        K = 128 * int(rng.choice([rng.integers(2, 6), rng.integers(6, 20), rng.integers(20, 42)]))
+        f6s = bool(it & 1)
+        order = lib.atom_gemm_w4a4_f6_order(M, N, K)
+        assert order in (1, 2)
+        seen.add(order)
+        d = rand_gemm_operands(M, N, K, seed=1000 + it)
+        t = to_device(d, "plain")
+        a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+        b6 = ops.repack_weight_f6(t[1], t[3]) if f6s else ops.repack_weight_f6(t[1])
+        out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
+        assert_gemm_close(t2n(out), _exact(d), f"f6 random {M}x{N}x{K} f6s={f6s}")
+        rows = np.unique(np.clip(np.r_[0:4, M // 2:M // 2 + 4, M - 4:M], 0, M - 1))
+        want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
+                             d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-2 if order == 2 else 1)
+        assert np.array_equal(bits16(t2n(out)[rows]), bits16(want)), (M, N, K, f6s, order)
+    assert seen == {1, 2}
