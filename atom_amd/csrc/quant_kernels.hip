@@ -162,6 +162,26 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
   }
 }
 
+// Sum over the 64 lanes in the butterfly order xor 32, 16, 8, 4, 2, 1 (every lane ends with the total), without the LDS pipeline:
+// v_permlane32_swap / v_permlane16_swap put x[i] and x[i ^ 32] (x[i ^ 16]) side by side in every lane; from then on the partial sums
+// repeat with period 16 (8, 4, 2) over the lanes, so the lane i ^ k a stage needs holds the same value as lane (i + k) mod 16 of the
+// row: v_add_f32 with the DPP row rotation.  Same additions, same order as six ds_bpermute round trips (oracle.sumsq_tree).
+__device__ __forceinline__ float wave_sum_butterfly(float x) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128, 0xF, 0xF, true));   // row_ror:8
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124, 0xF, 0xF, true));   // row_ror:4
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x122, 0xF, 0xF, true));   // row_ror:2
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x121, 0xF, 0xF, true));   // row_ror:1
+  return x;
+}
+
 // reorder / rmsnorm: persistent workgroups, LDS-DMA double buffer.  NP = slots (16 channels) per thread per row.
 template <int OP, bool SIM, bool DQ, int NP>
 __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
@@ -230,7 +250,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 
   // loop-invariant per-thread state: LDS byte offsets of my channels, gathered RMSNorm weights
   int off[NP][16];
-  float wg[NP][16];
+  half_t wg[NP][16];                                        // (halves: 8 registers per slot, and the SIM product is a half multiply)
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     const int slot = ps * 256 + tid;
@@ -254,12 +274,12 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wg[ps][k] = (float)*reinterpret_cast<const half_t *>(wbuf + off[ps][k]);
+        for (int k = 0; k < 16; ++k) wg[ps][k] = *reinterpret_cast<const half_t *>(wbuf + off[ps][k]);
     } else {                                                // (hidden 16384 with the fused residual add: LDS is full)
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wg[ps][k] = (float)p.b[off[ps][k] >> 1];
+        for (int k = 0; k < 16; ++k) wg[ps][k] = p.b[off[ps][k] >> 1];
     }
   }
 
@@ -292,8 +312,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
           for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)sum[k], (float)sum[k], ss);
         }
       }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      ss = wave_sum_butterfly(ss);
       if (lane == 0) red[b * 4 + wave] = ss;
       __syncthreads();                                      // sums visible to the gather, partial sums to everyone
     } else if constexpr (NORM) {
@@ -307,42 +326,51 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
           for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)a[k], (float)a[k], ss);
         }
       }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      ss = wave_sum_butterfly(ss);
       if (lane == 0) red[b * 4 + wave] = ss;
       __syncthreads();
     }
 
     float x[NP][16];
+    half_t xh[NP][16];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       if (p.idx) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[ps][k] = (float)*reinterpret_cast<const half_t *>(row + off[ps][k]);
+        for (int k = 0; k < 16; ++k) xh[ps][k] = *reinterpret_cast<const half_t *>(row + off[ps][k]);
       } else {
         v4u raw[2];
         raw[0] = *reinterpret_cast<const v4u *>(row + off[ps][0]);
         raw[1] = *reinterpret_cast<const v4u *>(row + off[ps][0] + 16);
         const half_t *hv = reinterpret_cast<const half_t *>(raw);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[ps][k] = (float)hv[k];
+        for (int k = 0; k < 16; ++k) xh[ps][k] = hv[k];
       }
     }
     if constexpr (NORM) {
       const float tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
-      const float var = tot / (float)H;                     // correctly rounded divide, sqrt and divide (hipcc default)
+      // correctly rounded divide, sqrt and divide (hipcc default); a power-of-two H divides exactly by multiplying
+      const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
       const float rinv = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           if constexpr (SIM) {
-            x[ps][k] = round_h(wg[ps][k] * round_h(x[ps][k] * rinv));     // HF LlamaRMSNorm, half opmath
+            // HF LlamaRMSNorm, half opmath: half(x * rinv) from the FP32 product, then a half multiply by the weight (the exact
+            // product of two halves rounded once: what round_h(w * y) in FP32 gives)
+            const half_t y = (half_t)((float)xh[ps][k] * rinv);
+            x[ps][k] = (float)(half_t)(wg[ps][k] * y);
           } else {
-            x[ps][k] = round_h((x[ps][k] * wg[ps][k]) * rinv);            // RMSNorm.cuh:145-151
+            x[ps][k] = (float)(half_t)(((float)xh[ps][k] * (float)wg[ps][k]) * rinv);   // RMSNorm.cuh:145-151
           }
         }
       }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[ps][k] = (float)xh[ps][k];
     }
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
