@@ -139,6 +139,26 @@ __device__ __forceinline__ unsigned o4_code(float x, float zero, float rs, float
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: done once per device and kernel (`done` is a
+// Sum over the 64 lanes in the butterfly order xor 32, 16, 8, 4, 2, 1 (every lane ends with the total), without the LDS pipeline:
+// v_permlane32_swap / v_permlane16_swap put x[i] and x[i ^ 32] (x[i ^ 16]) side by side in every lane; from then on the partial sums
+// repeat with period 16 (8, 4, 2) over the lanes, so the lane i ^ k a stage needs holds the same value as lane (i + k) mod 16 of the
+// row: v_add_f32 with the DPP row rotation.  Same additions, same order as six ds_bpermute round trips (the RMSNorm sum of squares, oracle.sumsq_tree; the decode GEMV's final sum).
+__device__ __forceinline__ float wave_sum_butterfly(float x) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128, 0xF, 0xF, true));   // row_ror:8
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124, 0xF, 0xF, true));   // row_ror:4
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x122, 0xF, 0xF, true));   // row_ror:2
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x121, 0xF, 0xF, true));   // row_ror:1
+  return x;
+}
+
 // per-kernel bit mask of device ids; setting the attribute twice is harmless, so a relaxed race costs one extra call).
 inline int ensure_max_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
   int dev = 0;

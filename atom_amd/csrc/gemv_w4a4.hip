@@ -102,8 +102,7 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
         d = quad_sum(d);
         d += __shfl_xor(d, 4);
         float s = acc[m];
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k);
+        s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
         if (lane == 0 && m < p.M) {
           const float t = (float)d * sAl[m * (G + 1) + G];
           p.D[(int64_t)m * p.N + n] = f2h(__builtin_fmaf(t, sb8, s));
@@ -194,8 +193,7 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
       d = quad_sum(d);
       d += __shfl_xor(d, 4);
       float s = acc[r];
-#pragma unroll
-      for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k);
+      s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
       if (lane == 0 && n < p.N) {
         const float t = (float)d * (float)sa8h;
         p.D[n] = f2h(__builtin_fmaf(t, (float)sb8h[r], s));

@@ -162,26 +162,6 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
   }
 }
 
-// Sum over the 64 lanes in the butterfly order xor 32, 16, 8, 4, 2, 1 (every lane ends with the total), without the LDS pipeline:
-// v_permlane32_swap / v_permlane16_swap put x[i] and x[i ^ 32] (x[i ^ 16]) side by side in every lane; from then on the partial sums
-// repeat with period 16 (8, 4, 2) over the lanes, so the lane i ^ k a stage needs holds the same value as lane (i + k) mod 16 of the
-// row: v_add_f32 with the DPP row rotation.  Same additions, same order as six ds_bpermute round trips (oracle.sumsq_tree).
-__device__ __forceinline__ float wave_sum_butterfly(float x) {
-  {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128, 0xF, 0xF, true));   // row_ror:8
-  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124, 0xF, 0xF, true));   // row_ror:4
-  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x122, 0xF, 0xF, true));   // row_ror:2
-  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x121, 0xF, 0xF, true));   // row_ror:1
-  return x;
-}
-
 // reorder / rmsnorm: persistent workgroups, LDS-DMA double buffer.  NP = slots (16 channels) per thread per row.
 template <int OP, bool SIM, bool DQ, int NP>
 __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
