@@ -336,25 +336,31 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     }
   }
 
-  // merge the 16 quads: lanes with equal u hold the same 32 output dims
-  float mall = m;
-#pragma unroll
-  for (int x = 4; x < 64; x <<= 1) mall = fmaxf(mall, __shfl_xor(mall, x));
+  // merge the 16 quads: lanes with equal u hold the same 32 output dims.  Butterfly over lane bits 5, 4, 3, 2 without the LDS
+  // pipeline (35 values x 4 stages were 140 ds_bpermute per wave): v_permlane32_swap / v_permlane16_swap bring lane i ^ 32
+  // (i ^ 16) alongside; after those the values repeat with period 16 (then 8) over the lanes, so lane i ^ 8 (i ^ 4) holds what
+  // lane (i + 8) (i + 4) of the same 16-lane row holds: DPP row rotations.
+  auto over_quads = [](float x, auto op) {
+    {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      x = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      x = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    x = op(x, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128, 0xF, 0xF, true)));   // row_ror:8
+    x = op(x, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124, 0xF, 0xF, true)));   // row_ror:4
+    return x;
+  };
+  auto fadd = [](float a, float b) { return a + b; };
+  auto fmax_ = [](float a, float b) { return fmaxf(a, b); };
+  const float mall = over_quads(m, fmax_);
   const float sc = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mall);
-  d *= sc;
-  zacc *= sc;
+  d = over_quads(d * sc, fadd);
+  zacc = over_quads(zacc * sc, fadd);
 #pragma unroll
-  for (int x = 4; x < 64; x <<= 1) {
-    d += __shfl_xor(d, x);
-    zacc += __shfl_xor(zacc, x);
-  }
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    float v = o[i] * sc;
-#pragma unroll
-    for (int x = 4; x < 64; x <<= 1) v += __shfl_xor(v, x);
-    o[i] = v - zacc;                                    // sum p*(s*u - z)
-  }
+  for (int i = 0; i < 32; ++i) o[i] = over_quads(o[i] * sc, fadd) - zacc;   // sum p*(s*u - z)
   if (t != 0) return;
   if (p.splits == 1) {
     const float rd = d > 0.f ? 1.0f / d : 0.f;

@@ -15,11 +15,13 @@ def run(batch, seqlen, heads=32, block=16, reps=20):
     pool.param.copy_((torch.rand(pool.param.shape, device=dev) * 0.2 + 0.01).half())
     kv = BatchedKvCacheInt4([KvCacheInt4(pool, seqlen) for _ in range(batch)])
     q = torch.randn((batch, heads, 128), device=dev).half()
-    for _ in range(3):
-        ops.batch_decode_i4(q, kv, 0)
+    side = torch.cuda.Stream()                            # the split workspace is per (device, stream): warm up on the capture stream
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ops.batch_decode_i4(q, kv, 0)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):
         for _ in range(reps):
             ops.batch_decode_i4(q, kv, 0)
     g.replay()
