@@ -6,10 +6,10 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 CMD="python $R/bench.py --no-cpu-baseline --steps 500 --warmup 100"   # 500 timed + 100 warm-up launches per operand format (+ the 1500-launch ramp)
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o bench -- $CMD > $OUT/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM --output-format csv -d $OUT/sq2 -o bench -- $CMD > $OUT/sq2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o bench -- $CMD > $OUT/sq1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM --output-format csv -d $OUT/sq2 -o bench -- $CMD > $OUT/sq2.log 2>&1
 tail -1 $OUT/stats.log
 cd $R && python tools/summarize_profile.py $OUT $R/gpurun_out/prof_summary
