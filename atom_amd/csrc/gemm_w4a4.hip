@@ -194,7 +194,7 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
 }
 
 // Packed operands of prefill size: re-code both into the F6 format (one bandwidth-bound launch, ~12 us with its launch gap at
-// N = K = 4096) and run the block-scaled-MFMA kernels: 70-75 instead of 92 us at 4096^3.  From 768 rows since the two-K-group
+// N = K = 4096) and run the block-scaled-MFMA kernels: 65-68 instead of 92 us at 4096^3.  From 768 rows since the two-K-group
 // kernels (tools/r02/packed_route_probe.py: 1024x4096x4096 36.6 us against 44.9 on the INT8 tile kernels, 768x..: 35.6 / 42.7;
 // 512x..: 31.6 against 31.1 for the INT8 kernel with split-K -- break-even, left there).
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {

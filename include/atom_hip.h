@@ -125,7 +125,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
  * Same result, with an optional caller-owned scratch buffer.  Two uses: (1) skinny shapes (few output tiles) split
  * the K loop over several workgroups: FP32 partial sums [splits, M, N] are written to `workspace` and reduced, in split
  * order, by a second launch on the same stream; (2) PACKED operands of prefill size (M >= 768, N >= 2048) are re-coded into the
- * F6 format inside the workspace (one bandwidth-bound launch) and multiplied by the block-scaled-MFMA kernels: 70-75 instead of
+ * F6 format inside the workspace (one bandwidth-bound launch) and multiplied by the block-scaled-MFMA kernels: 65-68 instead of
  * 92 us at 4096^3, 37 instead of 45 us at 1024x4096x4096; bit-identical to atom_gemm_w4a4_f16 where
  * atom_gemm_w4a4_f6_order(M, N, K_total) == 1, the sum of two ordered halves of the K steps where it is 2 (see ATOM_AB_F6).
  * atom_gemm_w4a4_workspace_bytes() returns the size that enables it

@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02
+S=$(date +%s)
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r02/bench_line.json 2> gpurun_out/r02/bench_err.txt
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02/bench_line.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','abi_value')}, d['roofline']['frac'], d['roofline']['kernel_us'])
+print({k:(v['value'],v['kernel_us'],v['bit_identical_to_headline_output']) for k,v in d['other_operand_formats'].items()})
+PY
+
+echo "bench wall: $(( $(date +%s) - S )) s"
