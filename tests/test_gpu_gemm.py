@@ -448,7 +448,8 @@ def _gemm_plain_entry(t, M, N, K, layout_flags):
 # the 256x256 F6 kernel with appended fp32 weight scales (ATOM_B_F6S, "q" kernel): whole and ragged tiles, G = 1, 2, 4, 7, 31
 # int4 groups (every tail variant of its unrolled-by-3 K loop)
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (4096, 4096, 256), (4096, 4096, 384), (4096, 4096, 640),
-                                   (4096, 4096, 1024), (4000, 4096, 512), (4096, 4032, 768), (8192, 2048, 896)])
+                                   (4096, 4096, 1024), (4000, 4096, 512), (4096, 4032, 768), (8192, 2048, 896),
+                                   (40000, 64, 512), (36900, 192, 384)])          # tall and narrow: a quarter / three quarters of one tile column
 def test_gemm_f6s_headline_kernel_vs_int8_kernel(M, N, K):
     """Two different kernel families on the same operands, bit for bit: the F6 256x256 kernel (BF6 MFMA, weight scales as the
     fp32 array atom_repack_weight_f6s appends) against the INT8 MFMA tile kernel behind the plain entry point -- and both against
