@@ -42,7 +42,11 @@ constexpr int kMagicBits = 0x4B400000;
 // skinny M.
 template <int BM_, int BN_, int TM_, int NS_, int OCC_ = 2, int FS_ = 0>
 struct Cfg {
-  static constexpr int FS = FS_;                                       // 1: float32 weight scales staged per int4 step (ATOM_B_F6S)
+  // FS = 1: float32 weight scales staged per int4 step (ATOM_B_F6S); FS = 2: fp16 weight scales staged (as FS = 0: 256 B less per
+  // stage -- three workgroups of the 128x128 geometry fit a CU only with those) but converted once per step; both: float32 token
+  // scale from the record, unscaled MFMA
+  static constexpr int FS = FS_;
+  static constexpr int FS32 = FS_ == 1;
   static constexpr int OCC = OCC_;                                     // waves per SIMD the register budget is set for
   static constexpr int BM = BM_, BN = BN_, TM = TM_, NS = NS_;
   static constexpr int WM = 32 * TM, WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
@@ -51,10 +55,10 @@ struct Cfg {
   static constexpr int NBA = (A_BYTES + 1023) / 1024;                  // activation rows: the last block may be partial
   static constexpr int A_TAIL = (A_BYTES % 1024) / 16;                 // lanes of that partial block (0 = it is whole)
   static constexpr int NSB8 = BN / 128;                                // weight-scale pieces (128 fp16 = 64 dwords each)
-  static constexpr int NSB = FS ? BN / 64 : NSB8;                      // ... of an int4 step (float32: 64 per piece)
+  static constexpr int NSB = FS32 ? BN / 64 : NSB8;                    // ... of an int4 step (float32: 64 per piece)
   static constexpr int A_OFF = W_BYTES;
   static constexpr int SB_OFF = W_BYTES + NBA * 1024;                  // BN fp16 weight scales (int4 steps and keeper)
-  static constexpr int STAGE_BYTES = SB_OFF + BN * (FS ? 4 : 2);
+  static constexpr int STAGE_BYTES = SB_OFF + BN * (FS32 ? 4 : 2);
   static constexpr int KP_SA_OFF = (BN + BM) * 64;                     // keeper half-steps: rows of 64 B, then BM dwords sA8
   static constexpr int NPIECE = NBW + NBA + NSB;                       // DMA instructions per int4 stage
   static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB8;          // ... per keeper half-step
@@ -82,7 +86,7 @@ __device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, cha
     // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
     if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
       lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
-  } else if constexpr (C::FS) {                            // 64 float32 weight scales per piece (rows padded: no clamp)
+  } else if constexpr (C::FS32) {                          // 64 float32 weight scales per piece (rows padded: no clamp)
     const int part = j - (C::NBW + C::NBA);
     lds_dma<4>(p.sB32 + (int64_t)g * p.f6_rows_b + n0 + part * 64 + lane, slot + C::SB_OFF + part * 256);
   } else {                                                 // 128 weight scales per piece, a dword (2 channels) per lane
@@ -459,10 +463,10 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
   constexpr int NTB = C::WM / 16;                                             // token blocks of the wave tile
   const char *pa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + kb * 24;    // + tb*16*PITCH
   const char *psa = slot + C::A_OFF + (wm * C::WM + l15) * PITCH + 96;        // + tb*16*PITCH
-  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * (C::FS ? 4 : 2);  // + fb*32 (float32: fb*64)
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * (C::FS32 ? 4 : 2);   // + fb*32 (float32: fb*64)
   v8i af[4], bf[2];
-  // scales: float32 straight into the de-quantisation (C::FS: the record's float32 token scale, the staged float32 weight
-  // scales) or fp16 converted per use
+  // scales: float32 straight into the de-quantisation (C::FS: the record's float32 token scale; the weight scales staged as float32
+  // (FS = 1) or converted once per step (FS = 2)) or fp16 converted per use (FS = 0)
   using sa_t = typename std::conditional<C::FS != 0, float, half_t>::type;
   using sb_t = typename std::conditional<C::FS != 0, v4f_t, v2u>::type;
   constexpr int SA_AT = C::FS ? 4 : 0;
@@ -474,7 +478,15 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
 #pragma unroll
   for (int fb = 1; fb < 4; ++fb) af[fb] = frag24(pw + fb * 16 * PITCH);
 #pragma unroll
-  for (int fb = 0; fb < 4; ++fb) sb[fb] = *reinterpret_cast<const sb_t *>(psb + fb * (C::FS ? 64 : 32));
+  for (int fb = 0; fb < 4; ++fb) {
+    if constexpr (C::FS == 2) {
+      const v2u raw = *reinterpret_cast<const v2u *>(psb + fb * 32);
+      const half_t *hv = reinterpret_cast<const half_t *>(&raw);
+      sb[fb] = v4f_t{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    } else {
+      sb[fb] = *reinterpret_cast<const sb_t *>(psb + fb * (C::FS32 ? 64 : 32));
+    }
+  }
   // tiles in pairs (fb 0,1 / 2,3 of a token block): a pair's MFMAs are issued one pair ahead of its 16 VALU instructions
   // (8 multiplies, then 8 FMAs: no dependent back-to-back issue)
   constexpr int GS = 2, NG = 4 * NTB / GS, GPB = 4 / GS, DEPTH = 1;
@@ -1683,24 +1695,30 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
-  if (cfg == 3) {                                                              // 4 waves, three workgroups per CU
-    if (p.sB32) {                                                              // float32 weight scales (ATOM_B_F6S)
+  if (cfg == 3) {                                                              // 128x128, 4 waves
+    // float32 weight scales staged (ATOM_B_F6S): 8 % fewer cycles per tile, but 54,272 B of LDS = two workgroups per CU (the LDS
+    // granule makes it 55,040); fp16 scales staged and converted once per step: 53,760 B = three.  The former unless the third
+    // workgroup saves a round of tiles (profiles/r02_mid_m.txt: 1536x4096x4096 37.7 vs 40.9 us, 1024x11008x4096 64.7 vs 55.4).
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.sB32 && (t128 + 511) / 512 <= (t128 + 767) / 768) {
       if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, true>(p, s);
       return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);
     }
-    if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, true>(p, s);
-    return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);
+    if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, true>(p, s);
+    return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);
   }
   // two K groups of 4 waves per workgroup: for shapes that put at most one tile on a CU (f6_pick_cfg)
   if (cfg == 5 || cfg == 6) {                                                  // 128x128; 2 (tuning) / 3 stages per group
     if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
                                 : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
-    return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3>, false, 2>(p, s);
+    return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
   }
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
-    return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3>, false, 2, true>(p, s);
+    return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 2>, false, 2, true>(p, s);
   }
+  if (cfg == 51 && p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);   // tuning: the two scale forms of cfg 3
+  if (cfg == 52) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);
   if (cfg == 53) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);            // tuning: cfg 3 with fp16 weight scales
   if (cfg == 40) return f6::launch_x16<f6::Cfg<256, 256, 4, 3>>(p, s);        // tuning: 256x256, first-generation micro-tile kernel
   if (cfg == 4) {                                                              // 128x128, 8 waves of 64 features x 32 tokens

@@ -27,7 +27,7 @@ def run(M, N, K):
     out = {}
     res = {}
     for name, env in (("cfg3", {"ATOM_F6_CFG": "3", "ATOM_F6_SPLITS3": "1"}), ("cfg3s2", {"ATOM_F6_CFG": "3", "ATOM_F6_SPLITS3": "2"}),
-                      ("cfg5", {"ATOM_F6_CFG": "5"}), ("cfg6", {"ATOM_F6_CFG": "6"}), ("cfg7", {"ATOM_F6_CFG": "9"}), ("cfg8", {"ATOM_F6_CFG": "5"}), ("cfg59", {})):
+                      ("cfg5", {"ATOM_F6_CFG": "5"}), ("cfg6", {"ATOM_F6_CFG": "6"}), ("cfg7", {"ATOM_F6_CFG": "9"}), ("cfg8", {"ATOM_F6_CFG": "51"}), ("cfg59", {})):
         for k in ("ATOM_F6_CFG", "ATOM_F6_SPLITS3"):
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -40,7 +40,7 @@ def run(M, N, K):
         res[name] = time_call(fn, 100)
     same = torch.equal(out["cfg6"], out["cfg5"]) and torch.equal(out["cfg7"], out["cfg5"])
     close = (out["cfg5"].float() - out["cfg3"].float()).abs().max().item()
-    print(f"{M:5d}x{N:5d}x{K:5d}  cfg3 {res['cfg3']:7.2f}  cfg3+s2 {res['cfg3s2']:7.2f}  cfg5 {res['cfg5']:7.2f}  cfg6 {res['cfg6']:7.2f}  cfg9 {res['cfg7']:7.2f}  default {res['cfg59']:7.2f} us   "
+    print(f"{M:5d}x{N:5d}x{K:5d}  cfg3 {res['cfg3']:7.2f}  cfg3+s2 {res['cfg3s2']:7.2f}  cfg5 {res['cfg5']:7.2f}  cfg6 {res['cfg6']:7.2f}  cfg9 {res['cfg7']:7.2f}  cfg3(f32 staged) {res['cfg8']:7.2f}  default {res['cfg59']:7.2f} us   "
           f"consistent {same}  max|cfg5-cfg3| {close:.4f}", flush=True)
 
 
