@@ -55,7 +55,8 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   if (t256 >= 144 && 5 * t256 >= 3 * rounds * 256) return 0;
   // at most one tile per CU: a lone 4-wave workgroup is latency-bound (barrier, fragment loads: ~1 us per K step), so two
   // groups of 4 waves share the tile and its K steps (profiles/r02_mid_m.txt: 1024x4096x4096 33.1 -> 23.4 us, 512x..: 26.3 ->
-  // 18.4).  The result is the sum of two ordered halves of the K steps (atom_gemm_w4a4_f6_order).
+  // 18.4).  The result is the sum of two (four) ordered ranges of the K steps (atom_gemm_w4a4_f6_order).
+  if (steps >= 16 && t64 <= 256) return 12;               // ... four groups on a 64x128 tile (K = 4096: 17.9 -> 15.0 us at 256 rows)
   if (steps >= 8 && t64 <= 256) return 9;
   if (steps >= 8 && t128 <= 256) return 6;
   return 3;
@@ -66,7 +67,7 @@ extern "C" {
 int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   const int cfg = f6_pick_cfg(M, N, K_total);
-  return (cfg == 5 || cfg == 6 || cfg == 9) ? 2 : 1;
+  return cfg == 12 ? 4 : ((cfg == 5 || cfg == 6 || cfg == 9) ? 2 : 1);
 }
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }

@@ -57,8 +57,11 @@ struct Cfg {
   static constexpr int NSB8 = BN / 128;                                // weight-scale pieces (128 fp16 = 64 dwords each)
   static constexpr int NSB = FS32 ? BN / 64 : NSB8;                    // ... of an int4 step (float32: 64 per piece)
   static constexpr int A_OFF = W_BYTES;
-  static constexpr int SB_OFF = W_BYTES + NBA * 1024;                  // BN fp16 weight scales (int4 steps and keeper)
-  static constexpr int STAGE_BYTES = SB_OFF + BN * (FS32 ? 4 : 2);
+  // BN weight scales (int4 steps: fp16 or float32; keeper: fp16): behind the activation blocks, or -- when the last, partial block
+  // leaves room (64-token tiles: 512 B) -- in its unwritten tail, which makes the 64x128 stage exactly 20 KiB
+  static constexpr bool SB_IN_TAIL = A_TAIL != 0 && NBA * 1024 - A_BYTES >= BN * (FS32 ? 4 : 2);
+  static constexpr int SB_OFF = SB_IN_TAIL ? W_BYTES + A_BYTES : W_BYTES + NBA * 1024;
+  static constexpr int STAGE_BYTES = SB_IN_TAIL ? W_BYTES + NBA * 1024 : SB_OFF + BN * (FS32 ? 4 : 2);
   static constexpr int KP_SA_OFF = (BN + BM) * 64;                     // keeper half-steps: rows of 64 B, then BM dwords sA8
   static constexpr int NPIECE = NBW + NBA + NSB;                       // DMA instructions per int4 stage
   static constexpr int NKP = (BN + BM) / 16 + BM / 64 + NSB8;          // ... per keeper half-step
@@ -641,6 +644,53 @@ __device__ __forceinline__ void kg_exchange_store(const GemmParams &p, char *lds
   }
 }
 
+// Four K groups (KG = 4; 64x128 tiles, wave tiles of 4 feature blocks x 2 token blocks = 8 micro-tiles): group g finishes micro-tiles
+// 2g and 2g + 1 (token block g / 2, feature blocks 2 (g % 2) + {0, 1}); every wave parks the six it does not own in LDS and the owner
+// adds the four partial sums in K order, ((p0 + p1) + p2) + p3.
+template <class C>
+__device__ __forceinline__ void kg4_exchange_store(const GemmParams &p, char *lds_all, float (&c)[4][C::WM / 16][4], int kg, int wave, int wm,
+                                                   int wn, int lane, int m0, int n0) {
+  static_assert(C::WM == 32, "kg4: wave tiles of 64 features x 32 tokens");
+  constexpr int EP_STRIDE = 80, EP_WAVE = 16 * EP_STRIDE, NWA = C::NW * 4;
+  const int l15 = lane & 15, kb = lane >> 4;
+  float *xb = reinterpret_cast<float *>(lds_all + NWA * EP_WAVE);          // [group][wave][micro-tile][r][lane]
+  auto xat = [&](int g, int mt, int r) { return xb + ((((g * C::NW + wave) * 8 + mt) * 4 + r) << 6) + lane; };
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+    if (mt >> 1 != kg) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *xat(kg, mt, r) = c[mt & 3][mt >> 2][r];
+    }
+  __builtin_amdgcn_s_barrier();
+  char *ep = lds_all + (kg * C::NW + wave) * EP_WAVE;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (g == kg) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int mt = 2 * g + f;
+        v2u o;
+        half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float part = k == g ? c[mt & 3][mt >> 2][r] : *xat(k, mt, r);
+            sum = k == 0 ? part : sum + part;
+          }
+          ov[r] = f2h(sum);
+        }
+        *reinterpret_cast<v2u *>(ep + l15 * EP_STRIDE + (f * 16 + 4 * kb) * 2) = o;
+      }
+    }
+  const int row = lane >> 2, ch = lane & 3;
+  const v4u v = *reinterpret_cast<const v4u *>(ep + row * EP_STRIDE + ch * 16);
+  const int m = m0 + wm * C::WM + (kg >> 1) * 16 + row;
+  const int n = n0 + wn * 64 + (kg & 1) * 32 + ch * 8;
+  if (m < p.M && n < p.N) *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = v;
+}
+
 // KG = 2: two groups of C::NW waves share the tile and split its K steps in halves (each group with its own LDS ring); the
 // halves are added through the LDS at the end, lower K range first -- the arithmetic of the split-K route with two splits,
 // without its FP32 round trip through HBM.  For shapes with at most one 128x128 tile per CU: the second wave per SIMD hides the
@@ -651,7 +701,7 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
   constexpr int NS = C::NS;
   constexpr int NTB = C::WM / 16;
   static_assert(C::WM % 32 == 0 && NS >= 2, "x16: wave tiles of 64 features x 32, 64 or 128 tokens");
-  static_assert(KG == 1 || (KG == 2 && !SK && NTB % 2 == 0), "K groups: two, without the global split");
+  static_assert(KG == 1 || ((KG == 2 || KG == 4) && !SK && NTB % 2 == 0), "K groups: two or four, without the global split");
   static_assert(!PH || KG == 2, "the half-step phase shift is between two K groups");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -756,7 +806,8 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
   if constexpr (KG > 1) {
     // one barrier per K step above: the group with the shorter range catches up
     for (int i = (nsteps - s_begin) * (PH ? 2 : 1); i < (total_steps + KG - 1) / KG * (PH ? 2 : 1); ++i) __builtin_amdgcn_s_barrier();
-    kg_exchange_store<C, KG>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
+    if constexpr (KG == 4) kg4_exchange_store<C>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
+    else kg_exchange_store<C, KG>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
     if constexpr (TR) {
       if (trl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1614,7 +1665,8 @@ static int launch_p(const GemmParams &p, hipStream_t s) {
 template <class C, bool SK = false, int KG = 1, bool PH = false, bool TR = false>
 static int launch_x16(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  constexpr int XCH = C::NW * KG * (C::WM / 2) * (144 + 64 * 4);      // K groups: epilogue rows + the sums handed over
+  // K groups: epilogue rows + the sums handed over
+  constexpr int XCH = KG == 4 ? C::NW * 4 * (16 * 80 + 8 * 4 * 64 * 4) : C::NW * KG * (C::WM / 2) * (144 + 64 * 4);
   constexpr int LDS = (KG > 1 ? (KG * C::NS * C::STAGE_BYTES > XCH ? KG * C::NS * C::STAGE_BYTES : XCH) : C::LDS_BYTES) + (TR ? 2048 : 0);
   static_assert(LDS <= 160 * 1024, "LDS");
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6x16_kernel<C, SK, KG, PH, TR>), LDS, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
@@ -1716,6 +1768,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 2>, false, 2, true>(p, s);
+  }
+  if (cfg == 12) {                                                             // 64x128, four K groups of 4 waves (exactly 160 KiB of LDS)
+    if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 1>, false, 4>(p, s);
+    return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 2>, false, 4>(p, s);
   }
   if (cfg == 51 && p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);   // tuning: the two scale forms of cfg 3
   if (cfg == 52) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);

@@ -82,8 +82,10 @@ extern "C" {
  * 128x128 (4 waves) -- results bit-identical to the INT8 kernels -- and, for shapes of at most 256 tiles (one per CU: mid-size
  * prefill batches, 256..1024 rows at Llama widths), 128x128 / 64x128 tiles shared by two groups of 4 waves that split the
  * K steps (the G int4 groups, then the two keeper halves) at (G + 2) / 2: each half is summed in order from 0 and
- * D = half(first + second) -- deterministic, same tolerance, 1.4x faster there (1024x4096x4096: 33 -> 23 us).
- * atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in order, 2 = two halves (0 = unsupported shape).
+ * D = half(first + second) -- deterministic, same tolerance, 1.4x faster there (1024x4096x4096: 33 -> 23 us); with at most 256
+ * tiles of 64x128 and K_total >= 2048, four groups and four ranges [(G + 2) k / 4, (G + 2) (k + 1) / 4), D = half(((p0 + p1) + p2)
+ * + p3) (512x4096x4096: 16.7 us).  atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in order, 2 = two halves,
+ * 4 = four ranges (0 = unsupported shape).
  * Ahead of the INT8 kernels from 256 rows up (1.5x at 512-1024 rows, 1.35x at 4096^3).
  */
 #define ATOM_QUANT_F6_CODES 0x200
@@ -127,7 +129,7 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
  * order, by a second launch on the same stream; (2) PACKED operands of prefill size (M >= 768, N >= 2048) are re-coded into the
  * F6 format inside the workspace (one bandwidth-bound launch) and multiplied by the block-scaled-MFMA kernels: 65-68 instead of
  * 92 us at 4096^3, 37 instead of 45 us at 1024x4096x4096; bit-identical to atom_gemm_w4a4_f16 where
- * atom_gemm_w4a4_f6_order(M, N, K_total) == 1, the sum of two ordered halves of the K steps where it is 2 (see ATOM_AB_F6).
+ * atom_gemm_w4a4_f6_order(M, N, K_total) == 1, the sum of two / four ordered ranges of the K steps where it is 2 / 4 (see ATOM_AB_F6).
  * atom_gemm_w4a4_workspace_bytes() returns the size that enables it
  * (0 = the shape does not benefit; then, or with a NULL / too small workspace, this is atom_gemm_w4a4_f16).
  * The reference has no counterpart (its 128x128 tile kernel runs every M, bench_dense_layer_gemm_i4_o16.cu:64-69).

@@ -364,10 +364,10 @@ def test_gemm_f6_operands_bit_identical(M, N, K):
     out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
     assert_gemm_close(t2n(out), _exact(d), f"f6 {M}x{N}x{K}")
     order = ops.L.lib().atom_gemm_w4a4_f6_order(M, N, K)
-    if order == 2:                                        # two K groups per tile: first half + second half of the K steps
+    if order > 1:                                         # two / four K groups per tile: ordered ranges of the K steps, summed
         from tests import c_oracle
         want = c_oracle.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"].T), d["sB"],
-                             d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=-2)
+                             d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=-order)
         assert np.array_equal(bits16(t2n(out)), bits16(want))
     elif M > 256 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0:
         assert order == 1
@@ -381,7 +381,7 @@ def test_gemm_f6_operands_bit_identical(M, N, K):
                                             (2048, 2048, 1152, "128x128")])
 @pytest.mark.parametrize("f6s", [True, False])
 def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
-    """Bit for bit against the C restatement with the K steps summed in two ordered halves (oracle gemm_core, nsplit = -2), on
+    """Bit for bit against the C restatement with the K steps summed in two / four ordered ranges (oracle gemm_core, nsplit = -2 / -4), on
     rows from the first, a middle and the last tile; the whole output against the exact value."""
     from tests import c_oracle
     from tests.helpers import f6_codes
@@ -389,7 +389,8 @@ def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
     lib = ops.L.lib()
     t64, t128 = -(-M // 64) * -(-N // 128), -(-M // 128) * -(-N // 128)
     assert (t64 <= 256) == (want_cfg == "64x128") and t128 <= 256                       # the dispatch rule this case is meant to hit
-    assert lib.atom_gemm_w4a4_f6_order(M, N, K) == 2
+    order = lib.atom_gemm_w4a4_f6_order(M, N, K)
+    assert order == (4 if want_cfg == "64x128" and K // 128 + 1 >= 16 else 2)           # four K groups from 16 K steps on 64x128 tiles
     d = rand_gemm_operands(M, N, K, seed=5 * M + N + 3 * K)
     t = to_device(d, "plain")
     a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
@@ -398,7 +399,7 @@ def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
     assert_gemm_close(t2n(out), _exact(d), f"f6 two K groups {M}x{N}x{K}")
     rows = np.unique(np.r_[0:6, M // 2 - 3:M // 2 + 3, M - 6:M])
     want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
-                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-2)
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order)
     assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
     # the plain entry point takes the same route (no workspace involved)
     D = torch.empty_like(out)
@@ -491,7 +492,7 @@ def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
         K = 128 * int(rng.choice([rng.integers(2, 6), rng.integers(6, 20), rng.integers(20, 42)]))
         f6s = bool(it & 1)
         order = lib.atom_gemm_w4a4_f6_order(M, N, K)
-        assert order in (1, 2)
+        assert order in (1, 2, 4)
         seen.add(order)
         d = rand_gemm_operands(M, N, K, seed=1000 + it)
         t = to_device(d, "plain")
@@ -501,6 +502,6 @@ def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
         assert_gemm_close(t2n(out), _exact(d), f"f6 random {M}x{N}x{K} f6s={f6s}")
         rows = np.unique(np.clip(np.r_[0:4, M // 2:M // 2 + 4, M - 4:M], 0, M - 1))
         want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
-                             d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-2 if order == 2 else 1)
+                             d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order if order > 1 else 1)
         assert np.array_equal(bits16(t2n(out)[rows]), bits16(want)), (M, N, K, f6s, order)
-    assert seen == {1, 2}
+    assert seen == {1, 2, 4}
