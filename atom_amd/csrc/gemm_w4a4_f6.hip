@@ -9,14 +9,22 @@
 //
 // Operand format "F6" (produced by the activation quantisers with ATOM_QUANT_F6_CODES and by atom_repack_weight_f6):
 //   [G][rows_pad][104 bytes]   group-major; 96 bytes = the group's 128 codes as a little-endian stream of 6-bit BF6
-//                              fields, byte 96..97 = the fp16 scale of (row, group), 98..103 zero
+//                              fields; activations: byte 96..97 = the fp16 scale of (row, group), 100..103 = the same as
+//                              float32 (weights: zero; their scales are a dense fp16 array, optionally repeated as float32
+//                              [G][rows_pad] behind the records: ATOM_B_F6S)
 // Group-major makes the 256 rows a tile needs for one K step ONE contiguous 26 KiB block: the LDS-DMA is base + 16*lane
 // with no per-row address, rows_pad (a multiple of 256) keeps tail tiles in bounds, and the 104-byte pitch (26 dwords =
 // 2 x odd) makes the 32 rows of an MFMA fragment read (3 x ds_read_b64 of 24 bytes) hit 32 distinct bank pairs with no
 // swizzle.  The token scale is read from the row itself (no scale DMA, no scale region); weight scales keep their dense
 // fp16 array.  The INT8 keeper runs as the two 64-column half-steps of the INT8 kernel in the same stage buffer.
 // Arithmetic is the same contract: t = round_f32(idot * sA), c = fma(t, sB, c) per group in order, keeper last --
-// results are bit-identical to the INT8 kernels.
+// results are bit-identical to the INT8 kernels, except where two or four groups of waves share a tile (KG = 2 / 4, shapes of
+// at most 256 tiles): those sum consecutive ranges of the K steps and add the partial sums in order.
+//
+// Kernels in this file, by generation: gemm_w4a4_f6_kernel (32x32x64 MFMA; tuning and the 64x128 split-K geometry),
+// gemm_w4a4_f6x16_kernel (16x16x128 micro-tiles; the 128x128 / 64x128 geometries incl. the K-group variants),
+// gemm_w4a4_f6p_kernel (256x256, pipelined across K steps, fp16 weight scales), gemm_w4a4_f6q_kernel (256x256, the headline;
+// also the fused gate/up + SiLU x up + quantiser epilogue).  launch_gemm_f6() at the end maps the cfg numbers.
 #include <type_traits>
 #include "common.h"
 #include "quant_math.h"
