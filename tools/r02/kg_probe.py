@@ -1,4 +1,4 @@
-"""F6 tile kernels with two in-workgroup K groups (cfg 5 / 6: 128x128 with 2 / 3 stages, cfg 9: 64x128) against the 4-wave 128x128
+"""F6 tile kernels with in-workgroup K groups (cfg 5 / 6: 128x128, two groups, 2 / 3 stages; cfg 9: 64x128, two groups; cfg 12: 64x128, four) against the 4-wave 128x128
 kernel (cfg 3) and cfg 3 + split-K 2; "default" = what the dispatch picks.  Time and bits.
 Needs the tools build (make -C atom_amd/csrc tools): the geometry is forced through ATOM_F6_CFG / ATOM_F6_SPLITS3."""
 import os, sys
@@ -40,12 +40,12 @@ def run(M, N, K):
         res[name] = time_call(fn, 100)
     same = torch.equal(out["cfg6"], out["cfg5"]) and torch.equal(out["cfg7"], out["cfg5"])
     close = (out["cfg8"].float() - out["cfg3"].float()).abs().max().item()
-    print(f"{M:5d}x{N:5d}x{K:5d}  cfg3 {res['cfg3']:7.2f}  cfg3+s2 {res['cfg3s2']:7.2f}  cfg5 {res['cfg5']:7.2f}  cfg6 {res['cfg6']:7.2f}  cfg9 {res['cfg7']:7.2f}  cfg12(KG4) {res['cfg8']:7.2f}  default {res['cfg59']:7.2f} us   "
+    print(f"{M:5d}x{N:5d}x{K:5d}  cfg3 {res['cfg3']:7.2f}  cfg3+s2 {res['cfg3s2']:7.2f}  cfg5 {res['cfg5']:7.2f}  cfg6 {res['cfg6']:7.2f}  cfg9 {res['cfg7']:7.2f}  cfg12 {res['cfg8']:7.2f}  default {res['cfg59']:7.2f} us   "
           f"consistent {same}  max|cfg12-cfg3| {close:.4f}", flush=True)
 
 
-for M in (128, 256, 384, 512, 768, 1024):
+for M in (128, 256, 384, 512, 768, 1024, 1536, 2048):
     run(M, 4096, 4096)
 for (N, K) in ((5120, 5120), (13824, 5120), (5120, 13824), (11008, 4096), (4096, 11008)):
-    for M in (256, 512):
+    for M in (256, 512, 1024):
         run(M, N, K)
