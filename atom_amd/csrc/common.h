@@ -139,6 +139,19 @@ __device__ __forceinline__ unsigned o4_code(float x, float zero, float rs, float
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: done once per device and kernel (`done` is a
+// v_cvt_scalef32_2xpk16_bf6_f32 (32 floats -> 32 BF6 fields, the two sources interleaved) through inline asm with an EARLY-CLOBBER
+// destination.  With the builtin, hipcc (ROCm 7.2) lets the register allocator place the 6-register result inside the 16-register
+// sources at an offset (v[2:7] <- v[0:15]), and the multi-pass instruction then overwrites source elements it has not read yet: a
+// re-compile of silu_quant2_kernel turned fields 4.. of some rows into 0 (caught by tests/test_gpu_quant.py).  Result and source at
+// the SAME base register are fine; any other overlap is not, and only the constraint rules it out.
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+typedef unsigned v6u_t __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ v6u_t cvt_2xpk16_bf6(v16f_t a, v16f_t b) {
+  v6u_t r;
+  asm("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // Sum over the 64 lanes in the butterfly order xor 32, 16, 8, 4, 2, 1 (every lane ends with the total), without the LDS pipeline:
 // v_permlane32_swap / v_permlane16_swap put x[i] and x[i ^ 32] (x[i ^ 16]) side by side in every lane; from then on the partial sums
 // repeat with period 16 (8, 4, 2) over the lanes, so the lane i ^ k a stage needs holds the same value as lane (i + k) mod 16 of the

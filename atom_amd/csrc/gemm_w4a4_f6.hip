@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
           ea[i] = i < 4 ? tr[2 * i] : 0.f;
           eb[i] = i < 4 ? tr[2 * i + 1] : 0.f;
         }
-        const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);   // fields 0..7 = my 8 codes: 48 bits
+        const v6u f = cvt_2xpk16_bf6(ea, eb);   // fields 0..7 = my 8 codes: 48 bits
         uint8_t *dst = o.o6 + ((int64_t)bn * o.o6_rows + m) * PITCH;
         uint8_t *d6 = dst + wn * 24 + kb * 6;               // 2-byte aligned: 4 + 2 or 2 + 4 byte stores
         if ((kb & 1) == 0) {

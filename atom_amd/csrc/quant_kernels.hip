@@ -121,7 +121,7 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
         ea[8 + i] = 0.f;
         eb[8 + i] = 0.f;
       }
-      const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+      const v6u f = cvt_2xpk16_bf6(ea, eb);
       uint8_t *dst = p.o4 + ((int64_t)g * p.f6_rows + r) * 104;
       *reinterpret_cast<v3u *>(dst + 12 * j) = v3u{f[0], f[1], f[2]};
       if (j == 0) {                                       // the GEMM reads the token scale from the row itself
@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
   const int Gt = H >> 7;
   const int K4h = (H - kKeeper) >> 1;
   const half_t *arow = p.x + r * (int64_t)H, *brow = p.b + r * (int64_t)H;
-  for (int slot = tid; slot < nslots; slot += 256) {
+  // gridDim.y > 1 (decode batches): a row is shared by gridDim.y workgroups, 256 slots each -- the 128-channel groups are independent
+  // (H = 11008 at 1..16 rows: 4.5 -> 2.7 us under graph replay, tools/r02/quant_latency_probe.py)
+  for (int slot = blockIdx.y * 256 + tid; slot < nslots; slot += 256 * gridDim.y) {
     const int e0 = slot * 16;
     v4u ra[2], rb[2];
     ra[0] = *reinterpret_cast<const v4u *>(arow + e0);
@@ -430,7 +432,8 @@ static void launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
 template <int OP, bool SIM, bool DQ>
 static void launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
   if constexpr (OP == OP_SILU_MUL) {
-    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)(((p.M + 7) >> 3) << 3)), dim3(256), 0, s, p);
+    const unsigned parts = p.M <= 1024 ? (unsigned)(((p.H >> 4) + 255) >> 8) : 1u;
+    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)(((p.M + 7) >> 3) << 3), parts), dim3(256), 0, s, p);
   } else {
     const int np = ((p.H >> 4) + 255) >> 8;
     if (np == 1) launch_act_quant2_np<OP, SIM, DQ, 1>(p, s);
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
         ea[i] = (float)((int)(byte << 28) >> 28);          // element 2i: low nibble, sign-extended
         eb[i] = (float)((int)(byte << 24) >> 28);          // element 2i+1: high nibble
       }
-      const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+      const v6u f = cvt_2xpk16_bf6(ea, eb);
 #pragma unroll
       for (int k = 0; k < 6; ++k) dst[6 * q + k] = f[k];
     }
