@@ -154,18 +154,20 @@ def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="k
 
 
 _WS = {}
+_WS_RETIRED = []      # buffers replaced during a graph capture: launches captured earlier still point at them
 
 
 def _workspace(device, nbytes):
     """Scratch for split-K partial sums / re-coded operands / decode partials, per (device, stream): calls on one stream reuse it
-    in stream order; calls on different streams never share a buffer.  Grown on demand in steps (the old buffer is returned to the
-    caching allocator, which keeps it alive for work already queued on its stream); during HIP-graph capture a buffer is never
-    re-allocated from under earlier captured launches -- size it with a warm-up call before capturing."""
+    in stream order; calls on different streams never share a buffer.  Grown on demand (the old buffer is returned to the caching
+    allocator, which keeps it alive for work already queued on its stream).  During HIP-graph capture a too small buffer is not
+    freed -- launches captured earlier (also of an earlier graph captured on the same stream) reference it -- but retired, and
+    the new one comes out of the capturing graph's memory pool like every other tensor allocated during capture."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None and torch.cuda.is_current_stream_capturing():
-            raise L.AtomHipError("workspace would have to grow during graph capture: run the op once before capturing")
+            _WS_RETIRED.append(t)
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = t
     return t

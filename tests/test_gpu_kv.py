@@ -228,3 +228,25 @@ def test_batch_decode_empty_sequence_gives_zeros(max_pages):
     o = ops.batch_decode_i4(q, kv3, 1)
     assert torch.isfinite(o).all() and not o[1].any()
     assert torch.allclose(o[[0, 2]].float(), want.float(), atol=2e-3 * float(want.float().abs().max()), rtol=0)
+
+
+def test_graph_capture_grows_the_workspace_safely():
+    """The split workspace of atom_batch_decode_i4 is per (device, stream).  Two HIP graphs captured one after the other with torch's
+    default capture stream share that key; the second needs a bigger workspace.  Growing it during the capture must neither fail nor
+    free the buffer the first graph's launches point at: both graphs replay to the eager results afterwards."""
+    from atom_amd import ops
+    graphs = []
+    for seqlens in ([600], [900] * 6):                      # 1 sequence, then 6: more (batch x head x split) partials
+        pool, cs, kv, g = _setup(seqlens, heads=32, block=16, seed=3 + len(seqlens))
+        q = torch.randn((len(seqlens), 32, 128), device="cuda", generator=g).half()
+        want = ops.batch_decode_i4(q, kv, 0).clone()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = ops.batch_decode_i4(q, kv, 0)
+        graphs.append((gr, out, want, pool, kv, q))
+    for gr, out, want, *_ in graphs + graphs[::-1]:
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
