@@ -143,7 +143,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // destination.  With the builtin, hipcc (ROCm 7.2) lets the register allocator place the 6-register result inside the 16-register
 // sources at an offset (v[2:7] <- v[0:15]), and the multi-pass instruction then overwrites source elements it has not read yet: a
 // re-compile of silu_quant2_kernel turned fields 4.. of some rows into 0 (caught by tests/test_gpu_quant.py).  Result and source at
-// the SAME base register are fine; any other overlap is not, and only the constraint rules it out.
+// the SAME base register are fine; any other overlap is not, and only the constraint rules it out.  (repack_f6_kernel keeps the builtin:
+// the asm form doubles its time at 2048 x 13824 x 5120; tests/test_abi_cpu.py disassembles the library and fails on any offset overlap.)
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 typedef unsigned v6u_t __attribute__((ext_vector_type(6)));
 __device__ __forceinline__ v6u_t cvt_2xpk16_bf6(v16f_t a, v16f_t b) {

@@ -789,7 +789,8 @@ __global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
         ea[i] = (float)((int)(byte << 28) >> 28);          // element 2i: low nibble, sign-extended
         eb[i] = (float)((int)(byte << 24) >> 28);          // element 2i+1: high nibble
       }
-      const v6u f = cvt_2xpk16_bf6(ea, eb);
+      // (the builtin, not cvt_2xpk16_bf6: see common.h -- guarded by the disassembly check in tests/test_abi_cpu.py)
+      const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
 #pragma unroll
       for (int k = 0; k < 6; ++k) dst[6 * q + k] = f[k];
     }

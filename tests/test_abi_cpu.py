@@ -69,3 +69,34 @@ def test_f6_summation_order_query():
     assert order(512, 4096, 4096) == 4 and order(256, 4096, 11008) == 4 and order(100, 4096, 4096) == 4
     assert order(1500, 1408, 640) == 1                        # fewer than 8 K steps: no K groups
     assert order(16, 4096, 4000) == 0 and order(0, 4096, 4096) == 0 and order(16, 32, 4096) == 0
+
+
+def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):
+    """Guard against a code-generation trap of hipcc (ROCm 7.2): v_cvt_scalef32_2xpk16_bf6_f32 reads two 16-register sources over
+    several passes and writes a 6-register result; the register allocator may place the result INSIDE a source at an offset
+    (v[2:7] <- v[0:15]) and the instruction then overwrites elements it has not read yet (wrong BF6 codes, silently).  Result
+    and source at the same base register are fine.  Disassemble every gfx950 code object of the product library and check."""
+    import re
+    import shutil
+    import subprocess
+    from atom_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in tmp_path.iterdir() if "gfx950" in p.name)
+    assert objs, "no gfx950 code objects found in the library"
+    pat = re.compile(r"v_cvt_scalef32_2xpk16_bf6_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]")
+    seen = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        for m in pat.finditer(asm):
+            d0, d1, a0, a1, b0, b1 = map(int, m.groups())
+            seen += 1
+            for s0, s1 in ((a0, a1), (b0, b1)):
+                overlap = not (d1 < s0 or s1 < d0)
+                assert not overlap or d0 == s0, f"{m.group(0)} in {o.name}: result overlaps a source at an offset"
+    assert seen >= 100          # the quantisers, the re-coding kernel and the fused gate/up epilogue all use it
