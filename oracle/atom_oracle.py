@@ -437,6 +437,34 @@ def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
     return c.astype(f16)
 
 
+def gemm_w4a4_contract(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8, kgroups: int = 1) -> np.ndarray:
+    """The C-ABI arithmetic contract (include/atom_hip.h) in numpy float32, independent of oracle/atom_oracle.c:
+    K steps = the G int4 groups in order, then the keeper as two 64-column halves; per step t = f32(idot * sA),
+    c = fma(t, sB, c) (the fma through float64: the product of two float32 is exact there and one rounding of the sum to
+    float32 is the fused result up to double rounding, which the 2^-29 headroom of these operands excludes -- checked against
+    the C restatement in tests).  kgroups = 1: one ordered sum (tile kernels).  kgroups = 2 / 4: the K-group tile kernels
+    (gemm_w4a4_f6.hip) -- the steps are cut into ranges [(G+2)k/kg, (G+2)(k+1)/kg), each summed from 0, partial sums added
+    in order.  Returns float16 [M, N]."""
+    M, K4 = qa4.shape
+    G = K4 // GROUP
+    steps = []
+    for g in range(G):
+        steps.append((_group_int_dots(qa4, qb4, g), sA[:, g].astype(f32), sB[g].astype(f32)))
+    for h in range(2):
+        I8 = qa8[:, 64 * h:64 * h + 64].astype(f32) @ qb8[:, 64 * h:64 * h + 64].astype(f32).T
+        steps.append((I8, sA8.astype(f32), sB8.astype(f32)))
+    T = len(steps)
+    total = None
+    for k in range(kgroups):
+        c = np.zeros((M, qb4.shape[0]), dtype=f32)
+        for I, sa, sb in steps[T * k // kgroups:T * (k + 1) // kgroups]:
+            t = (I * sa[:, None]).astype(f32)
+            c = (t.astype(np.float64) * sb[None, :].astype(np.float64) + c.astype(np.float64)).astype(f32)
+        total = c if total is None else (total + c).astype(f32)
+    with np.errstate(over="ignore"):
+        return total.astype(f16)
+
+
 def quant_o4(D32: np.ndarray, ref_extrema: bool = False):
     """The _o4 epilogue (e2e/.../GEMM/DenseLayerGEMM_i4_o4.cu:704-788): asymmetric u4 per 128-col
     output group of the FP32 accumulators.  scale = (max-min)/15, zero = -min, r = 1/scale,

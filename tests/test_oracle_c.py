@@ -83,3 +83,17 @@ def test_gemm_decode_summation_order(K):
     G = (K - 128) // 128
     huge = C.gemm(*args, nsplit=2 * (G + 1))       # per = 1 -> every item its own wave: still a valid order
     assert np.abs(bits16(huge).astype(np.int32) - bits16(exh).astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("K,kgroups", [(640, 1), (1152, 2), (2176, 2), (2176, 4), (4096, 4), (1408, 4)])
+def test_gemm_k_group_orders_c_vs_numpy(K, kgroups):
+    """The summation orders of the tile kernels (one ordered sum; two / four ordered ranges of the K steps, atom_gemm_w4a4_f6_order)
+    restated twice, independently: oracle/atom_oracle.c (gemm_core, nsplit = -kgroups) and numpy (gemm_w4a4_contract).  Bit for bit."""
+    d = rand_gemm_operands(11, 128, K, seed=3 * K + kgroups)
+    args = (O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+    c = C.gemm(*args, nsplit=-kgroups if kgroups > 1 else 1)
+    n = O.gemm_w4a4_contract(d["qa4"], d["qb4"], d["sA"], d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], kgroups=kgroups)
+    assert np.array_equal(bits16(c), bits16(n))
+    if kgroups > 1:                                            # a different order than the single sum, same value to 1 fp16 ulp
+        base = C.gemm(*args)
+        assert np.abs(bits16(c).astype(np.int32) - bits16(base).astype(np.int32)).max() <= 1
