@@ -119,6 +119,29 @@ __device__ __forceinline__ void lds_dma(const void *gsrc, const void *lds_dst) {
   else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
 }
 
+// The same with the LDS byte address as an integer.  lds_addr() of a stage slot once, then integer offsets per piece: the generic -> LDS
+// cast carries a null check (64-bit add, compare, select: 4 SALU), which the compiler keeps per piece when every piece casts its own
+// pointer (125 -> 97 SALU per K step of the 128x128 F6 kernel).
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p; }
+template <int BYTES>
+__device__ __forceinline__ void lds_dma_at(const void *gsrc, unsigned lds_byte_addr) {
+  static_assert(BYTES == 16 || BYTES == 4 || BYTES == 2, "LDS-DMA piece size");
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  if constexpr (BYTES == 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+  else if constexpr (BYTES == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+  else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+}
+
+// ... and with the global address as a wave-uniform base (SGPR pair) + a 32-bit lane offset: no 64-bit VALU add per piece.
+template <int BYTES>
+__device__ __forceinline__ void lds_dma_sv(const void *sbase, unsigned voff, unsigned lds_byte_addr) {
+  static_assert(BYTES == 16 || BYTES == 4 || BYTES == 2, "LDS-DMA piece size");
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  if constexpr (BYTES == 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+  else if constexpr (BYTES == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+
 // u4 code of one value under the _o4 epilogue.  REF = the reference code's arithmetic (no clamp, low 4 bits of the int8 cast;
 // |result| beyond int8 saturates), else clamp to [0, 15] and 0 for an all-equal group.
 template <bool REF>

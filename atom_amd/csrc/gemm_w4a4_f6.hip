@@ -87,24 +87,25 @@ template <class C>
 __device__ __forceinline__ void issue_int4_piece(const GemmParams &p, int g, char *slot, int wave, int lane, int m0, int n0, int i) {
   const uint8_t *wsrc = p.B4 + ((int64_t)g * p.f6_rows_b + n0) * PITCH;
   const uint8_t *asrc = p.A4 + ((int64_t)g * p.f6_rows_a + m0) * PITCH - C::W_BYTES;   // block j >= NBW is asrc + j*1024
+  const unsigned sl = lds_addr(slot);                      // (one cast per stage; integer offsets per piece)
   int j = i * C::NDW + wave;                               // piece j: NBW weight blocks, NBA activation blocks, NSB scales
   j = j < C::NPIECE ? j : C::NPIECE - C::NSB + (j - C::NPIECE) % C::NSB;   // padding repeats a scale piece (same bytes, same place)
   if (i * C::NDW + C::NDW <= C::NBW + C::NBA - (C::A_TAIL ? 1 : 0)) {              // compile time: whole data blocks only
     const uint8_t *base = (i * C::NDW + C::NDW <= C::NBW || j < C::NBW) ? wsrc : asrc;
-    lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
+    lds_dma_sv<16>(base + j * 1024, (unsigned)lane * 16u, sl + j * 1024);
   } else if (j < C::NBW + C::NBA) {
     const uint8_t *base = j < C::NBW ? wsrc : asrc;
     // the partial last activation block runs with fewer lanes enabled (one instruction either way: vmcnt stays uniform)
     if (!C::A_TAIL || j < C::NBW + C::NBA - 1 || lane < C::A_TAIL)
-      lds_dma<16>(base + j * 1024 + lane * 16, slot + j * 1024);
+      lds_dma_sv<16>(base + j * 1024, (unsigned)lane * 16u, sl + j * 1024);
   } else if constexpr (C::FS32) {                          // 64 float32 weight scales per piece (rows padded: no clamp)
     const int part = j - (C::NBW + C::NBA);
-    lds_dma<4>(p.sB32 + (int64_t)g * p.f6_rows_b + n0 + part * 64 + lane, slot + C::SB_OFF + part * 256);
+    lds_dma_sv<4>(p.sB32 + (int64_t)g * p.f6_rows_b + n0 + part * 64, (unsigned)lane * 4u, sl + C::SB_OFF + part * 256);
   } else {                                                 // 128 weight scales per piece, a dword (2 channels) per lane
     const int part = j - (C::NBW + C::NBA);
     const half_t *sBb = p.sB + (int64_t)g * p.N;
     const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-    lds_dma<4>(sBb + n, slot + C::SB_OFF + part * 256);
+    lds_dma_at<4>(sBb + n, sl + C::SB_OFF + part * 256);
   }
 }
 
@@ -120,6 +121,7 @@ __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char
   // only two of these per tile: addresses are computed here instead of living in registers through the int4 loop
   const unsigned kj = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   constexpr int ND = (C::BN + C::BM) / 16, NSA = C::BM / 64;
+  const unsigned sl = lds_addr(slot);
 #pragma unroll
   for (int i = 0; i < C::GLDS; ++i) {
     int j = i * C::NDW + wave;
@@ -128,16 +130,16 @@ __device__ __forceinline__ void issue_keeper(const GemmParams &p, int half, char
       const int row = j * 16 + (lane >> 2);
       const unsigned idx = (unsigned)(j < C::BN / 16 ? min(n0 + row, p.N - 1) : min(m0 + row - C::BN, p.M - 1));
       const uint8_t *base = (j < C::BN / 16 ? p.B8 : p.A8) + half * 64;
-      lds_dma<16>(base + idx * kKeeper + kj, slot + j * 1024);
+      lds_dma_at<16>(base + idx * kKeeper + kj, sl + j * 1024);
     } else if (j < ND + NSA) {                             // sA8 of 64 tokens: one fp16 per lane -> zero-extended dword
       const int pc = j - ND;
       const int idx = min(m0 + pc * 64 + lane, p.M - 1);
       const unsigned ksa = (unsigned)(p.ref_layout ? ref_scale_index(idx) : idx);
-      lds_dma<2>(p.sA8 + ksa, slot + C::KP_SA_OFF + pc * 256);
+      lds_dma_at<2>(p.sA8 + ksa, sl + C::KP_SA_OFF + pc * 256);
     } else {
       const int part = j - ND - NSA;
       const int n = min(n0 + part * 128 + 2 * lane, p.N - 2);
-      lds_dma<4>(p.sB8 + n, slot + C::SB_OFF + part * 256);
+      lds_dma_at<4>(p.sB8 + n, sl + C::SB_OFF + part * 256);
     }
   }
 }
