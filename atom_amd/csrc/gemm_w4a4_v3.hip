@@ -96,6 +96,7 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
   const unsigned strideW = int4 ? (unsigned)p.K4h : (unsigned)kKeeper;
   const unsigned strideA = int4 ? (unsigned)(C::AW ? 2 * p.K4h : p.K4h) : (unsigned)kKeeper;
   const unsigned kmask = (C::AW && !int4) ? 0x30u : 0x70u;
+  const unsigned sl0 = lds_addr(slot);                     // one generic -> LDS cast per stage, integer offsets per piece (common.h)
 #pragma unroll
   for (int i = 0; i < C::IPW; ++i) {
     const int gidx = wave * C::IPW + i;
@@ -103,7 +104,7 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
     const uint8_t *base = isW ? wb : ab;
     const unsigned ja = (((gidx - C::GW) & 1) ? a.ja1 : a.ja) & kmask;
     const unsigned off = a.idx[i] * (isW ? strideW : strideA) + (isW ? a.jw : ja);
-    lds_dma<16>(base + off, slot + gidx * 1024);
+    lds_dma_sv<16>(base, off, sl0 + gidx * 1024);
   }
   const bool keeper = step >= p.G;
   const int g = min(step, p.G - 1);
@@ -113,10 +114,10 @@ __device__ __forceinline__ void issue_stage(const GemmParams &p, int step, char 
   for (int s = 0; s < C::SPW; ++s) {
     const int sl = wave * C::SPW + s;
     if (sl < C::NSA) {   // one fp16 per lane; lands as one zero-extended dword per lane (tools/probes/glds_probe.cpp)
-      lds_dma<2>(sAb + a.scale[s], slot + C::SA_OFF + sl * 256);
+      lds_dma_sv<2>(sAb, (unsigned)a.scale[s] * 2u, sl0 + C::SA_OFF + sl * 256);
     } else {             // a dword = two adjacent channels per lane, dense fp16 image (padding slots repeat part 0)
       const int part = sl - C::NSA < C::NSB ? sl - C::NSA : 0;
-      lds_dma<4>(sBb + a.scale[s], slot + C::SB_OFF + part * 256);
+      lds_dma_sv<4>(sBb, (unsigned)a.scale[s] * 2u, sl0 + C::SB_OFF + part * 256);
     }
   }
 }

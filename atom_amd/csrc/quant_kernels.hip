@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   float *red = reinterpret_cast<float *>(smem + 2 * stage);        // [2][4] partial sums of squares
   const int j = tid & 7;
 
+  const unsigned smem0 = lds_addr(smem);
   auto issue_row = [&](int64_t r, int b) {                  // DMA row r into buffer b
     const char *src = reinterpret_cast<const char *>(p.x + r * (int64_t)H);
     const char *src2 = reinterpret_cast<const char *>(p.res + r * (int64_t)H);
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       const int blk = i * 4 + wave;                         // 1 KiB block
       if (blk * 64 < nchunks) {
         const int c = min(blk * 64 + lane, nchunks - 1);    // tail lanes re-read the last chunk into the padding
-        lds_dma<16>(src + c * 16, smem + b * stage + blk * 1024);
+        lds_dma_sv<16>(src, (unsigned)c * 16u, smem0 + b * stage + blk * 1024);
         if constexpr (ADD)
-          lds_dma<16>(src2 + c * 16, smem + b * stage + bufbytes + blk * 1024);
+          lds_dma_sv<16>(src2, (unsigned)c * 16u, smem0 + b * stage + bufbytes + blk * 1024);
       }
     }
   };
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
         const int blk = i * 4 + wave;
         if (blk * 64 < nchunks) {
           const int c = min(blk * 64 + lane, nchunks - 1);
-          lds_dma<16>(reinterpret_cast<const char *>(p.b) + c * 16, wbuf + blk * 1024);
+          lds_dma_sv<16>(p.b, (unsigned)c * 16u, lds_addr(wbuf) + blk * 1024);
         }
       }
     }
