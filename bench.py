@@ -375,9 +375,11 @@ def main():
                 continue
             st2 = make_step(name)
             D.zero_()
-            # side measurements, not the contract's K steps: each format gets its own short ramp (its kernels draw different power:
-            # 20 steps after 5 launches read 75 us for packed_ws, 68 us sustained) and at least 100 timed steps; both are reported
-            n_warm, n_steps = max(args.warmup, 100), max(args.steps, 100)
+            # side measurements, not the contract's K steps: each format gets its own ramp like the headline's (its kernels draw
+            # different power and the chip takes several hundred launches to settle: 20 steps after 5 launches read 75 us for
+            # packed_ws, 100 after 100 read 67, sustained 65; the INT8 kernel 106 / 109 / 94) and at least 100 timed steps; both
+            # counts are reported
+            n_warm, n_steps = max(args.warmup, min(args.ramp, 1000) if args.ramp else 100), max(args.steps, 100)
             for _ in range(n_warm):                              # (at least one launch: the comparison below is of ITS output)
                 st2()
             torch.cuda.synchronize(dev)
