@@ -161,7 +161,6 @@ __device__ __forceinline__ unsigned o4_code(float x, float zero, float rs, float
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: done once per device and kernel (`done` is a
 // v_cvt_scalef32_2xpk16_bf6_f32 (32 floats -> 32 BF6 fields, the two sources interleaved) through inline asm with an EARLY-CLOBBER
 // destination.  With the builtin, hipcc (ROCm 7.2) lets the register allocator place the 6-register result inside the 16-register
 // sources at an offset (v[2:7] <- v[0:15]), and the multi-pass instruction then overwrites source elements it has not read yet: a
@@ -196,6 +195,7 @@ __device__ __forceinline__ float wave_sum_butterfly(float x) {
   return x;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: done once per device and kernel (`done` is a
 // per-kernel bit mask of device ids; setting the attribute twice is harmless, so a relaxed race costs one extra call).
 inline int ensure_max_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
   int dev = 0;

@@ -410,37 +410,45 @@ static int resident_blocks(K kernel, size_t lds) {           // persistent grid:
 }
 
 template <int OP, bool SIM, bool DQ, int NP>
-static void launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
+static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   ActQuantParams p = p0;
   const size_t rowb = (size_t)((p.H * 2 + 1023) & ~1023);
   constexpr bool NORMOP = OP == OP_RMSNORM || OP == OP_ADD_RMSNORM;
   const size_t base = (OP == OP_ADD_RMSNORM ? 4 : 2) * rowb + 1024;
   p.w_lds = NORMOP && base + rowb <= 160 * 1024;
   const size_t lds = base + (p.w_lds ? rowb : 0);
-  // occupancy depends on the LDS size, i.e. on H; cache the last answer (benign race: same inputs, same value)
-  static size_t cached_lds = 0;
-  static int resident = 0;
-  if (cached_lds != lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&act_quant2_kernel<OP, SIM, DQ, NP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    resident = resident_blocks(act_quant2_kernel<OP, SIM, DQ, NP>, lds);
-    cached_lds = lds;
+  // the dynamic-LDS attribute is per device (ensure_max_lds); the occupancy answer depends on the device and on the LDS size, i.e.
+  // on H: one cached (lds, resident) word per device slot and kernel (a race re-computes the same value)
+  static std::atomic<uint64_t> lds_set{0};
+  static std::atomic<uint64_t> cache[64];
+  const auto kernel = act_quant2_kernel<OP, SIM, DQ, NP>;
+  if (const int st = ensure_max_lds(reinterpret_cast<const void *>(kernel), 160 * 1024, lds_set); st != ATOM_OK) return st;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return ATOM_ERR_LAUNCH;
+  std::atomic<uint64_t> &slot = cache[dev & 63];
+  uint64_t c = slot.load(std::memory_order_relaxed);
+  if ((c >> 32) != lds) {
+    c = ((uint64_t)lds << 32) | (uint32_t)resident_blocks(kernel, lds);
+    slot.store(c, std::memory_order_relaxed);
   }
+  const int resident = (int)(uint32_t)c;
   const unsigned grid = (unsigned)(p.M < resident ? p.M : resident);
-  hipLaunchKernelGGL((act_quant2_kernel<OP, SIM, DQ, NP>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, p);
+  return ATOM_OK;
 }
 
 template <int OP, bool SIM, bool DQ>
-static void launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
+static int launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
   if constexpr (OP == OP_SILU_MUL) {
     const unsigned parts = p.M <= 1024 ? (unsigned)(((p.H >> 4) + 255) >> 8) : 1u;
     hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)(((p.M + 7) >> 3) << 3), parts), dim3(256), 0, s, p);
+    return ATOM_OK;
   } else {
     const int np = ((p.H >> 4) + 255) >> 8;
-    if (np == 1) launch_act_quant2_np<OP, SIM, DQ, 1>(p, s);
-    else if (np == 2) launch_act_quant2_np<OP, SIM, DQ, 2>(p, s);
-    else if (np == 3) launch_act_quant2_np<OP, SIM, DQ, 3>(p, s);
-    else launch_act_quant2_np<OP, SIM, DQ, 4>(p, s);
+    if (np == 1) return launch_act_quant2_np<OP, SIM, DQ, 1>(p, s);
+    if (np == 2) return launch_act_quant2_np<OP, SIM, DQ, 2>(p, s);
+    if (np == 3) return launch_act_quant2_np<OP, SIM, DQ, 3>(p, s);
+    return launch_act_quant2_np<OP, SIM, DQ, 4>(p, s);
   }
 }
 
@@ -464,11 +472,12 @@ static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
   p.ld = (int64_t)atom_scale_size(p.M, scale_layout);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define ATOM_LAUNCH2(OPV)                                             \
-  if (p.sim && p.xq) launch_act_quant2<OPV, true, true>(p, s);        \
-  else if (p.sim) launch_act_quant2<OPV, true, false>(p, s);          \
-  else if (p.xq) launch_act_quant2<OPV, false, true>(p, s);           \
-  else launch_act_quant2<OPV, false, false>(p, s);
+  int st = ATOM_OK;
+#define ATOM_LAUNCH2(OPV)                                                  \
+  if (p.sim && p.xq) st = launch_act_quant2<OPV, true, true>(p, s);        \
+  else if (p.sim) st = launch_act_quant2<OPV, true, false>(p, s);          \
+  else if (p.xq) st = launch_act_quant2<OPV, false, true>(p, s);           \
+  else st = launch_act_quant2<OPV, false, false>(p, s);
   switch (op) {
     case OP_REORDER: ATOM_LAUNCH2(OP_REORDER) break;
     case OP_RMSNORM: ATOM_LAUNCH2(OP_RMSNORM) break;
@@ -476,7 +485,7 @@ static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_
     default: ATOM_LAUNCH2(OP_SILU_MUL) break;
   }
 #undef ATOM_LAUNCH2
-  return check_launch();
+  return st != ATOM_OK ? st : check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -132,9 +132,12 @@ class LlamaMLP(nn.Module):
 
     def forward(self, x):
         outlier, norms, outlier_scales, norm_scales = x
-        if outlier.size(0) >= self.FUSED_MIN_ROWS and self.intermediate_size % GROUP == 0:
+        if (outlier.size(0) >= self.FUSED_MIN_ROWS and self.intermediate_size % GROUP == 0
+                and ops.L.lib().atom_gemm_w4a4_f6_order(outlier.size(0), self.intermediate_size, self.hidden_size) == 1):
             # prefill batches: gate_proj + up_proj + activate_fp16_i4 in ONE launch, bit-identical to the three
-            # launches below; the activation is re-coded to the F6 operand once (the two GEMMs would each do it in their workspace)
+            # launches below wherever those sum the K steps in order too (atom_gemm_w4a4_f6_order == 1: every shape that fills the
+            # chip; few-tile shapes keep the three launches so that the output does not depend on the route);
+            # the activation is re-coded to the F6 operand once (the two GEMMs would each do it in their workspace)
             a6 = norms if norms.dim() == 3 else ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
             act = ops.gate_up_silu_quant_f6(a6, outlier, outlier_scales, self._fused_gate_up())
             return self.down_proj(act)

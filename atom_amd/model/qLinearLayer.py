@@ -102,6 +102,12 @@ class QLinearLayer(nn.Module):
         self._unpackable_key = key
         return None
 
+    def release_codes(self):
+        """keep_packed_with_f6 = False: drop the packed INT4 codes once a wider form made from them exists (the F6 operand of this
+        layer, or the fused gate/up operand of the MLP that owns it); the keeper and the scales stay."""
+        if not self.keep_packed_with_f6 and self._packed is not None and self._packed[0] is not None:
+            self._packed = (None,) + tuple(self._packed[1:])
+
     @torch.no_grad()
     def forward(self, x):
         codes = get_codes(x)
@@ -113,8 +119,7 @@ class QLinearLayer(nn.Module):
                     if b4 is None:
                         b4 = self.packed_weight(need_codes=True)[0]
                     self._f6 = (self._packed_key, _ops.repack_weight_f6(b4, sb))
-                    if not self.keep_packed_with_f6:      # release the INT4 codes (see the class comment)
-                        self._packed = (None, b8, sb, sb8)
+                    self.release_codes()                  # keep_packed_with_f6 = False (see the class comment)
                 b4 = self._f6[1]
             y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
                                               scale_layout=codes.layout, a_wide=codes.wide)
@@ -130,10 +135,13 @@ class QLinearLayer(nn.Module):
         if self._packed is not None:
             dev = self.weight.device
             if dev.type == "cuda":
-                self._packed = tuple(t.to(dev) for t in self._packed)
+                # released INT4 codes (keep_packed_with_f6 = False) are None entries
+                self._packed = tuple(None if t is None else t.to(dev) for t in self._packed)
                 self._packed_key = self._weight_key()
             else:
                 self._packed_key = None      # packed form stays on its GPU; re-keyed when the weight comes back
+        if self._f6 is not None and self._f6[0] != self._packed_key:
+            self._f6 = None                  # made for another device / weight: rebuilt by the next prefill batch
         return self
 
     # ------------------------------------------------------------------------------------------------ quant

@@ -272,14 +272,28 @@ class QLlamaMLP(nn.Module):
     FUSED_MIN_ROWS = 512          # the fused launch always runs the 256x256 geometry
 
     def _fused_gate_up(self):
-        """The interleaved gate/up weight operand of gate_up_silu_quant_f6, cached per packed form of the two layers."""
-        pg, pu = self.gate_proj.packed_weight(), self.up_proj.packed_weight()
-        if pg is None or pu is None or self.gate_proj.bias is not None or self.up_proj.bias is not None:
+        """The interleaved gate/up weight operand of gate_up_silu_quant_f6, cached per packed form of the two layers.  Built from the
+        packed INT4 codes of both layers; a layer with keep_packed_with_f6 = False gets them re-packed for the build only and
+        releases them again afterwards (the cache check itself does not need them)."""
+        if self.gate_proj.bias is not None or self.up_proj.bias is not None:
+            return None
+        if self.gate_proj.packed_weight(need_codes=False) is None or self.up_proj.packed_weight(need_codes=False) is None:
             return None
         key = (self.gate_proj._packed_key, self.up_proj._packed_key)
         if getattr(self, "_fused", None) is None or self._fused[0] != key:
+            pg, pu = self.gate_proj.packed_weight(), self.up_proj.packed_weight()
             self._fused = (key, _ops.fuse_gate_up_weights(pg, pu))
+            self.gate_proj.release_codes()
+            self.up_proj.release_codes()
         return self._fused[1]
+
+    def _fused_is_bit_identical(self, rows):
+        """The fused launch sums the K steps in order (256x256 geometry).  The stand-alone gate / up GEMMs do so too where
+        atom_gemm_w4a4_f6_order(M, N_inter, K) == 1; for few-tile shapes they add two / four ordered K ranges instead, and the fp16
+        gate / up values can differ in the last bit.  Fuse only where the results are bit-identical to the three launches, so that
+        the model's output does not depend on which side of FUSED_MIN_ROWS a batch falls."""
+        n, k = self.gate_proj.weight.shape
+        return _ops.L.lib().atom_gemm_w4a4_f6_order(int(rows), int(n), int(k)) == 1
 
     @torch.no_grad()
     def forward(self, x):
@@ -287,7 +301,8 @@ class QLlamaMLP(nn.Module):
         hot = self.act_quant.hot_args(inter)
         codes = get_codes(x)
         if (hot is not None and codes is not None and codes.wide == "f6" and codes.rows >= self.FUSED_MIN_ROWS and x.is_cuda
-                and self._act_is_silu() and codes.hidden == self.gate_proj.weight.shape[1] and inter % 128 == 0):
+                and self._act_is_silu() and codes.hidden == self.gate_proj.weight.shape[1] and inter % 128 == 0
+                and self._fused_is_bit_identical(codes.rows)):
             fused = self._fused_gate_up()
             if fused is not None:
                 # gate_proj, up_proj, act_fn(gate) * up and the quantiser in one launch: bit-identical to the path below

@@ -195,8 +195,9 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
         assert a.shape == (k // GROUP_SIZE - 1, f6_rows(m), L.F6_PITCH) and b.shape == (a.shape[0], f6_rows(n), L.F6_PITCH)
     d = torch.empty((m, n), dtype=torch.float16, device=a.device)
     lib = L.lib()
-    # > 0 for skinny shapes that gain from split-K, and for packed operands of prefill size (re-coded to F6 in the workspace)
-    ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide and m >= 2048) else 0
+    # > 0 for skinny shapes that gain from split-K, and for packed operands of prefill size (re-coded to F6 in the workspace);
+    # operands that are F6 already need none (the F6 kernels take no workspace)
+    ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide == "f6" or (a_wide and m >= 2048)) else 0
     ws = _workspace(a.device, ws_bytes) if ws_bytes else None
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),

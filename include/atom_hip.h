@@ -332,8 +332,10 @@ int atom_repack_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_
  * order.  Outputs = atom_silu_mul_quant_f16's with ATOM_QUANT_F6_CODES, for hidden N_inter: o_outliers int8 [M, 128], o_norms_f6
  * uint8 [N_inter / 128 - 1][atom_f6_rows(M)][104] (the F6 activation operand of down_proj), outlier_scales / norm_scales per
  * `scale_layout`, optional xq fp16 [M, N_inter] (NULL: not written).  quant_mode ATOM_QUANT_SIM / ATOM_QUANT_KERNEL, clip as there.
- * Bit-identical to the three launches it replaces (fp16 GEMM outputs are formed in registers and go through the same arithmetic);
- * saves writing and re-reading 2 * M * N_inter fp16.  Always the 256x256 geometry: meant for prefill batches (M >= 512).
+ * The K steps are summed in order (fp16 GEMM outputs are formed in registers and go through the same arithmetic): bit-identical to
+ * the three launches it replaces wherever atom_gemm_w4a4_f6_order(M, N_inter, K_total) == 1 (every shape that fills the chip); for
+ * few-tile shapes, where the stand-alone GEMMs add two / four ordered K ranges, same tolerance instead (the module wrappers fuse only
+ * in the first case).  Saves writing and re-reading 2 * M * N_inter fp16.  Always the 256x256 geometry: meant for prefill batches (M >= 512).
  * N_inter % 128 == 0, N_inter >= 256; K_total as atom_gemm_w4a4_f16.
  */
 int atom_gemm_w4a4_silu_mul_quant_f6(const void *A_f6, const void *Bgu_f6s, const void *A8, const void *Bgu8, const void *sA8,

@@ -43,6 +43,15 @@ SPEC = {
         ("Norm/RMSNorm.cu", r"^#define SCALE_SIZE_A\(", "line"),
         ("Norm/test_RMSNorm.cu", r"^void run_cpu_rmsnorm_fp16_i4\(", "block"),
     ],
+    # the u4-output GEMM's epilogue helpers (DenseLayerGEMM_i4_o4.cu:63-80): PackInt4, mymax / mymin and local_max_min, which is
+    # __host__ __device__ -- the one piece of that epilogue that exists as host-callable reference code (the rest, :729-771, is
+    # the tail of a __global__ kernel and is applied line by line in oracle/ref/wrap.cpp around this function)
+    "o4.inc": [
+        ("GEMM/DenseLayerGEMM_i4_o4.cu", r"^struct PackInt4\{", "block"),
+        ("GEMM/DenseLayerGEMM_i4_o4.cu", r"^#define mymax\(", "line"),
+        ("GEMM/DenseLayerGEMM_i4_o4.cu", r"^#define mymin\(", "line"),
+        ("GEMM/DenseLayerGEMM_i4_o4.cu", r"^__forceinline__ __host__ __device__ void local_max_min\(", "block"),
+    ],
     # the reference's CPU implementations of the INT4 paged KV cache append and of quantised attention (its own test oracle,
     # kernels/src/flashinfer/cpu_reference.h) with the few definitions they use (paths relative to the reference root), one file
     # per namespace they live in

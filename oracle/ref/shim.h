@@ -59,6 +59,9 @@ using std::min;
 #include <vector>
 struct half2 { half x, y; };
 inline float __half2float(half h) { return (float)h; }
+// ---- for the u4-output GEMM epilogue (DenseLayerGEMM_i4_o4.cu:72-80, :722-786)
+struct float4 { float x, y, z, w; };
+inline half2 __floats2half2_rn(float a, float b) { return half2{half(a), half(b)}; }
 #define __host__
 #define __device__
 #define __forceinline__ inline

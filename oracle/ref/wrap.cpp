@@ -36,7 +36,60 @@ using namespace flashinfer;
 }  // namespace cpu_reference
 }  // namespace ref_kv
 
+// The u4-output GEMM's epilogue (DenseLayerGEMM_i4_o4.cu:704-788).  Only local_max_min (:72-80, __host__ __device__) exists as
+// host-callable reference code; the rest is the tail of the __global__ kernel.  o4_tile_row() applies that tail's scalar lines, in
+// their order and with their expressions, to one row of one 128-column output block, with the two threads of the row (loc_idx 0 /
+// 1, 64 elements each, :712-720) run one after the other and the shfl.bfly exchange (:737-747) as a plain swap -- around the
+// reference's own local_max_min, PackInt4, mymax and mymin.
+namespace ref_o4 {
+using std::abs;                                            // device code resolves abs((float)x) to the float overload
+#include "../_ref/o4.inc"
+constexpr int GROUP_SIZE = 128, elements_per_thread = 64, loadIters = elements_per_thread * sizeof(float) / 16;   // :708, :719-720
+inline void o4_tile_row(const float *row /* 128 FP32 sums */, uint8_t *D_row /* 64 bytes */, half2 *scale_zero) {
+  float4 elements_float4[2][loadIters];
+  float local_max[2], local_min[2];
+  for (int loc_idx = 0; loc_idx < 2; ++loc_idx) {
+    for (int i = 0; i < loadIters; ++i)                    // :722-727
+      elements_float4[loc_idx][i] = *(reinterpret_cast<const float4 *>(row + loc_idx * GROUP_SIZE / 2) + i);
+    local_max[loc_idx] = __half2float(half(-INFINITY));    // :729  0xFC00
+    local_min[loc_idx] = __half2float(half(INFINITY));     // :730  0x7C00
+    for (int i = 0; i < loadIters; ++i)                    // :732-735
+      local_max_min<float, float4>(elements_float4[loc_idx] + i, local_max[loc_idx], local_min[loc_idx]);
+  }
+  const float pmax[2] = {local_max[1], local_max[0]}, pmin[2] = {local_min[1], local_min[0]};   // :737-747 (bfly, lane ^ 1)
+  for (int loc_idx = 0; loc_idx < 2; ++loc_idx) {
+    float temp = pmax[loc_idx];
+    local_max[loc_idx] = mymax(local_max[loc_idx], temp);
+    temp = pmin[loc_idx];
+    local_min[loc_idx] = mymin(local_min[loc_idx], temp);
+    float scale = (local_max[loc_idx] - local_min[loc_idx]) / 15.f;   // :749-751
+    float zero = -local_min[loc_idx];
+    float r_scale = 1.f / scale;
+    if (loc_idx == 0) *scale_zero = __floats2half2_rn(scale, zero);   // :753-759
+    PackInt4 quantized[elements_per_thread / 2];
+    float *elements_float = reinterpret_cast<float *>(elements_float4[loc_idx]);
+    for (int i = 0; i < elements_per_thread; i += 2) {                // :762-771
+      int8_t result_0, result_1;
+      result_0 = (int8_t)(round((elements_float[i] + zero) * r_scale));
+      result_1 = (int8_t)(round((elements_float[i + 1] + zero) * r_scale));
+      quantized[i / 2].low = result_0 & 0xf;
+      quantized[i / 2].high = result_1 & 0xf;
+    }
+    std::memcpy(D_row + loc_idx * GROUP_SIZE / 2 / 2, quantized, sizeof(quantized));   // :774-786
+  }
+}
+}  // namespace ref_o4
+
 extern "C" {
+
+// c32 float [M, N] (the GEMM's FP32 sums) -> D u8 [M, N/2], output_scale half2 (scale, zero) [M, N/128]
+// (D + row * N/2 + bi * 64 + loc_idx * 32, output_scale[row * N/128 + bi]: DenseLayerGEMM_i4_o4.cu:758, :781-783)
+void ref_cpu_o4_epilogue(const float *c32, int M, int N, uint8_t *D, void *output_scale) {
+  for (int row = 0; row < M; ++row)
+    for (int bi = 0; bi < N / 128; ++bi)
+      ref_o4::o4_tile_row(c32 + (size_t)row * N + bi * 128, D + (size_t)row * N / 2 + bi * 64,
+                          reinterpret_cast<half2 *>(output_scale) + (size_t)row * N / 128 + bi);
+}
 
 // Append: cache u8 [pages, L, 2, N, P, D/2] / param half2 [pages, L, 2, N, P] (punica/utils/kvcache.py:17-26); k, v u8 [T, N, D/2] and
 // k_param, v_param half2 [T, N] hold the new tokens of all sequences back to back (append_indptr int32 [B + 1])

@@ -1,0 +1,101 @@
+"""Golden vectors for ONE Llama-7B-width decoder block from the UNMODIFIED reference (BASELINE config 4 at its stated width, at the
+batch the CPU oracle can hold -- SURVEY 8(d): "CPU oracle at reduced batch (B=1) because the naive attention materialises
+[B,32,2048,2048]"): hidden 4096 = 32 heads x 128, intermediate 11008, batch 1 x seq 2048, KV-cache INT4 fake-quant, W4A4 g128
+keeper 128, clips 0.9 / 0.85.
+
+Runs reference model/qLlamaLayer.py:86-127 (QLlamaDecoderLayer.forward) on CPU through the duck-typed "original layer" of
+gen_golden_block.py, prepared the way modelutils_llama.py prepares a layer (reorder -> quantiser wrappers -> quant()).  The output
+is 2048 x 4096 halves (16 MB); the fixture keeps a FIXED SAMPLE of token rows (every 32nd row + the first and last 8 = 80 rows,
+0.6 MB compressed) of y and of the residual-stream input of the MLP half, checksums of the full tensors, and checksums of the
+weights and of x, which the test re-generates from the same seeds (torch CPU generators are platform-independent).
+Container only (needs /root/reference; ~2 min on 8 cores):
+
+    python tests/golden/gen_golden_block7b.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from gen_golden import _import_reference, paper_args, n  # noqa: E402
+import gen_golden_block as GB  # noqa: E402
+
+HIDDEN, HEADS, INTER, BSZ, SEQ = 4096, 32, 11008, 1, 2048
+SEED_W, SEED_X = 17, 18
+
+
+def sample_rows(seq=SEQ):
+    """The token rows the fixture stores: every 32nd row plus the first and the last 8."""
+    rows = sorted(set(range(0, seq, 32)) | set(range(8)) | set(range(seq - 8, seq)))
+    return np.array(rows, dtype=np.int64)
+
+
+def build_original():
+    """Llama-7B-width duck-typed layer: weights ~ N(0, 0.02) (HF initializer_range), norm weights 1 + 0.1 N(0, 1)."""
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+    import types
+    g = torch.Generator().manual_seed(SEED_W)
+    lin = lambda i, o, s: GB._lin(i, o, s, g)
+    attn = types.SimpleNamespace(config=None, hidden_size=HIDDEN, num_heads=HEADS, num_key_value_heads=HEADS,
+                                 num_key_value_groups=1, max_position_embeddings=4096, rope_theta=10000.0,
+                                 q_proj=lin(HIDDEN, HIDDEN, 0.02), k_proj=lin(HIDDEN, HIDDEN, 0.02),
+                                 v_proj=lin(HIDDEN, HIDDEN, 0.02), o_proj=lin(HIDDEN, HIDDEN, 0.02),
+                                 rotary_emb=GB.Rotary(HIDDEN // HEADS))
+    mlp = types.SimpleNamespace(gate_proj=lin(HIDDEN, INTER, 0.02), up_proj=lin(HIDDEN, INTER, 0.02),
+                                down_proj=lin(INTER, HIDDEN, 0.02), act_fn=torch.nn.SiLU())
+    n1, n2 = LlamaRMSNorm(HIDDEN, eps=1e-5), LlamaRMSNorm(HIDDEN, eps=1e-5)
+    n1.weight.data = 1.0 + 0.1 * torch.randn(HIDDEN, generator=g)
+    n2.weight.data = 1.0 + 0.1 * torch.randn(HIDDEN, generator=g)
+    return types.SimpleNamespace(hidden_size=HIDDEN, self_attn=attn, mlp=mlp, input_layernorm=n1.half(),
+                                 post_attention_layernorm=n2.half())
+
+
+def weight_abs_sum(orig):
+    s = 0.0
+    for mod in (orig.self_attn.q_proj, orig.self_attn.k_proj, orig.self_attn.v_proj, orig.self_attn.o_proj,
+                orig.mlp.gate_proj, orig.mlp.up_proj, orig.mlp.down_proj):
+        s += float(mod.weight.detach().double().abs().sum())
+    return s + float(orig.input_layernorm.weight.detach().double().abs().sum()
+                     + orig.post_attention_layernorm.weight.detach().double().abs().sum())
+
+
+def make_inputs():
+    """Reorder indices, x ~ N(0, 1) [1, 2048, 4096] with 32 outlier channels x 8, positions, causal mask."""
+    return GB.make_inputs(HIDDEN, INTER, BSZ, SEQ, seed=SEED_X)
+
+
+def main():
+    quant, qLinearLayer, qLlamaLayer = _import_reference()
+    torch.set_num_threads(os.cpu_count() or 8)
+    args = paper_args(kv_cache=True)
+    t0 = time.time()
+    orig = build_original()
+    wsum = weight_abs_sum(orig)
+    idx, x, pos, mask = make_inputs()
+    m = qLlamaLayer.QLlamaDecoderLayer(orig, args)
+    GB.prepare(m, args, idx, quant)
+    print("prepared in %.1f s" % (time.time() - t0))
+    mid = {}
+    h = m.post_attention_layernorm.register_forward_hook(lambda mod, inp, out: mid.__setitem__("h", inp[0].detach().clone()))
+    t0 = time.time()
+    with torch.no_grad():
+        y = m(x.clone(), attention_mask=mask, position_ids=pos)[0]
+    h.remove()
+    print("reference QLlamaDecoderLayer.forward at 1 x %d x %d on CPU: %.1f s" % (SEQ, HIDDEN, time.time() - t0))
+    rows = sample_rows()
+    yf = y[0].float()
+    out = dict(rows=rows, y_rows=n(y[0][rows]), h_rows=n(mid["h"][0][rows]),
+               y_abs_sum=np.float64(yf.double().abs().sum().item()), y_sq_sum=np.float64(yf.double().pow(2).sum().item()),
+               y_row_abs_sum=n(yf.double().abs().sum(-1)).astype(np.float32),       # one number per token row: localises a mismatch
+               x_abs_sum=np.float64(x.double().abs().sum().item()), weight_abs_sum=np.float64(wsum))
+    path = os.path.join(HERE, "llama_block_7b_1x2048.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; |y| rms", float(yf.pow(2).mean().sqrt()))
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ def lib():
         L.ref_cpu_append_paged_kv_i4.argtypes = [vp] * 5 + [i] * 6 + [vp] * 5
         L.ref_cpu_single_decode_i4.restype = None
         L.ref_cpu_single_decode_i4.argtypes = [vp] * 5 + [i, i, i, ctypes.c_float, ctypes.c_float, vp]
+        L.ref_cpu_o4_epilogue.restype = None
+        L.ref_cpu_o4_epilogue.argtypes = [vp, i, i, vp, vp]
         L.ref_scale_index.restype = i
         L.ref_scale_index.argtypes = [i]
         _lib = L
@@ -88,6 +90,30 @@ def activate(a, b):
 
 def rmsnorm(x, w, eps, idx):
     return _run("rmsnorm", x, w=w, idx=idx, eps=eps)
+
+
+def o4_epilogue(c32):
+    """The u4-output GEMM's epilogue as the reference CODE computes it (DenseLayerGEMM_i4_o4.cu:722-786 applied around the
+    reference's own local_max_min, :72-80; oracle/ref/wrap.cpp) on FP32 sums [M, N] -> (u8 [M, N/2], f16 (scale, zero) [M, N/128, 2]).
+    The reference casts round(...) to int8_t with no clamp (:766-767): out of the int8 range that is undefined behaviour on the host
+    (and a saturating cvt on the device), so callers compare only where in_range() holds."""
+    c32 = np.ascontiguousarray(c32, dtype=np.float32)
+    M, N = c32.shape
+    D = np.zeros((M, N // 2), np.uint8)
+    sz = np.zeros((M, N // 128, 2), np.float16)
+    lib().ref_cpu_o4_epilogue(_p(c32), M, N, _p(D), _p(sz))
+    return D, sz
+
+
+def o4_in_range(c32):
+    """[M, N/128] bool: groups whose reference-code quotients (x + zero) * r all lie inside the int8 range (see o4_epilogue)."""
+    g = np.asarray(c32, np.float32).reshape(c32.shape[0], -1, 128)
+    a = np.abs(g)
+    mx, mn = a.max(-1), a.min(-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.float32(1) / ((mx - mn) / np.float32(15)).astype(np.float32)
+        q = ((g - mn[..., None]).astype(np.float32) * r[..., None]).astype(np.float32)
+    return np.isfinite(q).all(-1) & (np.abs(q) < 127).all(-1)
 
 
 # ---- INT4 paged KV cache: the reference's CPU restatements (kernels/src/flashinfer/cpu_reference.h)

@@ -212,3 +212,138 @@ def test_qlinear_weight_memory_policy():
     assert torch.equal(a(small), b(small))                                  # re-packed on demand
     assert b.weight_bytes()["packed_int4"] == wa["packed_int4"]
     assert torch.equal(a(big), b(big))
+    # a .to() round trip with released codes (None entries in the packed tuple) and a cached F6 form
+    c = mk()
+    c.weight = a.weight.clone()
+    c.keep_packed_with_f6 = False
+    c.quant()
+    want = a(big)
+    assert torch.equal(c(big), want) and c.weight_bytes()["packed_int4"] == 0
+    c = c.to("cuda").half()
+    assert torch.equal(c(big), want)
+    c = c.to("cpu").to("cuda")
+    assert torch.equal(c(big), want) and torch.equal(c(small), a(small))
+
+
+def test_mlp_fused_gate_up_honours_weight_memory_policy():
+    """QLlamaMLP builds its fused gate/up operand from the packed INT4 codes of both layers; with keep_packed_with_f6 = False the
+    codes are re-packed for the build only and released again, and later batches (cache hit) do not bring them back."""
+    import gen_golden_block as G
+    from atom_amd.model import quant, qLlamaLayer
+    args = _args()
+    hidden, inter = 1024, 2816
+    orig = G.build_original(hidden, 8, inter, seed=11)
+    mlp = qLlamaLayer.QLlamaMLP(orig.mlp, args).to("cuda")
+    ref = qLlamaLayer.QLlamaMLP(G.build_original(hidden, 8, inter, seed=11).mlp, args).to("cuda")
+    for mod in (mlp, ref):
+        from functools import partial
+        mod.act_quant.configure(partial(quant.quantize_activation_wrapper, args=args), None)
+        for l in (mod.gate_proj, mod.up_proj, mod.down_proj):
+            l.quant()
+    for l in (mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+        l.keep_packed_with_f6 = False
+    x = quant.hip_act_quant((torch.randn(4096, hidden, device="cuda") * 1.5).half(), args)
+    assert quant.get_codes(x).wide == "f6"
+    assert torch.equal(mlp(x), ref(x)) and mlp._fused is not None
+    held = lambda mod: sum(l.weight_bytes()["packed_int4"] for l in (mod.gate_proj, mod.up_proj, mod.down_proj))
+    assert held(ref) == 3 * hidden * inter // 2 - 128 * inter - 64 * hidden and held(mlp) == 0
+    assert torch.equal(mlp(x), ref(x)) and held(mlp) == 0
+
+
+def test_llama7b_block_matches_reference_at_stated_width(golden_dir):
+    """BASELINE config 4 at its stated WIDTH (hidden 4096 = 32 heads x 128, intermediate 11008), batch 1 x 2048 tokens -- the batch
+    the CPU oracle can hold -- against the UNMODIFIED reference QLlamaDecoderLayer.forward (model/qLlamaLayer.py:86-127)
+    run on CPU by tests/golden/gen_golden_block7b.py.  Weights, indices and x are re-generated from the same seeds (checksums in
+    the fixture); the fixture holds 80 sampled token rows of the block output y and of the MLP half's input, plus per-row and
+    whole-tensor checksums of y.  Same three statements as the 512-wide test, at the width the path is built for:
+      (1) every one of the 7 W4A4 GEMMs (here: F6 operands on the block-scaled MFMA kernels, 2048 rows) within 1e-2 of F.linear on
+          the same fake-quant operands;
+      (2) the block through our modules with the packed weights dropped (fused HIP quantisers + F.linear in the reference's order)
+          reproduces the reference's sampled rows and row checksums;
+      (3) the full HIP path: INT4 code flips per quantiser between the HIP run and the reference-order run within the limits the
+          512-wide test established, and the sampled rows within the end-to-end bound that follows."""
+    import gen_golden_block7b as G7
+    import gen_golden_block as G
+    from atom_amd.model import quant, qLlamaLayer
+    from atom_amd.model.qLinearLayer import find_qlinear_layers
+    z = np.load(os.path.join(golden_dir, "llama_block_7b_1x2048.npz"))
+    args = _args()
+    orig = G7.build_original()
+    wsum = G7.weight_abs_sum(orig)
+    idx, x, pos, mask = G7.make_inputs()
+    assert abs(wsum - float(z["weight_abs_sum"])) < 1e-9 * wsum
+    assert abs(float(x.double().abs().sum()) - float(z["x_abs_sum"])) < 1e-9 * float(z["x_abs_sum"])
+    m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
+    G.prepare(m, args, {k: v.cuda() for k, v in idx.items()}, quant)
+    layers = find_qlinear_layers(m)
+    assert len(layers) == 7 and all(l.packed_weight() is not None for l in layers.values())
+    rows = torch.from_numpy(z["rows"]).cuda()
+    seen, codes_hip, codes_ref, mid = {}, {}, {}, {}
+
+    def unpack6(cd):
+        """INT4 code fields of an activation operand, whatever its format: F6 records [G, rows_pad, 104] or packed nibbles."""
+        if cd.wide == "f6":
+            b = cd.o4[:, : cd.rows, :96].reshape(cd.o4.shape[0], cd.rows, 32, 3).to(torch.int32)
+            w = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+            f = torch.stack([(w >> (6 * i)) & 0x3F for i in range(4)], -1).reshape(cd.o4.shape[0], cd.rows, 128)
+            return torch.where(f == 0x20, torch.zeros_like(f), f)
+        a = cd.o4.view(torch.uint8)
+        return torch.stack([a & 0xF, a >> 4], -1)
+
+    def hook(name, store, check):
+        def f(mod, inp, out):
+            cd = quant.get_codes(inp[0])
+            assert cd is not None, f"{name}: activation codes lost -> would silently use F.linear"
+            store[name] = (unpack6(cd), cd.o8.clone())
+            if check:
+                assert cd.wide == "f6" and mod._f6 is not None, name        # 2048 rows: the F6 route
+                ref = torch.nn.functional.linear(inp[0], mod.weight, mod.bias).float()
+                seen[name] = ((out.float() - ref).abs().max() / ref.pow(2).mean().sqrt()).item()
+        return f
+    handles = [l.register_forward_hook(hook(n_, codes_hip, True)) for n_, l in layers.items()]
+    fused_min = type(m.mlp).FUSED_MIN_ROWS
+    m.mlp.FUSED_MIN_ROWS = 1 << 30               # gate_proj / up_proj as their own launches, so that their hooks see them
+    y = m(x.cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda())[0]
+    for h in handles:
+        h.remove()
+    assert len(seen) == 7 and max(seen.values()) <= 1e-2, seen                          # (1)
+    m.mlp.FUSED_MIN_ROWS = fused_min             # and as the module runs them at this size: gate / up / SiLU x up / quantiser fused
+    y_fused = m(x.cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda())[0]
+    assert m.mlp._fused is not None and torch.equal(y_fused, y)                         # same bits (summation order 1 at this shape)
+    for l in layers.values():                    # force the reference forward (F.linear on the fake-quant weight)
+        l._packed = None
+        l._f6 = None
+        l._unpackable_key = l._weight_key()
+    m.mlp._fused = None
+    handles = [l.register_forward_hook(hook(n_, codes_ref, False)) for n_, l in layers.items()]
+    handles.append(m.post_attention_layernorm.register_forward_hook(lambda mod, inp, out: mid.__setitem__("h", inp[0].detach().clone())))
+    y2 = m(x.cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda())[0]
+    for h in handles:
+        h.remove()
+    want = torch.from_numpy(z["y_rows"]).cuda().double()
+    rms = want.pow(2).mean().sqrt().item()
+    got2 = y2[0][rows].double()
+    h2 = mid["h"][0][rows].double()
+    hw = torch.from_numpy(z["h_rows"]).cuda().double()
+    rel_h = ((h2 - hw).norm() / hw.norm()).item()
+    rel2 = ((got2 - want).norm() / want.norm()).item()
+    rowsum = y2[0].double().abs().sum(-1)
+    rel_rows = ((rowsum - torch.from_numpy(z["y_row_abs_sum"]).cuda().double()).abs() / rowsum).max().item()
+    print("reference-order run vs reference golden: attention half", rel_h, "block", rel2, "worst row checksum", rel_rows)
+    assert rel_h < 5e-3 and rel2 < 5e-3                                                 # (2)
+    assert (got2 - want).abs().max().item() <= 0.1 * rms
+    assert rel_rows < 2e-2 and abs(float(y2.double().abs().sum()) - float(z["y_abs_sum"])) < 2e-3 * float(z["y_abs_sum"])
+    flips = {}
+    for n_ in layers:                                                                   # (3)
+        a4, a8 = codes_hip[n_]
+        b4, b8 = codes_ref[n_]
+        flips[n_] = ((a4 != b4).float().mean().item(), (a8 != b8).float().mean().item())
+    print("code flips per quantiser (INT4, INT8 keeper):", {k: (round(v[0], 5), round(v[1], 5)) for k, v in flips.items()})
+    limit = {"self_attn.q_proj": 0.0, "self_attn.k_proj": 0.0, "self_attn.v_proj": 0.0, "self_attn.o_proj": 0.03,
+             "mlp.gate_proj": 0.02, "mlp.up_proj": 0.02, "mlp.down_proj": 0.12}
+    for n_, (f4, _) in flips.items():
+        assert f4 <= limit[n_], (n_, flips)
+    got = y[0][rows].double()
+    rel = ((got - want).norm() / want.norm()).item()
+    print("end-to-end relative Frobenius deviation of the HIP run on the sampled rows:", rel)
+    assert rel < 0.10

@@ -15,13 +15,19 @@ def _weights(ops, N, K, g, scale):
     return ops.quant_weight_w4(W, 0.85, 2)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 256, 384), (1000, 1408, 640), (2048, 11008, 4096), (300, 512, 1152)])
+@pytest.mark.parametrize("M,N,K,order", [(512, 256, 384, 1), (1000, 1408, 640, 1), (2048, 11008, 4096, 1), (512, 11008, 4096, 1),
+                                         (300, 512, 1152, 2), (512, 1024, 4096, 4)])
 @pytest.mark.parametrize("mode,clip", [("sim", 0.9), ("kernel", 1.0)])
 @pytest.mark.parametrize("layout", ["plain", "ref"])
-def test_fused_gate_up_equals_three_launches(M, N, K, mode, clip, layout):
+def test_fused_gate_up_equals_three_launches(M, N, K, order, mode, clip, layout):
+    """order = the summation order of the stand-alone gate / up GEMMs (atom_gemm_w4a4_f6_order).  The fused launch always sums the K
+    steps in order: where the stand-alone GEMMs do too (order 1) everything is bit-identical; where they add two / four ordered K
+    ranges (few-tile shapes, which the module wrappers do not fuse) a gate / up value can differ in its last fp16 bit, so the bound is
+    a stated fraction of codes off by one step."""
     from atom_amd import ops
     if layout == "ref" and N > 2000:
         pytest.skip("layout coverage on the small shapes")
+    assert ops.L.lib().atom_gemm_w4a4_f6_order(M, N, K) == order
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = (torch.randn((M, K), device="cuda", generator=g)).half()
     x[:, -128:] *= 12
@@ -35,6 +41,12 @@ def test_fused_gate_up_equals_three_launches(M, N, K, mode, clip, layout):
     want = ops.activate_fp16_i4(y_g, y_u, quant_mode=mode, clip=clip, scale_layout=layout, return_dequant=True, wide_codes="f6")
     fused = ops.fuse_gate_up_weights(gate, up)
     got = ops.gate_up_silu_quant_f6(a[1], a[0], a[2], fused, quant_mode=mode, clip=clip, scale_layout=layout, return_dequant=True)
+    if order != 1:
+        g6, w6 = f6_fields(t2n(got[1])[:, :M]).astype(np.int32), f6_fields(t2n(want[1])[:, :M]).astype(np.int32)
+        assert (g6 != w6).mean() <= 2e-3 and (got[0] != want[0]).float().mean().item() <= 2e-2
+        d = (got[4].float() - want[4].float()).abs().max().item()
+        assert d <= 1.01 * t2n(want[3]).astype(np.float32).max() * 2, d              # at most ~ one quantisation step
+        return
     assert torch.equal(got[0], want[0]), "keeper INT8 codes"
     g6, w6 = t2n(got[1])[:, :M], t2n(want[1])[:, :M]
     assert np.array_equal(f6_fields(g6), f6_fields(w6)), "BF6 code fields"

@@ -112,3 +112,36 @@ def test_batch_decode_matches_reference_cpu_implementation():
         want = R.single_decode_i4(q[b], gather(data, 0), gather(data, 1), gather(param, 0), gather(param, 1))
         scale = np.abs(want).max()
         assert np.abs(got[b] - want).max() <= 2e-5 * scale + 1e-6, (b, np.abs(got[b] - want).max(), scale)
+
+
+# ---- the u4-output GEMM epilogue: the restatement of the reference CODE against the reference's own local_max_min
+def o4_sums(M, N, seed):
+    """FP32 sums with every case the epilogue distinguishes: all-positive rows, mixed signs, a wide dynamic range, groups whose
+    magnitudes nearly coincide (large quotients) and an all-equal group (scale 0)."""
+    g = np.random.default_rng(seed)
+    c = (g.standard_normal((M, N)) * g.uniform(0.05, 40.0, size=(M, 1))).astype(np.float32)
+    c[: M // 4] = np.abs(c[: M // 4])
+    if M >= 8:
+        c[M // 4] = np.float32(3.0) + (g.standard_normal(N) * 1e-3).astype(np.float32)     # |x| nearly equal: quotients up to ~ 1e4
+        c[M // 4 + 1, :128] = np.float32(-2.5)                                              # scale 0
+    return c
+
+
+@pytest.mark.parametrize("M,N", [(1, 128), (40, 512), (257, 4096)])
+def test_o4_reference_code_restatement_vs_reference_local_max_min(M, N):
+    """oracle.quant_o4(ref_extrema=True) -- what ATOM_O4_REF_EXTREMA is tested against on the GPU -- equals the reference's epilogue
+    (DenseLayerGEMM_i4_o4.cu:722-786 around its own local_max_min, compiled from the reference source) bit for bit: (scale, zero)
+    everywhere, codes wherever the reference's unclamped int8 cast is defined."""
+    c = o4_sums(M, N, seed=M + N)
+    want_q, want_sz = R.o4_epilogue(c)
+    got_q, got_sz = O.quant_o4(c, ref_extrema=True)
+    assert np.array_equal(bits16(got_sz), bits16(want_sz))
+    ok = R.o4_in_range(c)
+    assert ok.mean() > 0.9
+    assert np.array_equal(got_q.reshape(M, -1, 64)[ok], want_q.reshape(M, -1, 64)[ok])
+    # and the intended epilogue (the library's default) is the same thing on groups without negative values
+    pos = (c.reshape(M, -1, 128) >= 0).all(-1) & ok
+    if pos.any():
+        dq, dsz = O.quant_o4(c)
+        assert np.array_equal(dq.reshape(M, -1, 64)[pos], want_q.reshape(M, -1, 64)[pos])
+        assert np.array_equal(bits16(dsz)[pos], bits16(want_sz)[pos])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tools/probes/issue_probe.cpp: MFMA / VALU co-issue probe for gfx950 (MI355X).
+"""Generates build/tools/gen/issue_probe.cpp (not committed: `make -C atom_amd/csrc probes`): MFMA / VALU co-issue probe for gfx950 (MI355X).
 
 Question: does VALU work hide under the MFMA of a SIMD, and under which stream shapes?  Every kernel
 is ONE hand-written instruction stream (inline asm on hard-coded registers v64..v127, so the order is exactly what is
@@ -246,7 +246,7 @@ int main(int argc, char **argv) {
   return 0;
 }
 ''')
-    open(sys.argv[1] if len(sys.argv) > 1 else "tools/probes/issue_probe.cpp", "w").write("\n".join(out) + "\n")
+    open(sys.argv[1] if len(sys.argv) > 1 else "build/tools/gen/issue_probe.cpp", "w").write("\n".join(out) + "\n")
 
 
 if __name__ == "__main__":
