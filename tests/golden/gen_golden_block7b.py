@@ -6,8 +6,8 @@ keeper 128, clips 0.9 / 0.85.
 Runs reference model/qLlamaLayer.py:86-127 (QLlamaDecoderLayer.forward) on CPU through the duck-typed "original layer" of
 gen_golden_block.py, prepared the way modelutils_llama.py prepares a layer (reorder -> quantiser wrappers -> quant()).  The output
 is 2048 x 4096 halves (16 MB); the fixture keeps a FIXED SAMPLE of token rows (every 32nd row + the first and last 8 = 80 rows,
-0.6 MB compressed) of y and of the residual-stream input of the MLP half, checksums of the full tensors, and checksums of the
-weights and of x, which the test re-generates from the same seeds (torch CPU generators are platform-independent).
+0.6 MB compressed) of y and of the residual-stream input of the MLP half, 16 rows of the intermediate tensors either side of every
+quantiser (for stage-wise, teacher-forced checks), checksums of the full tensors, and checksums of the weights and of x, which the test re-generates from the same seeds (torch CPU generators are platform-independent).
 Container only (needs /root/reference; ~2 min on 8 cores):
 
     python tests/golden/gen_golden_block7b.py
@@ -32,6 +32,11 @@ def sample_rows(seq=SEQ):
     """The token rows the fixture stores: every 32nd row plus the first and the last 8."""
     rows = sorted(set(range(0, seq, 32)) | set(range(8)) | set(range(seq - 8, seq)))
     return np.array(rows, dtype=np.int64)
+
+
+def mid_rows(seq=SEQ):
+    """The 16 token rows for which the fixture also stores intermediate tensors (stage-wise, teacher-forced checks)."""
+    return np.array(sorted(set(range(5, seq, 136)) | {0})[:16], dtype=np.int64)
 
 
 def build_original():
@@ -80,15 +85,27 @@ def main():
     GB.prepare(m, args, idx, quant)
     print("prepared in %.1f s" % (time.time() - t0))
     mid = {}
-    h = m.post_attention_layernorm.register_forward_hook(lambda mod, inp, out: mid.__setitem__("h", inp[0].detach().clone()))
+    keep = lambda name, io: (lambda mod, inp, out: mid.__setitem__(name, (inp[0] if io == "in" else out).detach().clone()))
+    hooks = [m.post_attention_layernorm.register_forward_hook(keep("h", "in")),
+             m.input_layernorm.register_forward_hook(keep("xq1", "out")),
+             m.post_attention_layernorm.register_forward_hook(keep("xq2", "out")),
+             m.self_attn.q_proj.register_forward_hook(keep("q", "out")),
+             m.self_attn.o_proj.register_forward_hook(keep("attn_q", "in")),
+             m.mlp.gate_proj.register_forward_hook(keep("gate", "out")),
+             m.mlp.up_proj.register_forward_hook(keep("up", "out")),
+             m.mlp.down_proj.register_forward_hook(keep("act_q", "in")),
+             m.mlp.down_proj.register_forward_hook(keep("down", "out"))]
     t0 = time.time()
     with torch.no_grad():
         y = m(x.clone(), attention_mask=mask, position_ids=pos)[0]
-    h.remove()
+    for h in hooks:
+        h.remove()
     print("reference QLlamaDecoderLayer.forward at 1 x %d x %d on CPU: %.1f s" % (SEQ, HIDDEN, time.time() - t0))
     rows = sample_rows()
     yf = y[0].float()
-    out = dict(rows=rows, y_rows=n(y[0][rows]), h_rows=n(mid["h"][0][rows]),
+    mr = mid_rows()
+    out = dict(rows=rows, y_rows=n(y[0][rows]), h_rows=n(mid["h"][0][rows]), mid_rows=mr,
+               **{"mid_" + k: n(v[0][mr]) for k, v in mid.items()},
                y_abs_sum=np.float64(yf.double().abs().sum().item()), y_sq_sum=np.float64(yf.double().pow(2).sum().item()),
                y_row_abs_sum=n(yf.double().abs().sum(-1)).astype(np.float32),       # one number per token row: localises a mismatch
                x_abs_sum=np.float64(x.double().abs().sum().item()), weight_abs_sum=np.float64(wsum))
