@@ -1408,16 +1408,125 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
   }
 }
 
+// Keeper half-step of the q kernel, pipelined like q_step (round 3; p_keeper above issued MFMA -> convert -> multiply -> FMA per
+// micro-tile with the MFMA's result latency exposed 32 times per half: 4.2 us of the 4096^3 launch for 1/32 of its work):
+//  * pair slots as in q_step -- the two INT8 MFMAs of slot i are issued before the de-quantisation of slot i - 1;
+//  * the accumulator starts at the bit pattern of 1.5 * 2^23 (the MFMA's C operand), so that the register read as a float is
+//    12582912 + idot exactly and t = fma(acc, sA8, -12582912 * sA8) IS round_f32(idot * sA8) (the INT8 tile kernel's trick,
+//    gemm_w4a4_v2.hip): no v_cvt_f32_i32, and the 8 + 8 VALU of an int4 pair;
+//  * the weight scales are converted to FP32 once per half-step, the token fragment of block tb + 2 is requested behind the last
+//    MFMA that reads block tb's;
+//  * STORE (the second half, plain fp16 output): a token block's 64 x 16 outputs are final once its pair h = 1 is de-quantised;
+//    they are converted and stored (two 16-byte stores per lane) behind the MFMAs of the following slot, so that the kernel's
+//    store tail -- 2-4 us with all 256 workgroups storing 32 MiB at once after the loop -- shrinks to the last block's.
+// Same arithmetic as p_keeper: bit-identical results.
+template <class C, bool STORE>
+__device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, int wm, int wn, int lane, float (&c)[4][8][4], int m0, int n0) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int sw = (l15 >> 1) & 3;                                       // swizzle key (row >> 2) & 3 of row 2 * l15 + (blk & 1)
+  const char *pw = slot + (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const char *pa = slot + (C::BN + wm * 128 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const char *psa = slot + C::KP_SA_OFF + (wm * 128 + 2 * l15) * 4;
+  const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
+  v4i af[4], bf[2];
+  float sb[2][8], sa[2], nms[2];
+  v4i acc[2][2];
+  const v4i magic = {kMagicBits, kMagicBits, kMagicBits, kMagicBits};
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb) af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + p_row(fb) * 64));
+  bf[0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(0) * 64));
+  bf[1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(1) * 64));
+  half_t sah[2];
+  sah[0] = *reinterpret_cast<const half_t *>(psa + p_row(0) * 4);
+  sah[1] = *reinterpret_cast<const half_t *>(psa + p_row(1) * 4);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const v4u w = *reinterpret_cast<const v4u *>(psb + 64 * h);
+    const half_t *hv = reinterpret_cast<const half_t *>(&w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sb[h][j] = (float)hv[j]; asm volatile("" : "+v"(sb[h][j])); }   // opaque: no v_fma_mix re-folding
+  }
+  auto store_block = [&](int tb) {                                     // fp16 outputs of token block tb: 8 consecutive features per pair
+    const int m = m0 + wm * 128 + p_row(tb) + 2 * l15;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + wn * 64 + 32 * h + 8 * kb;
+      if (n >= p.N) continue;
+      v4u o;
+      half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ov[2 * r] = f2h(c[2 * h][tb][r]);
+        ov[2 * r + 1] = f2h(c[2 * h + 1][tb][r]);
+      }
+      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = o;
+    }
+  };
+  auto dequant = [&](int j) {                                          // pair slot j: token block j / 2, feature-block pair j % 2
+    const int tb = j >> 1, h = j & 1;
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[4 * k + r] = __builtin_fmaf(__int_as_float(acc[j & 1][k][r]), sa[tb & 1], nms[tb & 1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c[2 * h + k][tb][r] = __builtin_fmaf(t[4 * k + r], sb[h][2 * r + k], c[2 * h + k][tb][r]);
+        asm volatile("" : "+v"(c[2 * h + k][tb][r]));
+      }
+  };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int tb = i >> 1, h = i & 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (h == 0) {                                                      // this block's token scale arrived with its fragment
+      sa[tb & 1] = (float)sah[tb & 1];
+      nms[tb & 1] = -kMagic * sa[tb & 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) acc[i & 1][k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * h + k], bf[tb & 1], magic, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h == 1 && tb + 2 < 8) {                                        // the buffer of block tb is free: block tb + 2
+      bf[tb & 1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(tb + 2) * 64));
+      sah[tb & 1] = *reinterpret_cast<const half_t *>(psa + p_row(tb + 2) * 4);
+    }
+    if constexpr (STORE) { if (h == 1 && tb >= 1) store_block(tb - 1); }   // final since slot i - 1's de-quantisation
+    __builtin_amdgcn_sched_barrier(0);
+    if (i > 0) dequant(i - 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dequant(15);
+  if constexpr (STORE) store_block(7);
+}
+
 // GU != 0: the weight rows are gate_proj / up_proj interleaved per wave (32 gate features, then the same 32 up features), so a
 // lane ends the K loop with gate and up of the SAME (token, feature) pairs, and the epilogue is the reference's next two ops --
 // act_fn(gate) * up and the per-token group quantiser (model/qLlamaLayer.py:345-351; punica/models/llama.py:85-87 ->
 // Activate.cuh:67-180) -- writing the F6 activation operand of down_proj directly (GU = 1: simulated-path arithmetic, 2: the CUDA
 // kernels').  Bit-identical to fp16 GEMMs + atom_silu_mul_quant_f16; saves writing and re-reading 2 x M x N_inter fp16.
-template <class C, int GU = 0>
+// TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
+// [0..15] kernel phases, [16 + s] start of K step s, [62], [63] s_memrealtime (100 MHz) at entry and exit
+template <class C, int GU = 0, bool TR = false>
 __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3 && C::NW == 8, "q kernel: 256x256, 8 waves of 64 x 128");
   using Q = QC<C>;
+  unsigned *trb = nullptr;
+  auto kstamp = [&](int k) {
+    if constexpr (TR) {
+      if (trb) { const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) trb[k] = t; }
+    }
+  };
+  if constexpr (TR) {
+    if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
+      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 64;
+      if ((threadIdx.x & 63) == 0) trb[62] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
+    kstamp(0);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1466,8 +1575,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   issue_all(std::integral_constant<int, 0>(), 0);
   if (G >= 2) issue_all(std::integral_constant<int, 1>(), 1);
   else issue_keeper<C>(p, 0, slot_of(1), wave, lane, m0, n0);
+  kstamp(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  kstamp(2);
 
   const int l15 = lane & 15, kb = lane >> 4;
   QRegs<C> R;
@@ -1507,6 +1618,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   // step s on slot SL: regular (the LDS-DMA of int4 stage s + 2 behind the mid-step barrier), K0 / K1 (the keeper halves instead)
   auto reg = [&](auto sl, int s) {
     constexpr int SL = decltype(sl)::value;
+    if constexpr (TR) { if (s < 44) kstamp(16 + s); }
     const int g = s + 2;
     const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
     const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
@@ -1518,8 +1630,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   int s = 0;
   for (; s + 4 < G; s += 3) { reg(S0(), s); reg(S1(), s + 1); reg(S2(), s + 2); }
   // The last 2..4 steps run on ONE generic code body (run-time stage slots): 0..2 regular steps, then the two whose LDS-DMA is a
-  // keeper half instead of an int4 stage (the second one has no next int4 stage to prefetch from).
+  // keeper half instead of an int4 stage (the second one has no next int4 stage to prefetch from).  (Round 3 tried compile-time
+  // slots for these steps too -- five step bodies, a wave-uniform branch per DMA group: ~750 cycles fewer per tail step in the
+  // s_memtime trace, no change in wall time at 4096^3 and -0.8 % at 8192^3 under the power cap; profiles/r03_gemm_experiments.txt.)
   for (; s < G; ++s) {
+    if constexpr (TR) { if (s < 44) kstamp(16 + s); }
     const int g = s + 2;                                    // the stage this step's LDS-DMA fetches: int4 g, or keeper half g - G
     const int dsl = g % 3;
     const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
@@ -1542,10 +1657,20 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
       for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][7][r]);
   }
   // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
-  p_keeper<C>(slot_of(G), wm, wn, lane, c);
+  kstamp(4);
+  q_keeper<C, false>(p, slot_of(G), wm, wn, lane, c, m0, n0);
+  kstamp(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  p_keeper<C>(slot_of(G + 1), wm, wn, lane, c);
+  kstamp(6);
+  q_keeper<C, GU == 0>(p, slot_of(G + 1), wm, wn, lane, c, m0, n0);     // GU == 0: the fp16 output leaves from inside this step
+  if constexpr (TR) {
+    kstamp(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    kstamp(8);
+    if (trb && (threadIdx.x & 63) == 0) trb[63] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  }
+  if constexpr (GU == 0) return;
 
   if constexpr (GU != 0) {
     constexpr bool SIM = GU == 1;
@@ -1631,33 +1756,14 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     }
     return;
   }
-  // epilogue: a lane holds 8 consecutive features per token and feature-block pair -> one 16-byte store each
-#pragma unroll
-  for (int tb = 0; tb < 8; ++tb) {
-    const int m = m0 + wm * 128 + p_row(tb) + 2 * l15;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = n0 + wn * 64 + 32 * h + 8 * kb;
-      if (n >= p.N) continue;
-      v4u o;
-      half_t *ov = reinterpret_cast<half_t *>(&o);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ov[2 * r] = f2h(c[2 * h][tb][r]);
-        ov[2 * r + 1] = f2h(c[2 * h + 1][tb][r]);
-      }
-      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = o;
-    }
-  }
 }
 
-template <class C, int GU = 0>
+template <class C, int GU = 0, bool TR = false>
 static int launch_q(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C, GU>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C, GU, TR>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C, GU>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C, GU, TR>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
   return check_launch();
 }
 
@@ -1734,6 +1840,13 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
     if (cfg == 1005) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2, false, true>(q, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, false, true>(q, s);
+  }
+  if (cfg == 2016) {   // traced run of the q kernel (tools/trace_f6q.cpp)
+    const char *e = getenv("ATOM_TRACE_PTR");
+    if (!e || !p.sB32) return ATOM_ERR_INVALID_ARG;
+    GemmParams q = p;
+    q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+    return f6::launch_q<f6::Cfg<256, 256, 4, 3>, 0, true>(q, s);
   }
   if (cfg == 1016) {   // traced run of the pipelined kernel (tools/trace_f6.cpp)
     const char *e = getenv("ATOM_TRACE_PTR");

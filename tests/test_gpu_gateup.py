@@ -45,7 +45,11 @@ def test_fused_gate_up_equals_three_launches(M, N, K, order, mode, clip, layout)
         g6, w6 = f6_fields(t2n(got[1])[:, :M]).astype(np.int32), f6_fields(t2n(want[1])[:, :M]).astype(np.int32)
         assert (g6 != w6).mean() <= 2e-3 and (got[0] != want[0]).float().mean().item() <= 2e-2
         d = (got[4].float() - want[4].float()).abs().max().item()
-        assert d <= 1.01 * t2n(want[3]).astype(np.float32).max() * 2, d              # at most ~ one quantisation step
+        from oracle import atom_oracle as O
+        s4 = t2n(want[3]) if layout == "plain" else O.scales_from_ref_layout(t2n(want[3]), M)   # (the replicated layout has unwritten gaps)
+        s8 = t2n(want[2]) if layout == "plain" else O.scales_from_ref_layout(t2n(want[2]), M)
+        step = max(float(s4[..., :M].astype(np.float32).max()), float(s8[..., :M].astype(np.float32).max()))
+        assert d <= 2.02 * step, (d, step)                                            # at most ~ one quantisation step (+ a scale ulp)
         return
     assert torch.equal(got[0], want[0]), "keeper INT8 codes"
     g6, w6 = t2n(got[1])[:, :M], t2n(want[1])[:, :M]
