@@ -24,6 +24,7 @@ QUANT_F6_CODES = 0x200     # ATOM_QUANT_F6_CODES
 AB_F6 = 0x200              # ATOM_AB_F6
 O4_REF_EXTREMA = 0x800     # ATOM_O4_REF_EXTREMA
 B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
+WS_WEIGHT_CACHED = 0x1000  # ATOM_WS_WEIGHT_CACHED: the workspace already holds this weight's F6 form
 F6_PITCH = 104
 
 _vp = ctypes.c_void_p
@@ -38,6 +39,7 @@ SIGNATURES = {
     "atom_scale_size": (ctypes.c_size_t, [_i64, _int]),
     "atom_gemm_w4a4_f16": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
+    "atom_gemm_w4a4_ws_recodes": (_int, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_o4": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_o4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),

@@ -151,7 +151,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
   const int f6 = (scale_layout & ATOM_AB_F6) != 0, f6s = (scale_layout & ATOM_B_F6S) != 0;
   p.o4_ref = (scale_layout & ATOM_O4_REF_EXTREMA) != 0;    // (only the _o4 entry points look at it)
-  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA);
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA | ATOM_WS_WEIGHT_CACHED);
   if ((a_wide && f6) || (f6s && !f6)) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
@@ -206,6 +206,11 @@ static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;
 }
 
+int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total) {
+  if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  return f6_route(M, N, K_total) ? 1 : 0;
+}
+
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   if (f6_route(M, N, K_total)) return f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;   // B: + float32 scales
@@ -227,9 +232,15 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   p.D = (half_t *)D;
   if (!p.a_wide && !p.f6_rows_a && f6_route(M, N, K_total)) {        // packed operands -> F6 copies in the workspace
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    uint8_t *a6 = (uint8_t *)workspace, *b6 = a6 + f6_bytes(M, K_total);
+    // layout: weight records, their float32 scales, then the activation records -- the weight region does not move with M, so a
+    // weight re-coded once serves later calls of any batch size (ATOM_WS_WEIGHT_CACHED)
+    uint8_t *b6 = (uint8_t *)workspace;
     float *sb32 = reinterpret_cast<float *>(b6 + f6_bytes(N, K_total));
-    const int r = launch_repack_f6_pair(p.A4, M, p.sA, p.ldA, p.ref_layout, a6, p.sB, sb32, p.B4, N, b6, p.K4h, p.G, hs);
+    uint8_t *a6 = b6 + f6_bytes(N, K_total) / 104 * 108;
+    // ATOM_WS_WEIGHT_CACHED: b6 / sb32 hold this weight's F6 form since an earlier call (the caller's assertion): activation only
+    const int r = (scale_layout & ATOM_WS_WEIGHT_CACHED)
+                      ? launch_repack_f6(p.A4, M, p.K4h, p.G, p.sA, p.ldA, p.ref_layout, a6, hs)
+                      : launch_repack_f6_pair(p.A4, M, p.sA, p.ldA, p.ref_layout, a6, p.sB, sb32, p.B4, N, b6, p.K4h, p.G, hs);
     if (r != ATOM_OK) return r;
     p.A4 = a6; p.B4 = b6;
     p.f6_rows_a = (M + 255) / 256 * 256;

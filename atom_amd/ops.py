@@ -154,15 +154,20 @@ def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="k
 
 
 _WS = {}
-_WS_RETIRED = []      # buffers replaced during a graph capture: launches captured earlier still point at them
+_WS_RETIRED = []               # buffers replaced during a graph capture: launches captured earlier still point at them
+_WS_WEIGHT = {}                # (device, stream) -> identity of the weight whose F6 form the workspace starts with
 
 
-def _workspace(device, nbytes):
+def _workspace(device, nbytes, weight_key=None):
     """Scratch for split-K partial sums / re-coded operands / decode partials, per (device, stream): calls on one stream reuse it
     in stream order; calls on different streams never share a buffer.  Grown on demand (the old buffer is returned to the caching
     allocator, which keeps it alive for work already queued on its stream).  During HIP-graph capture a too small buffer is not
     freed -- launches captured earlier (also of an earlier graph captured on the same stream) reference it -- but retired, and
-    the new one comes out of the capturing graph's memory pool like every other tensor allocated during capture."""
+    the new one comes out of the capturing graph's memory pool like every other tensor allocated during capture.
+    ``weight_key``: identity of the weight whose re-coded (F6) form this call leaves at the start of the buffer (the re-coding route
+    of atom_gemm_w4a4_f16_ws); the buffer remembers it, and the next call with the same key on the same buffer gets ``cached`` =
+    True (ATOM_WS_WEIGHT_CACHED: only the activation is re-coded).  Every other use of the buffer forgets the key.
+    Returns (buffer, cached)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
@@ -170,7 +175,10 @@ def _workspace(device, nbytes):
             _WS_RETIRED.append(t)
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = t
-    return t
+        _WS_WEIGHT.pop(key, None)
+    cached = weight_key is not None and _WS_WEIGHT.get(key) == weight_key
+    _WS_WEIGHT[key] = weight_key
+    return t, cached
 
 
 def _gemm_dims(a, b, a_keeper, a_wide=False, b_keeper=None):
@@ -198,12 +206,18 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     # > 0 for skinny shapes that gain from split-K, and for packed operands of prefill size (re-coded to F6 in the workspace);
     # operands that are F6 already need none (the F6 kernels take no workspace)
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide == "f6" or (a_wide and m >= 2048)) else 0
-    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    # packed operands on the re-coding route: the weight's F6 form stays at the start of the workspace; a repeat call with the same
+    # weight (same storage, same version counters) on the same workspace re-codes the activation only
+    wkey = None
+    if ws_bytes and not a_wide and lib.atom_gemm_w4a4_ws_recodes(m, n, k):
+        wkey = (b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k)
+    ws, cached = _workspace(a.device, ws_bytes, wkey) if ws_bytes else (None, False)
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
                                    _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0))
-                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0),
+                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0)
+                                   | (L.WS_WEIGHT_CACHED if cached else 0),
                                    L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
@@ -223,7 +237,7 @@ def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_
     d_scale = torch.empty((m, n // 128 * 2), dtype=torch.float16, device=a.device)
     lib = L.lib()
     ws_bytes = lib.atom_gemm_w4a4_o4_workspace_bytes(m, n, k) if use_workspace else 0
-    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
+    ws = _workspace(a.device, ws_bytes)[0] if ws_bytes else None
     st = lib.atom_gemm_w4a4_o4_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                   a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                   b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
@@ -357,7 +371,7 @@ def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 
     lib = L.lib()
     max_pages = int(getattr(kv, "max_pages", 0))
     ws_bytes = lib.atom_batch_decode_i4_workspace_bytes(batch, num_heads, page_size, max_pages)
-    ws = _workspace(q.device, ws_bytes) if ws_bytes else None
+    ws = _workspace(q.device, ws_bytes)[0] if ws_bytes else None
     st = lib.atom_batch_decode_i4(o.data_ptr(), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
                                   kv.indptr.data_ptr(), kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), batch,
                                   num_layers, int(layer_idx), num_heads, page_size, head_dim, float(rope_theta),

@@ -117,8 +117,10 @@ def aggregate(world, steps, wall_s, kern_ms, M, N, K):
 
 def measured_traffic(M, N, K, fmt):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN/bench_hbm_traffic*.json), or None."""
+    (profiles/rNN/bench_hbm_traffic*.json) -- only from a pass taken on the kernel sources of THIS tree
+    (kernel_source_sha256 in the file, written by tools/summarize_profile.py), else None."""
     best = None
+    sha = kernel_source_sha()
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
         for d in sorted(os.listdir(pdir)):
@@ -127,7 +129,7 @@ def measured_traffic(M, N, K, fmt):
                 if os.path.isfile(f):
                     t = json.load(open(f))
                     if t.get("algorithmic_bytes_per_launch") == algorithmic_bytes(M, N, K) and \
-                            t.get("operand_format", "packed") == fmt:
+                            t.get("operand_format", "packed") == fmt and t.get("kernel_source_sha256") == sha:
                         best = int(t["traffic_bytes_per_launch"])
     return best
 
@@ -152,6 +154,38 @@ def build_f6_operands(ops_, M, N, K, dev):
     a6[:, :M, 100:104] = ops_[2].float().reshape(G, M, 1).view(torch.uint8).reshape(G, M, 4)   # ... and the same value as fp32
     b6 = aops.repack_weight_f6(ops_[1].view(torch.uint8), ops_[3])                         # codes + float32 scales (ATOM_B_F6S)
     return a6, b6
+
+
+def cold_launches(step, dev, n=30, flush_mb=512):
+    """The reference's second methodology (kernels/baselines/python-api.ipynb:33-56: one event pair per launch, an L2-sized memset
+    between launches), sized for this chip: 512 MB zero-filled between launches evicts the 32 MB of L2 AND the 256 MB Infinity
+    Cache, so every operand byte of the timed launch comes from HBM.  Returns (mean us, median us, n)."""
+    flush = torch.empty(flush_mb << 20, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = []
+    for i in range(n + 3):
+        flush.zero_()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        step()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        if i >= 3:
+            times.append(e0.elapsed_time(e1) * 1e3)
+    del flush
+    return float(np.mean(times)), float(np.median(times)), len(times)
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: a committed PMC pass is quoted only for the sources it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "atom_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def spawn_ranks(n, argv):
@@ -336,18 +370,21 @@ def main():
                "both operands BF6 group-major (ATOM_AB_F6): v_mfma_f32_16x16x128_f8f6f4, exact integer dot products; the "
                "format the fused quantisers emit for prefill batches"),
         "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
-                      "reference packed format through atom_gemm_w4a4_f16_ws: both operands re-coded to BF6 in the caller's "
-                      "workspace (one launch), then the BF6 MFMA kernel; what atom_amd.ops does for packed operands"),
+                      "reference packed format through atom_gemm_w4a4_f16_ws: the activation is re-coded to BF6 in the caller's workspace "
+                      "by every call, the (static) weight by the first call only (ATOM_WS_WEIGHT_CACHED afterwards), then the BF6 "
+                      "MFMA kernel; what atom_amd.ops does for packed operands"),
     }
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    ws_state = {"flag": 0}
 
     def make_step(name):
         vp, layout, _ = variants[name]
 
         def step():
-            if name == "packed_ws":
-                st = lib.atom_gemm_w4a4_f16_ws(*vp, D.data_ptr(), M, N, K, 128, 128, layout, ws.data_ptr(), ws_bytes, stream)
+            if name == "packed_ws":                              # (the weight is static: re-coded by the first call, then cached)
+                st = lib.atom_gemm_w4a4_f16_ws(*vp, D.data_ptr(), M, N, K, 128, 128, layout | ws_state["flag"], ws.data_ptr(), ws_bytes, stream)
+                ws_state["flag"] = L.WS_WEIGHT_CACHED if lib.atom_gemm_w4a4_ws_recodes(M, N, K) else 0
             else:
                 st = lib.atom_gemm_w4a4_f16(*vp, D.data_ptr(), M, N, K, 128, 128, layout, stream)
             if st != 0:
@@ -365,9 +402,19 @@ def main():
         timed_steps(step, 2, 0, sync, dist, dev)  # synchronize / barrier of the process): 2 more untimed launches, counted in "ramp"
     wall, kern_ms = timed_steps(step, args.steps, args.warmup, sync, dist, dev)
 
-    # N=1 only: the other operand formats beside the headline, and a bit-for-bit comparison of the outputs
+    # N=1 only: the headline kernel with every operand byte coming from HBM ("additionally reported with a 512 MB flush
+    # buffer"), then the other operand formats beside the headline, and a bit-for-bit comparison of the outputs
     others = {}
+    cold = None
     if world == 1:
+        c_mean, c_med, c_n = cold_launches(step, dev)
+        cold = {"kernel_us": round(c_mean, 2), "median_us": round(c_med, 2), "launches": c_n,
+                "value": round(2.0 * M * N * K / (c_mean * 1e-6) / 1e12, 2), "unit": "TOPS",
+                "frac": round(2.0 * M * N * K / (c_mean * 1e-6) / 1e12 / PEAK_I8_TOPS, 4),
+                "method": "one event pair per launch, 512 MB zero-filled between launches (L2 32 MB + Infinity Cache 256 MB evicted; "
+                          "kernels/baselines/python-api.ipynb:33-56 scaled to this chip); the launch starts from an idle, flushed chip"}
+        for _ in range(200):                                     # back to the sustained state for the side measurements
+            step()
         D_head = D.clone()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for name in variants:
@@ -418,12 +465,15 @@ def main():
             "gbps": round(agg["gbps"], 1),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_I8_TOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_I8_TOPS, 4), "traffic": measured_traffic(M, N, K, args.format),
-                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
-                                         "(profiles/rNN/bench_hbm_traffic_*.json), not measured in this run",
+                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command on these kernel "
+                                         "sources (profiles/rNN/bench_hbm_traffic_*.json; null when no pass of the same sources is "
+                                         "committed), not measured in this run",
                          "kernel_us": round(kern_ms * 1e3, 2),
                          "algorithmic_bytes": algorithmic_bytes(M, N, K), "algorithmic_ops": int(ops_per_step),
                          "peak_note": "dense INT8 MFMA peak (BASELINE.md); the BF6 MFMA this format runs on peaks at ~10 POPS"},
         }
+        if cold is not None:
+            out["cold"] = cold
         if others:
             out["other_operand_formats"] = others
             if "packed_ws" in others:                            # what a punica.ops caller (the reference's operand ABI) gets

@@ -98,6 +98,12 @@ int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
  * (its consumer de-quantises code * scale - zero, flashinfer/quantization.cuh:59-84); the default implements the intended
  * min / max.  Opt-in, for bit-comparisons against a reference run. */
 #define ATOM_O4_REF_EXTREMA 0x800
+/* atom_gemm_w4a4_f16_ws with PACKED operands on its re-coding route (use (2) below) only: the weight region of `workspace` already
+ * holds the F6 form of exactly these B4 / sB (N, K_total) -- written by an earlier call with the same workspace and weight (the
+ * weight of a layer is static) -- so only the activation is re-coded: 5 instead of 10 us of re-coding at 4096^3.  The library keeps no
+ * state: the CALLER asserts it (atom_amd.ops tracks which weight its workspace holds).  Wrong flag = wrong results, never a fault
+ * (the region is inside the workspace either way).  Ignored on every other route. */
+#define ATOM_WS_WEIGHT_CACHED 0x1000
 #define ATOM_F6_PITCH 104
 
 const char *atom_version(void);
@@ -136,6 +142,9 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
  * FP32 summation order differs from the unsplit kernel (per-split partial sums, then their sum): same tolerance.
  */
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total);
+/* 1 when atom_gemm_w4a4_f16_ws takes use (2) for packed operands of this shape (the workspace then starts with the re-coded weight:
+ * F6 records + float32 scales, atom_f6_weight_bytes(N, K_total) bytes, whatever M is -- what ATOM_WS_WEIGHT_CACHED refers to) */
+int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total);
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB,
                           const void *A8, const void *B8, const void *sA8, const void *sB8,
                           void *D, int64_t M, int64_t N, int64_t K_total,

@@ -505,3 +505,46 @@ def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
                              d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order if order > 1 else 1)
         assert np.array_equal(bits16(t2n(out)[rows]), bits16(want)), (M, N, K, f6s, order)
     assert seen == {1, 2, 4}
+
+
+def test_packed_route_weight_cached_in_workspace():
+    """ATOM_WS_WEIGHT_CACHED: on the re-coding route of atom_gemm_w4a4_f16_ws (packed operands of prefill size) the weight's F6 form
+    stays at the start of the caller's workspace; atom_amd.ops passes the flag when the same weight (storage + version counters)
+    meets the same workspace again.  Results must not depend on it: repeat calls, another batch size, another weight in between, and a
+    weight rewritten in place all give the bits of a fresh workspace."""
+    from atom_amd import ops
+    lib = ops.L.lib()
+    N, K = 2048, 1152
+    d1 = rand_gemm_operands(1024, N, K, seed=11)
+    d2 = rand_gemm_operands(1024, N, K, seed=12)
+    assert lib.atom_gemm_w4a4_ws_recodes(1024, N, K) == 1 and lib.atom_gemm_w4a4_ws_recodes(256, N, K) == 0
+    dev1, dev2 = to_device(d1, "plain"), to_device(d2, "plain")
+
+    def fresh(dev):
+        ops._WS.clear(); ops._WS_WEIGHT.clear()
+        return ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")
+    want1, want2 = fresh(dev1), fresh(dev2)
+    ops._WS.clear(); ops._WS_WEIGHT.clear()
+    key = lambda: next(iter(ops._WS_WEIGHT.values()))
+    y = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
+    k1 = key()
+    assert k1 is not None and torch.equal(y, want1)
+    y = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")            # cached: activation re-coded only
+    assert key() == k1 and torch.equal(y, want1)
+    # same weight, other activations and another batch size (the weight region does not move with M)
+    mixed = [dev2[0][:800], dev1[1], dev2[2][:, :800].contiguous(), dev1[3], dev2[4][:800], dev1[5], dev2[6][:800], dev1[7]]
+    y = ops.dense_layer_gemm_i4_fp16(*mixed, scale_layout="plain")
+    ops._WS.clear(); ops._WS_WEIGHT.clear()
+    assert torch.equal(y, ops.dense_layer_gemm_i4_fp16(*mixed, scale_layout="plain"))
+    # another weight in between, a split-K call in between (partials over the weight region), then the first weight again
+    ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev2, scale_layout="plain"), want2)
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1)
+    small = [dev1[0][:300], dev1[1], dev1[2][:, :300].contiguous(), dev1[3], dev1[4][:300], dev1[5], dev1[6][:300], dev1[7]]
+    ops.dense_layer_gemm_i4_fp16(*small, scale_layout="plain")
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1)
+    # the weight rewritten IN PLACE: the version counter changes, the cache entry does not match
+    dev1[1].copy_(dev2[1]); dev1[3].copy_(dev2[3]); dev1[5].copy_(dev2[5]); dev1[7].copy_(dev2[7])
+    got = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
+    ops._WS.clear(); ops._WS_WEIGHT.clear()
+    assert torch.equal(got, ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"))

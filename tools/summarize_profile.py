@@ -14,6 +14,12 @@ KERNELS = {"f6": "gemm_w4a4_f6q_kernel", "packed": "Cfg<256, 128, 3, 4, false>",
 ALGO_BYTES = 51380224       # SURVEY 8(d), M=N=K=4096
 
 
+def kernel_source_sha():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_source_sha()
+
+
 def main(raw, out):
     os.makedirs(out, exist_ok=True)
     stats = glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -44,6 +50,7 @@ def main(raw, out):
                 "correction": "gfx950 rocprofv3 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads "
                               "(MI355X_MICROARCH.md, HBM section): doubled; WRITE_SIZE taken as is",
                 "traffic_bytes_per_launch": int(round(2 * fetch_kib * 1024 + write_kib * 1024)),
+                "kernel_source_sha256": kernel_source_sha(),
                 "algorithmic_bytes_per_launch": ALGO_BYTES}, open(os.path.join(out, f"bench_hbm_traffic_{fmt}.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(out)))
 
