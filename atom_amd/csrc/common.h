@@ -85,6 +85,11 @@ struct GemmParams {
   int o4_ref;                     // ATOM_O4_REF_EXTREMA: the u4 epilogue with the reference code's |x| extrema and 4-bit wrap
   GateUpOut gu;                   // fused gate/up epilogue (launch_gemm_f6_gateup only)
   const float *sB32;              // ATOM_SB_F32: weight scales float32 [G][f6_rows_b] (then sB is not read by the 256x256 kernel)
+  // atom_gemm_w4a4_multi (decode batches): the N output features are nseg segments of seg_n, each with its own [M, seg_n] output
+  void *seg_out[3];               // fp16, or float32 where the segment's bit of seg_f32 is set
+  const half_t *seg_add;          // optional fp16 [M, seg_n] added to segment 0's fp16 output (the residual stream)
+  int seg_n;
+  unsigned seg_f32;
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
@@ -94,6 +99,7 @@ int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.
 int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_skinny.hip (decode batches, M <= 256)
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
+int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmented outputs (p.seg_*): q/k/v, gate/up, down + residual
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s);   // ... 256x256 kernel + fused SiLU x up -> quant epilogue
 

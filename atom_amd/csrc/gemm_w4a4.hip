@@ -293,6 +293,31 @@ int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const voi
   return launch_gemm_skinny_f32(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+int atom_gemm_w4a4_multi_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total) {
+  if (M < 1 || nseg < 1 || nseg > 3 || N_seg < 16 || (N_seg % 16) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  return skinny_fits(M, N_seg * nseg, K_total) && (K_total - kKeeper) / kGroup + 1 <= 8 * 14 ? 1 : 0;
+}
+
+int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                         const void *sA8, const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask,
+                         const void *add0_f16, int64_t M, int64_t N_seg, int nseg, int64_t K_total, int group, int keeper,
+                         int scale_layout, void *stream) {
+  if (nseg < 1 || nseg > 3 || !out0 || (nseg > 1 && !out1) || (nseg > 2 && !out2)) return ATOM_ERR_INVALID_ARG;
+  if (scale_layout & (ATOM_A_WIDE | ATOM_AB_F6)) return ATOM_ERR_INVALID_ARG;
+  if (N_seg < 16 || (N_seg % 16) != 0) return ATOM_ERR_SHAPE;
+  if ((f32_mask & 1u) && add0_f16) return ATOM_ERR_INVALID_ARG;      // the addend goes with an fp16 segment 0
+  GemmParams p;
+  const int st = fill_params(p, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N_seg * nseg, K_total, group, keeper, scale_layout);
+  if (st != ATOM_OK) return st;
+  if (!atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total)) return ATOM_ERR_SHAPE;
+  if (!aligned16(out0) || (out1 && !aligned16(out1)) || (out2 && !aligned16(out2)) || (add0_f16 && !aligned16(add0_f16))) return ATOM_ERR_ALIGN;
+  p.seg_out[0] = out0; p.seg_out[1] = out1; p.seg_out[2] = out2;
+  p.seg_add = (const half_t *)add0_f16;
+  p.seg_n = (int)N_seg;
+  p.seg_f32 = f32_mask;
+  return launch_gemm_skinny_multi(p, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t atom_gemm_w4a4_o4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 128 || (N % 128) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   return skinny_fits(M, N, K_total) ? (size_t)M * (size_t)N * sizeof(float) : 0;

@@ -44,8 +44,11 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 }
 
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
-template <int NW, int MBLK, int CNT, bool OUT32 = false>   // OUT32: FP32 sums to p.ws [M, N] (the u4-epilogue path)
+// OUT: 0 = fp16 D [M, N]; 1 = FP32 sums to p.ws [M, N] (the u4-epilogue path); 2 = segmented (atom_gemm_w4a4_multi): the features are
+// p.N / p.seg_n segments with their own [M, seg_n] outputs, fp16 or float32 per segment, segment 0 optionally + an fp16 addend
+template <int NW, int MBLK, int CNT, int OUT = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
+  constexpr bool OUT32 = OUT == 1;
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]
   float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw);
   const int lane = threadIdx.x & 63;
@@ -159,7 +162,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       s = v4f{s[0] + q[0], s[1] + q[1], s[2] + q[2], s[3] + q[3]};
     }
     const int m = tb * 16 + row;
-    if (m < p.M && OUT32) {
+    if constexpr (OUT == 2) {
+      if (m < p.M) {
+        const int seg = n0 / p.seg_n, nl = n0 - seg * p.seg_n + 4 * kb;       // wave-uniform segment (seg_n is a multiple of 16)
+        void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+        if ((p.seg_f32 >> seg) & 1u) {
+          *reinterpret_cast<v4f *>(reinterpret_cast<float *>(out) + (int64_t)m * p.seg_n + nl) = s;
+        } else {
+          v2u o;
+          half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = f2h(s[r]);
+          if (seg == 0 && p.seg_add) {                   // fp16 + fp16 as torch adds halves: one FP32 addition, one rounding
+            const v2u a = *reinterpret_cast<const v2u *>(p.seg_add + (int64_t)m * p.seg_n + nl);
+            const half_t *av = reinterpret_cast<const half_t *>(&a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = f2h((float)ov[r] + (float)av[r]);
+          }
+          *reinterpret_cast<v2u *>(reinterpret_cast<half_t *>(out) + (int64_t)m * p.seg_n + nl) = o;
+        }
+      }
+    } else if (m < p.M && OUT32) {
       *reinterpret_cast<v4f *>(p.ws + (int64_t)m * p.N + n0 + 4 * kb) = s;
     } else if (m < p.M) {
       v2u o;
@@ -171,29 +194,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   }
 }
 
-template <int NW, int MBLK, int CNT, bool OUT32 = false>
+template <int NW, int MBLK, int CNT, int OUT = 0>
 static int launch(const GemmParams &p, hipStream_t s) {
   constexpr size_t lds = (size_t)NW * MBLK * 64 * 16;
   if constexpr (lds > 64 * 1024) {
     static std::atomic<uint64_t> attr_done{0};
-    if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>), (int)lds, attr_done) != ATOM_OK)
+    if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT>), (int)lds, attr_done) != ATOM_OK)
       return ATOM_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT32>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
 
-template <int NW, int CNT, bool OUT32 = false>
+template <int NW, int CNT, int OUT = 0>
 static int launch_m(const GemmParams &p, hipStream_t s) {
   const int mblk = (p.M + 15) / 16;
-  if (mblk <= 1) return launch<NW, 1, CNT, OUT32>(p, s);
+  if (mblk <= 1) return launch<NW, 1, CNT, OUT>(p, s);
   if constexpr (!(NW == 8 && CNT == 14)) {              // (that instance spills 14 VGPRs; the 4-block one does not)
-    if (mblk <= 2) return launch<NW, 2, CNT, OUT32>(p, s);
+    if (mblk <= 2) return launch<NW, 2, CNT, OUT>(p, s);
   }
-  if (mblk <= 4) return launch<NW, 4, CNT, OUT32>(p, s);
+  if (mblk <= 4) return launch<NW, 4, CNT, OUT>(p, s);
   if constexpr (CNT <= 8) {
-    if (mblk <= 8) return launch<NW, 8, CNT, OUT32>(p, s);
-    if (mblk <= 16) return launch<NW, 16, CNT, OUT32>(p, s);
+    if (mblk <= 8) return launch<NW, 8, CNT, OUT>(p, s);
+    if (mblk <= 16) return launch<NW, 16, CNT, OUT>(p, s);
   }
   return ATOM_ERR_SHAPE;
 }
@@ -250,8 +273,22 @@ int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
   const int per = (p.G + 1 + 7) / 8;
   if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
-  return per <= 4 ? skinny::launch_m<8, 4, true>(p, s)
-                  : (per <= 8 ? skinny::launch_m<8, 8, true>(p, s) : skinny::launch_m<8, 14, true>(p, s));
+  return per <= 4 ? skinny::launch_m<8, 4, 1>(p, s)
+                  : (per <= 8 ? skinny::launch_m<8, 8, 1>(p, s) : skinny::launch_m<8, 14, 1>(p, s));
+}
+
+// Segmented outputs (atom_gemm_w4a4_multi): one launch for the projections that share an activation operand -- q / k / v, gate / up
+// -- or for one projection + the residual add.  Per-feature arithmetic and summation order are those of launch_gemm_skinny /
+// launch_gemm_skinny_f32 (a workgroup owns 16 features of ONE segment): bit-identical to the separate launches.
+int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s) {
+  if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0 || p.seg_n < 16 || (p.seg_n % 16) != 0 || (p.N % p.seg_n) != 0 ||
+      p.N / p.seg_n > 3)
+    return ATOM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
+  const int per = (p.G + 1 + 7) / 8;
+  if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
+  return per <= 4 ? skinny::launch_m<8, 4, 2>(p, s)
+                  : (per <= 8 ? skinny::launch_m<8, 8, 2>(p, s) : skinny::launch_m<8, 14, 2>(p, s));
 }
 
 // Decode path of the u4-output GEMM: the FP32 sums into the caller's workspace, then the u4 epilogue as a second launch

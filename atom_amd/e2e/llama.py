@@ -19,6 +19,7 @@ GROUP = 128
 
 
 _FUSED_KV_APPEND = os.environ.get("ATOM_FUSED_KV_APPEND", "1") != "0"   # 0: the reference's op sequence in decode steps too
+_FUSED_DECODE = os.environ.get("ATOM_FUSED_DECODE", "1") != "0"         # 0: one launch per projection in decode steps (round 2)
 
 
 class LinearInt4(nn.Module):
@@ -84,6 +85,21 @@ class LinearInt4(nn.Module):
         return f(norms, self.weight_int4, norm_scales, self.scale_int4, outlier, self.weight_int8, outlier_scales,
                  self.scale_int8)
 
+    def forward_add(self, input, residual):
+        """residual + forward(input): decode batches run the add inside the projection's launch (same bits as the torch add)."""
+        outlier, norms, outlier_scales, norm_scales = input
+        rows = outlier.size(0)
+        if (norms.dim() == 2 and self.out_dtype == "fp16" and _FUSED_DECODE and residual.is_contiguous()
+                and ops.multi_gemm_fits(rows, self.out_features, 1, self.in_features)):
+            key = ops.fused_key([self])
+            if getattr(self, "_single", None) is None or self._single["key"] != key:
+                b4, b8, sb, sb8 = self.packed()
+                self._single = {"b4": b4.view(torch.uint8), "b8": b8, "sb": sb.contiguous(), "sb8": sb8.contiguous(), "n_seg": self.out_features,
+                                "nseg": 1, "k": self.in_features, "key": key}
+            return ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self._single,
+                                                 add=residual.view(rows, self.out_features))[0].view(residual.shape)
+        return residual + self.forward(input)
+
     def forward_f32(self, input):
         """FP32 sums (decode batches only): what the "int4" epilogue would quantise; see LlamaAttention.forward."""
         outlier, norms, outlier_scales, norm_scales = input
@@ -130,18 +146,33 @@ class LlamaMLP(nn.Module):
             self._fused = (key, ops.fuse_gate_up_weights(self.gate_proj.packed(), self.up_proj.packed()))
         return self._fused[1]
 
-    def forward(self, x):
+    def _decode_gate_up(self):
+        """gate_proj + up_proj as one operand of dense_layer_gemm_i4_multi (decode batches)."""
+        mods = [self.gate_proj, self.up_proj]
+        if getattr(self, "_gu", None) is None or self._gu["key"] != ops.fused_key(mods):
+            self._gu = ops.fuse_projection_weights(mods)
+            self._fused = None                                   # (the prefill operand is keyed by the parameters' storage too)
+        return self._gu
+
+    def forward(self, x, residual=None):
+        """``residual`` (decode layers pass it): returns residual + mlp(x), the add inside down_proj's launch for decode batches."""
         outlier, norms, outlier_scales, norm_scales = x
-        if (outlier.size(0) >= self.FUSED_MIN_ROWS and self.intermediate_size % GROUP == 0
-                and ops.L.lib().atom_gemm_w4a4_f6_order(outlier.size(0), self.intermediate_size, self.hidden_size) == 1):
+        rows = outlier.size(0)
+        down = (lambda a: self.down_proj(a)) if residual is None else (lambda a: self.down_proj.forward_add(a, residual))
+        if (rows >= self.FUSED_MIN_ROWS and self.intermediate_size % GROUP == 0
+                and ops.L.lib().atom_gemm_w4a4_f6_order(rows, self.intermediate_size, self.hidden_size) == 1):
             # prefill batches: gate_proj + up_proj + activate_fp16_i4 in ONE launch (SURVEY 8(f) N4), bit-identical to the three
             # launches below wherever those sum the K steps in order too (atom_gemm_w4a4_f6_order == 1: every shape that fills the
             # chip; few-tile shapes keep the three launches so that the output does not depend on the route);
             # the activation is re-coded to the F6 operand once (the two GEMMs would each do it in their workspace)
             a6 = norms if norms.dim() == 3 else ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
             act = ops.gate_up_silu_quant_f6(a6, outlier, outlier_scales, self._fused_gate_up())
-            return self.down_proj(act)
-        return self.down_proj(ops.activate_fp16_i4(self.gate_proj(x), self.up_proj(x)))
+            return down(act)
+        if norms.dim() == 2 and _FUSED_DECODE and ops.multi_gemm_fits(rows, self.intermediate_size, 2, self.hidden_size):
+            # decode batches: gate_proj and up_proj in one launch (they read the same activation operand)
+            gate, up = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self._decode_gate_up())
+            return down(ops.activate_fp16_i4(gate, up))
+        return down(ops.activate_fp16_i4(self.gate_proj(x), self.up_proj(x)))
 
 
 def dequant_kv_u4(packed: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
@@ -189,18 +220,33 @@ class LlamaAttention(nn.Module):
         self.reorder_index = nn.Parameter(torch.randperm(self.hidden_size).to(torch.int16), requires_grad=False)
         self.rope_theta = float(getattr(config, "rope_theta", 1e4))
 
+    def _decode_qkv(self):
+        """q_proj + k_proj + v_proj as one operand of dense_layer_gemm_i4_multi (decode steps)."""
+        mods = [self.q_proj, self.k_proj, self.v_proj]
+        if getattr(self, "_qkv", None) is None or self._qkv["key"] != ops.fused_key(mods):
+            self._qkv = ops.fuse_projection_weights(mods)
+        return self._qkv
+
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv: BatchedKvCacheInt4 | None,
                 decode_kv: BatchedKvCacheInt4 | None) -> torch.Tensor:
-        q_proj = self.q_proj(hidden_states)
         nh, hd = self.num_heads, self.head_dim
         rows = hidden_states[0].size(0)
-        if (len(blen.prefills) == 0 and blen.decode == rows and _FUSED_KV_APPEND
-                and ops.decode_gemm_fits(rows, self.hidden_size, self.hidden_size)):
+        pure_decode = (len(blen.prefills) == 0 and blen.decode == rows and _FUSED_KV_APPEND
+                       and ops.decode_gemm_fits(rows, self.hidden_size, self.hidden_size))
+        fuse_qkv = (pure_decode and _FUSED_DECODE and hidden_states[1].dim() == 2
+                    and ops.multi_gemm_fits(rows, self.hidden_size, 3, self.hidden_size))
+        q_proj = None if fuse_qkv else self.q_proj(hidden_states)
+        if pure_decode:
             # pure decode step: k / v sums in FP32, then ONE launch quantises both per head and writes the cache slots
             # (same cache contents as the u4-epilogue GEMMs + append_kv_i4 below; three launches fewer)
             assert decode_kv is not None
-            ops.quant_append_kv_i4(decode_kv, self.k_proj.forward_f32(hidden_states), self.v_proj.forward_f32(hidden_states),
-                                   self.layer_idx)
+            if q_proj is None:                                   # q / k / v from one launch: q fp16, k and v as FP32 sums
+                outlier, norms, outlier_scales, norm_scales = hidden_states
+                q_proj, k32, v32 = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self._decode_qkv(),
+                                                                 f32_mask=0b110)
+            else:
+                k32, v32 = self.k_proj.forward_f32(hidden_states), self.v_proj.forward_f32(hidden_states)
+            ops.quant_append_kv_i4(decode_kv, k32, v32, self.layer_idx)
             o = ops.batch_decode_i4(q_proj.view(rows, nh, hd), decode_kv, self.layer_idx, rope_theta=self.rope_theta)
             return self.o_proj(ops.reorder_fp16_i4(o.view(rows, self.hidden_size), self.reorder_index))
         k_u4, k_sz = self.k_proj(hidden_states)
@@ -249,4 +295,4 @@ class LlamaDecoderLayer(nn.Module):
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
-        return residual + self.mlp(normed)
+        return self.mlp(normed, residual=residual)                                           # ... and the second one (decode: in down_proj's launch)

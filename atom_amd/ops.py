@@ -266,6 +266,57 @@ def dense_layer_gemm_i4_f32(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper
     return d
 
 
+def fuse_projection_weights(mods):
+    """Offline, once per layer: the packed weights of 2-3 ``LinearInt4`` modules that read the same activation (q / k / v; gate /
+    up) as ONE operand for dense_layer_gemm_i4_multi, concatenated along the output features.  The codes are not duplicated: the
+    modules' ``weight_int4`` / ``weight_int8`` parameters become views of the fused buffers (a later in-place load writes through;
+    a re-assigned parameter changes the key and the operand is rebuilt).  The scales (31 x N halves per projection) are copied.
+    Returns a dict; ``fused_key(mods)`` tells whether it is current."""
+    packs = [m.packed() for m in mods]
+    n = packs[0][0].shape[0]
+    assert all(pk[0].shape == packs[0][0].shape for pk in packs) and n % 16 == 0
+    b4 = torch.cat([pk[0].view(torch.uint8) for pk in packs], 0).contiguous()
+    b8 = torch.cat([pk[1] for pk in packs], 0).contiguous()
+    g = packs[0][2].shape[0]
+    sb = torch.cat([pk[2].reshape(g, n) for pk in packs], 1).contiguous()
+    sb8 = torch.cat([pk[3].reshape(-1) for pk in packs], 0).contiguous()
+    for i, m in enumerate(mods):                                   # the parameters now alias the fused storage
+        m.weight_int4.data = b4[i * n:(i + 1) * n]
+        m.weight_int8.data = b8[i * n:(i + 1) * n]
+    return {"b4": b4, "b8": b8, "sb": sb, "sb8": sb8, "n_seg": n, "nseg": len(mods), "k": b4.shape[1] * 2 + GROUP_SIZE,
+            "key": fused_key(mods)}
+
+
+def fused_key(mods):
+    return tuple((m.weight_int4.data_ptr(), m.weight_int4._version, m.weight_int8.data_ptr(), m.weight_int8._version,
+                  m.scale_int4.data_ptr(), m.scale_int4._version, m.scale_int8.data_ptr(), m.scale_int8._version) for m in mods)
+
+
+def multi_gemm_fits(m: int, n_seg: int, nseg: int, k: int) -> bool:
+    return bool(L.lib().atom_gemm_w4a4_multi_fits(int(m), int(n_seg), int(nseg), int(k)))
+
+
+def dense_layer_gemm_i4_multi(a, a_scale, a_keeper, a_keeper_scale, fused, *, f32_mask=0, add=None, scale_layout="ref"):
+    """NEW (decode batches; no reference counterpart): the projections in ``fused`` (fuse_projection_weights) applied to one
+    activation operand in ONE launch.  Returns a tuple of [M, n_seg] tensors, fp16 or (bits of ``f32_mask``) the FP32 sums;
+    ``add`` (fp16 [M, n_seg]) is added to the first output the way torch adds two half tensors (the residual add).  Bit-identical to
+    dense_layer_gemm_i4_f32 / the decode-batch kernel per projection (+ torch's add)."""
+    m = a.size(0)
+    n, nseg, k = fused["n_seg"], fused["nseg"], fused["k"]
+    assert a.size(1) * 2 + a_keeper.size(1) == k
+    outs = [torch.empty((m, n), dtype=torch.float32 if (f32_mask >> i) & 1 else torch.float16, device=a.device) for i in range(nseg)]
+    if add is not None:
+        _require_cuda_half(add, "add")
+        assert add.shape == (m, n) and add.is_contiguous()
+    st = L.lib().atom_gemm_w4a4_multi(a.data_ptr(), fused["b4"].data_ptr(), a_scale.data_ptr(), fused["sb"].data_ptr(), a_keeper.data_ptr(),
+                                      fused["b8"].data_ptr(), a_keeper_scale.data_ptr(), fused["sb8"].data_ptr(), outs[0].data_ptr(),
+                                      outs[1].data_ptr() if nseg > 1 else None, outs[2].data_ptr() if nseg > 2 else None,
+                                      int(f32_mask), L.ptr(add), m, n, nseg, k, GROUP_SIZE, GROUP_SIZE, _LAYOUTS[scale_layout],
+                                      L.current_stream(a.device))
+    L.check(st, "atom_gemm_w4a4_multi")
+    return tuple(outs)
+
+
 def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: int = 2, return_fake_quant=False):
     """NEW (no reference counterpart): quantise + pack a (column-reordered) FP16 weight [N,K] the
     way QLinearLayer.quant does (qLinearLayer.py:42-78).  Returns (B4 u8[N,K4/2], B8 i8[N,128], sB f16[G,N],

@@ -164,6 +164,23 @@ int atom_gemm_w4a4_o4(const void *A4, const void *B4, const void *sA, const void
                       int group, int keeper, int scale_layout, void *stream);
 
 /*
+ * Decode batches: ONE launch for the projections of a decode step that share an activation operand (no reference counterpart: the
+ * reference launches dense_layer_gemm_i4_fp16 / _o4 once per projection, punica/models/llama.py:85-87 gate / up, :110-119 q / k / v).
+ * B4 / sB / B8 / sB8 hold the `nseg` (1..3) weights concatenated along the output features: B4 [nseg * N_seg, K4/2], sB [G, nseg * N_seg]
+ * flat, B8 [nseg * N_seg, 128], sB8 [nseg * N_seg].  Segment s gets its own output out_s [M, N_seg]: fp16, or the FP32 sums where bit s
+ * of f32_mask is set (k / v ahead of atom_kv_quant_append_f32).  add0_f16 (optional, fp16 [M, N_seg]): added to segment 0's fp16
+ * output as torch adds two half tensors -- half(float(half(c)) + float(add)) -- i.e. the decoder layer's residual add
+ * (llama.py:268-275, :289-291) in the projection's own launch.  Per feature the arithmetic and the summation order are those of
+ * atom_gemm_w4a4_f32 / of the decode-batch kernel behind atom_gemm_w4a4_f16: bit-identical to the separate launches (+ torch's add).
+ * Shapes: atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total) (decode batches; N_seg % 16 == 0); packed operands only.
+ */
+int atom_gemm_w4a4_multi_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total);
+int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,
+                         const void *sA8, const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask,
+                         const void *add0_f16, int64_t M, int64_t N_seg, int nseg, int64_t K_total, int group, int keeper,
+                         int scale_layout, void *stream);
+
+/*
  * Same result contract, with an optional caller-owned scratch buffer for DECODE batches (the k/v projections of a
  * serving step; the shapes the decode-batch GEMM takes, M <= 256 at most).  The plain entry point runs the 256-row
  * tile kernel whatever M is (88 us at M = 16, N = K = 4096); with

@@ -154,3 +154,78 @@ def test_decoder_layer_prefill_then_decode_is_consistent():
         b = torch.cat([pool2.buf[i, 1] for i in c2.indicies], dim=2)[:, :, :c2.seqlen]
         assert torch.equal(a[:, :, :-1], b[:, :, :-1])
         assert (a[:, :, -1] != b[:, :, -1]).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("M,N,K,nseg", [(1, 256, 640, 3), (5, 512, 1152, 2), (16, 4096, 4096, 3), (40, 1408, 640, 2), (64, 4096, 11008, 1),
+                                        (7, 11008, 4096, 2)])
+def test_multi_projection_launch_equals_separate_launches(M, N, K, nseg):
+    """atom_gemm_w4a4_multi (decode batches: q / k / v, gate / up, down + residual in one launch): every segment bit-identical to
+    the decode-batch kernel on that projection alone -- FP32 sums (atom_gemm_w4a4_f32), their fp16 rounding, and the residual add as
+    torch adds two half tensors."""
+    import types
+    from atom_amd import ops
+    from tests.helpers import rand_gemm_operands, to_device
+    assert ops.multi_gemm_fits(M, N, nseg, K)
+    ds = [rand_gemm_operands(M, N, K, seed=31 + i) for i in range(nseg)]
+    devs = [to_device(d, "ref") for d in ds]
+    a = devs[0]                                                   # the shared activation operand: a, a_scale, a_keeper, a_keeper_scale
+    mods = [types.SimpleNamespace(weight_int4=torch.nn.Parameter(dv[1], requires_grad=False), weight_int8=torch.nn.Parameter(dv[5], requires_grad=False),
+                                  scale_int4=torch.nn.Parameter(dv[3], requires_grad=False), scale_int8=torch.nn.Parameter(dv[7], requires_grad=False),
+                                  packed=None) for dv in devs]
+    for md in mods:
+        md.packed = (lambda md=md: (md.weight_int4.data, md.weight_int8.data, md.scale_int4.data, md.scale_int8.data))
+    want32 = [ops.dense_layer_gemm_i4_f32(a[0], dv[1], a[2], dv[3], a[4], dv[5], a[6], dv[7]) for dv in devs]
+    fused = ops.fuse_projection_weights(mods)
+    assert fused["key"] == ops.fused_key(mods)
+    assert all(md.weight_int4.data_ptr() == fused["b4"].data_ptr() + i * N * (K - 128) // 2 for i, md in enumerate(mods))   # views, not copies
+    res = (torch.randn((M, N), device="cuda") * 3).half()
+    mask = 0b110 & ((1 << nseg) - 1)
+    outs = ops.dense_layer_gemm_i4_multi(a[0], a[2], a[4], a[6], fused, f32_mask=mask, add=res)
+    for i in range(nseg):
+        if (mask >> i) & 1:
+            assert outs[i].dtype == torch.float32 and torch.equal(outs[i], want32[i])
+        elif i == 0:
+            assert torch.equal(outs[0], want32[0].half() + res)
+        else:
+            assert torch.equal(outs[i], want32[i].half())
+    outs = ops.dense_layer_gemm_i4_multi(a[0], a[2], a[4], a[6], fused)
+    assert all(torch.equal(o, w.half()) for o, w in zip(outs, want32))
+    if M >= 2:                                                    # (M = 1 goes to the dot-product kernel behind the plain entry point)
+        assert torch.equal(outs[0], ops.dense_layer_gemm_i4_fp16(a[0], devs[0][1], a[2], devs[0][3], a[4], devs[0][5], a[6], devs[0][7]))
+
+
+@pytest.mark.parametrize("bsz", [1, 3, 16])
+def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
+    """A decode step of atom_amd.e2e.LlamaDecoderLayer with the round-3 launch fusions (q / k / v in one launch, gate / up in one
+    launch, the second residual add inside down_proj's launch: 14 -> 10 launches) against the same step with one launch per
+    projection (ATOM_FUSED_DECODE = 0, the reference's call order llama.py:259-292): same cache contents and same output, bit for
+    bit (batch 1: q comes from the decode-batch kernel instead of the dot-product kernel -- another summation order, one fp16 ulp)."""
+    import atom_amd.e2e.llama as E
+    from atom_amd.e2e import LlamaDecoderLayer
+    from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    torch.manual_seed(4)
+    cfg = _attn_cfg()
+    dev = torch.device("cuda")
+    layer = LlamaDecoderLayer(cfg, layer_idx=0).cuda()
+    _load_layer(layer, 7)
+    ctx = 40
+    x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
+    outs, caches = [], []
+    for fused in (False, True):
+        E._FUSED_DECODE = fused
+        pool = KvPoolInt4(num_layers=1, num_heads=4, head_dim=128, capacity=bsz * 4, block_len=16, device=dev)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
+        pool.param.copy_((torch.rand(pool.param.shape, device=dev, generator=g) * 0.05 + 0.01).half())
+        cs = [KvCacheInt4(pool, ctx) for _ in range(bsz)]
+        for c in cs:
+            c.acquire_one()
+        outs.append(layer(x, BatchLenInfo([], bsz, dev), None, BatchedKvCacheInt4(cs)))
+        caches.append((pool.buf.clone(), pool.param.clone()))
+    E._FUSED_DECODE = True
+    if bsz >= 2:
+        assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
+        assert torch.equal(outs[0], outs[1])
+    else:
+        assert (caches[0][0] != caches[1][0]).float().mean().item() == 0        # k / v take the same kernel either way
+        assert (outs[0].float() - outs[1].float()).abs().max().item() <= 0.05 * outs[0].float().abs().max().item()
