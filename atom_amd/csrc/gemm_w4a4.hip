@@ -295,7 +295,9 @@ int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const voi
 
 int atom_gemm_w4a4_multi_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total) {
   if (M < 1 || nseg < 1 || nseg > 3 || N_seg < 16 || (N_seg % 16) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
-  return skinny_fits(M, N_seg * nseg, K_total) && (K_total - kKeeper) / kGroup + 1 <= 8 * 14 ? 1 : 0;
+  const int64_t items = (K_total - kKeeper) / kGroup + 1;
+  if (items > 64 && M > 16) return 0;                      // 14-group slices per wave: one token block (the larger instances spill)
+  return skinny_fits(M, N_seg * nseg, K_total) && items <= 8 * 14 ? 1 : 0;
 }
 
 int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,

@@ -15,6 +15,11 @@
 //   * per group and 16x16 tile: t = round_f32(idot * sA[m,g]), c = fma(t, sB[g,n], c) -- the contract of
 //     include/atom_hip.h; the partial sums of the 8 waves are added in wave order through LDS (the FP32 summation ORDER
 //     therefore differs from the prefill kernels, like the decode kernel's; all are within 1 fp16 ulp of the exact value).
+// Round 3, what did NOT help for 32..256 tokens (profiles/r03_decode.txt): every block of a workgroup requested up front instead of
+// one block ahead, 64-token workgroups over blockIdx.y, weights widened / scales converted once per workgroup instead of per block,
+// the magic-number de-quantisation (2 instead of 3 VALU per element): 64 tokens 5.9-6.7 us against 6.1, 256 tokens 15.4-22.5 against
+// 15.0.  The limiter there is the activation volume -- every 16-feature workgroup re-reads M x K/2 bytes in 64-byte row pieces,
+// 128 MB per launch at 256 tokens -- so the next step is a wider feature tile per workgroup, not a faster block loop.
 // Replaces the M = 16..256 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
 // which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
 #include <cstdlib>
@@ -99,19 +104,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   }
   // ---- token block 0
   v4u a[CNT];
-  half_t sa[CNT];
+  // token scales stay RAW (the 16 loaded bits) until their use: declared as half_t the compiler converts each one to float right
+  // behind its load -- `global_load_ushort; global_load_dwordx4; s_waitcnt vmcnt(1); v_cvt_f32_f16` per group -- i.e. it waits for
+  // everything issued so far before it issues the next group's loads: CNT dependent round trips instead of one (round 2 shipped
+  // that: 0.1-0.2 us of every launch with the operands in L2).  opaque_half() is the use-site conversion the scheduler cannot hoist.
+  unsigned sa[CNT];
   auto load_act = [&](int tb, int j) { a[j] = *reinterpret_cast<const v4u *>(abase + j * 64 + aoff[tb]); };
-  auto load_sa = [&](int tb, int j) { sa[j] = *reinterpret_cast<const half_t *>(sabase + (int64_t)j * p.ldA * 2 + soff[tb]); };
+  auto load_sa = [&](int tb, int j) { sa[j] = *reinterpret_cast<const unsigned short *>(sabase + (int64_t)j * p.ldA * 2 + soff[tb]); };
+  auto opaque_half = [](unsigned raw) {
+    asm volatile("" : "+v"(raw));
+    return (float)__builtin_bit_cast(half_t, (unsigned short)raw);
+  };
 #pragma unroll
   for (int j = 0; j < CNT; ++j)
     if (j < ng) { load_act(0, j); load_sa(0, j); }
   v4u ak[2] = {};
-  half_t sak = (half_t)0;
+  unsigned sak = 0;
   auto load_keeper_act = [&](int tb) {
     const char *kp = reinterpret_cast<const char *>(p.A8) + koff[tb];
     ak[0] = *reinterpret_cast<const v4u *>(kp);
     ak[1] = *reinterpret_cast<const v4u *>(kp + 64);
-    sak = *reinterpret_cast<const half_t *>(reinterpret_cast<const char *>(p.sA8) + soff[tb]);
+    sak = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(p.sA8) + soff[tb]);
   };
   if (keeper) load_keeper_act(0);
 
@@ -133,12 +146,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
         v4i acc = {0, 0, 0, 0};
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, be, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bo, acc, 0, 0, 0);
-        dequant4(acc, (float)sa[j] * (1.0f / 256.0f), sb[j], c[tb]);
+        dequant4(acc, opaque_half(sa[j]) * (1.0f / 256.0f), sb[j], c[tb]);
         if (tb + 1 < MBLK) load_sa(tb + 1, j);
       }
     }
     if (keeper) {                                          // INT8 keeper, last, as two 64-column halves (the contract)
-      const float sa8 = (float)sak;
+      const float sa8 = opaque_half(sak);
 #pragma unroll
       for (int hlf = 0; hlf < 2; ++hlf) {
         v4i acc = {0, 0, 0, 0};
