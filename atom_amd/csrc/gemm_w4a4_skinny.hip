@@ -19,7 +19,13 @@
 // one block ahead, 64-token workgroups over blockIdx.y, weights widened / scales converted once per workgroup instead of per block,
 // the magic-number de-quantisation (2 instead of 3 VALU per element): 64 tokens 5.9-6.7 us against 6.1, 256 tokens 15.4-22.5 against
 // 15.0.  The limiter there is the activation volume -- every 16-feature workgroup re-reads M x K/2 bytes in 64-byte row pieces,
-// 128 MB per launch at 256 tokens -- so the next step is a wider feature tile per workgroup, not a faster block loop.
+// 128 MB per launch at 256 tokens -- or so it seemed: a second version that staged each token block's rows (one contiguous G KiB slab)
+// in LDS by LDS-DMA, double-buffered, one barrier per block, registers independent of M, measured 7.2 / 11.4 / 19.7 us at 64 / 128 /
+// 256 tokens (this kernel: 6.2 / 9.1 / 15.4), and an ablation of THIS kernel at 256 tokens (tools build) reads: full 18.3 us, without
+// the per-block activation loads 18.0, without MFMA + de-quantisation 12.8, without both 10.1, against 3.5 us for one block.  The
+// block loop is bound by what a wave ISSUES per block (widening both operands, the scale loads, address arithmetic: ~170
+// instructions at ~5.5 cycles each with two waves per SIMD), not by memory: the next step for 64+ tokens is a tile kernel whose
+// operands arrive widened (the F6 K-group kernels already take over at 256 rows), not another variant of this loop.
 // Replaces the M = 16..256 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
 // which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
 #include <cstdlib>
