@@ -268,39 +268,44 @@ __device__ __forceinline__ void compute_int4(const char *slot, int wm, int wn, i
   }
 }
 
-// keeper half-step out of LDS (INT8 MFMA, magic-biased accumulator), de-quantised per half
+// The keeper out of LDS (INT8 MFMA, magic-biased accumulator): its two 64-column halves sit in two stage slots and are multiplied
+// in ONE step -- four chained MFMAs per 32x32 tile into one accumulator, one de-quantisation (the contract of include/atom_hip.h; the
+// reference kernel accumulates both keeper k-steps before its dequant too, Dense_layer_gemm_i4_o16.cuh:640-691)
 template <class C>
-__device__ __forceinline__ void compute_keeper(const char *slot, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
+__device__ __forceinline__ void compute_keeper(const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[TN][C::TM][16]) {
   constexpr int TM = C::TM;
   const int l31 = lane & 31, h = lane >> 5;
   const int sw = (l31 >> 2) & 3;
-  const char *pw0 = slot + (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4);
-  const char *pw1 = slot + (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
-  const char *pa0 = slot + (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4);
-  const char *pa1 = slot + (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
+  const int ow0 = (wn * 64 + l31) * 64 + (((0 + h) ^ sw) << 4), ow1 = (wn * 64 + l31) * 64 + (((2 + h) ^ sw) << 4);
+  const int oa0 = (C::BN + wm * C::WM + l31) * 64 + (((0 + h) ^ sw) << 4), oa1 = (C::BN + wm * C::WM + l31) * 64 + (((2 + h) ^ sw) << 4);
   const char *psa = slot + C::KP_SA_OFF + (wm * C::WM + l31) * 4;
   const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * h) * 2;
-  v4i af[TN][2];
+  v4i af[TN][4];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    af[tn][0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw0 + tn * 2048));
-    af[tn][1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw1 + tn * 2048));
+    af[tn][0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + ow0 + tn * 2048));
+    af[tn][1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + ow1 + tn * 2048));
+    af[tn][2] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + ow0 + tn * 2048));
+    af[tn][3] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + ow1 + tn * 2048));
   }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const v4i b0 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa0 + tm * 2048));
-    const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa1 + tm * 2048));
+    const v4i b0 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + oa0 + tm * 2048));
+    const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + oa1 + tm * 2048));
+    const v4i b2 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa0 + tm * 2048));
+    const v4i b3 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa1 + tm * 2048));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + tm * 128);
     const float nms = -kMagic * sa;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       __builtin_amdgcn_sched_barrier(0);
-      // each 64-column half is de-quantised on its own (the contract of include/atom_hip.h): t = round_f32(idot * sA8)
       v16i magic;
 #pragma unroll
       for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
       v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], b0, magic, 0, 0, 0);
       a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][1], b1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][2], b2, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][3], b3, a, 0, 0, 0);
       v2u sbp[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
@@ -346,10 +351,13 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
 
-  // split-K (SK): blockIdx.y owns the K steps [s_begin, nsteps) and writes FP32 partial sums to p.ws
-  const int total_steps = p.G + 2;
-  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
-  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;
+  // K steps: the G int4 groups, then the keeper = G + 1 compute steps; DMA stages: G + 2 (the keeper's two 64-column halves).
+  // split-K (SK): blockIdx.y owns the compute steps [cb, ce) and writes FP32 partial sums to p.ws
+  const int csteps = p.G + 1;
+  const int s_begin = SK ? (int)((int64_t)csteps * blockIdx.y / p.splits) : 0;
+  const int c_end = SK ? (int)((int64_t)csteps * (blockIdx.y + 1) / p.splits) : csteps;
+  const bool has_keeper = c_end == csteps;
+  const int nsteps = c_end + (has_keeper ? 1 : 0);          // DMA stages [s_begin, nsteps)
   auto issue = [&](int step) {
     char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
@@ -385,9 +393,18 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
   for (; step < min(p.G, nsteps); ++step)
     ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_int4<C, ABL>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), nullptr, wave < C::NW / 2)))
   __builtin_amdgcn_s_setprio(0);
-  for (; step < nsteps; ++step)
-    ATOM_F6_STEP(if (!(ABL & 1)) issue(step + NS - 1), (compute_keeper<C>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c)))
 #undef ATOM_F6_STEP
+  if (has_keeper) {                                        // step == G: both halves (stages G, G + 1) in one compute step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NS == 2) {                               // (two-stage ring: the second half only fits once stage G - 1 is read)
+      if (wave < C::NDW) issue_keeper<C>(p, 1, lds + ((p.G + 1) % NS) * C::STAGE_BYTES, wave, lane, m0, n0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    compute_keeper<C>(lds + (p.G % NS) * C::STAGE_BYTES, lds + ((p.G + 1) % NS) * C::STAGE_BYTES, wm, wn, lane, c);
+    ++step;
+  }
   { ATOM_F6_STAMP(0) }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -569,21 +586,23 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
   }
 }
 
-// keeper half-step on v_mfma_i32_16x16x64_i8, same tile layout; each half de-quantised on its own (the contract)
+// the keeper on v_mfma_i32_16x16x64_i8, same tile layout: its two 64-column halves sit in two stage slots and are multiplied in ONE
+// step -- two chained MFMAs per micro-tile, one de-quantisation (the contract)
 template <class C, bool PH = false>
-__device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4]) {
+__device__ __forceinline__ void compute_keeper_x16(const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[4][C::WM / 16][4]) {
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 2) & 3;
-  const char *pw = slot + (wn * 64 + l15) * 64 + ((kb ^ sw) << 4);                     // + fb*16*64
+  const int ow = (wn * 64 + l15) * 64 + ((kb ^ sw) << 4);                              // + fb*16*64
   constexpr int NTB = C::WM / 16;
-  const char *pa = slot + (C::BN + wm * C::WM + l15) * 64 + ((kb ^ sw) << 4);          // + tb*16*64
+  const int oa = (C::BN + wm * C::WM + l15) * 64 + ((kb ^ sw) << 4);                   // + tb*16*64
   const char *psa = slot + C::KP_SA_OFF + (wm * C::WM + l15) * 4;                      // + tb*64
   const char *psb = slot + C::SB_OFF + (wn * 64 + 4 * kb) * 2;
-  v4i af[4];
+  v4i af[4], af1[4];
   v2u sb[4];
 #pragma unroll
   for (int fb = 0; fb < 4; ++fb) {
-    af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + fb * 1024));
+    af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + ow + fb * 1024));
+    af1[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + ow + fb * 1024));
     sb[fb] = *reinterpret_cast<const v2u *>(psb + fb * 32);
   }
 #pragma unroll
@@ -591,12 +610,14 @@ __device__ __forceinline__ void compute_keeper_x16(const char *slot, int wm, int
     if constexpr (PH) {
       if (tb == NTB / 2) __builtin_amdgcn_s_barrier();
     }
-    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + tb * 1024));
+    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + oa + tb * 1024));
+    const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa + tb * 1024));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + tb * 64);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
       v4i a = {0, 0, 0, 0};
       a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[fb], b, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[fb], b1, a, 0, 0, 0);
       const v4f_t f = {(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
       dequant4x(f, sa, sb[fb], c[fb][tb]);
     }
@@ -742,10 +763,14 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
 
-  // split-K (SK): blockIdx.y owns the K steps [s_begin, nsteps) and writes FP32 partial sums to p.ws
-  const int total_steps = p.G + 2;
-  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : (KG > 1 ? total_steps * kg / KG : 0);
-  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : (KG > 1 ? total_steps * (kg + 1) / KG : total_steps);
+  // K steps: the G int4 groups, then the keeper = G + 1 compute steps; DMA stages: G + 2 (the keeper's two 64-column halves).
+  // split-K (SK): blockIdx.y owns the compute steps [s_begin, c_end) and writes FP32 partial sums to p.ws; KG > 1: group kg owns
+  // [csteps kg / KG, csteps (kg + 1) / KG)
+  const int csteps = p.G + 1;
+  const int s_begin = SK ? (int)((int64_t)csteps * blockIdx.y / p.splits) : (KG > 1 ? csteps * kg / KG : 0);
+  const int c_end = SK ? (int)((int64_t)csteps * (blockIdx.y + 1) / p.splits) : (KG > 1 ? csteps * (kg + 1) / KG : csteps);
+  const bool has_keeper = c_end == csteps;
+  const int nsteps = c_end + (has_keeper ? 1 : 0);          // DMA stages [s_begin, nsteps)
   auto issue = [&](int step) {
     char *slot = lds + (step % NS) * C::STAGE_BYTES;
     const int s = min(step, nsteps - 1);
@@ -798,12 +823,16 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
     compute_int4_x16<C, NoDma, PRIO, PH>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c, NoDma(), older);
   }
   __builtin_amdgcn_s_setprio(0);
-  for (; step < nsteps; ++step) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::GLDS * (NS - 2)) : "memory");
+  if (has_keeper) {                                        // step == G: both halves (stages G, G + 1) in one compute step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(step + NS - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_keeper_x16<C, PH>(lds + (step % NS) * C::STAGE_BYTES, wm, wn, lane, c);
+    if constexpr (NS == 2) {                               // two-stage ring: the second half only fits once stage G - 1 is read
+      issue_keeper<C>(p, 1, lds + ((p.G + 1) % NS) * C::STAGE_BYTES, wave, lane, m0, n0);   // (one more barrier: the K groups below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     //  count it in)
+      __builtin_amdgcn_s_barrier();
+    }
+    compute_keeper_x16<C, PH>(lds + (p.G % NS) * C::STAGE_BYTES, lds + ((p.G + 1) % NS) * C::STAGE_BYTES, wm, wn, lane, c);
+    ++step;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -814,8 +843,10 @@ __global__ __launch_bounds__(C::NT * KG, C::OCC) void gemm_w4a4_f6x16_kernel(Gem
     if (kg == 0) __builtin_amdgcn_s_barrier();
   }
   if constexpr (KG > 1) {
-    // one barrier per K step above: the group with the shorter range catches up
-    for (int i = (nsteps - s_begin) * (PH ? 2 : 1); i < (total_steps + KG - 1) / KG * (PH ? 2 : 1); ++i) __builtin_amdgcn_s_barrier();
+    // one barrier per compute step above (two with the half-step phase shift; one more in the keeper's group of a two-stage ring):
+    // the groups with fewer catch up
+    for (int i = (c_end - s_begin) * (PH ? 2 : 1) + (NS == 2 && has_keeper ? 1 : 0); i < (csteps + KG - 1) / KG * (PH ? 2 : 1) + (NS == 2 ? 1 : 0); ++i)
+      __builtin_amdgcn_s_barrier();
     if constexpr (KG == 4) kg4_exchange_store<C>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
     else kg_exchange_store<C, KG>(p, lds_all, c, kg, wave, wm, wn, lane, m0, n0);
     if constexpr (TR) {
@@ -1060,30 +1091,36 @@ __device__ __forceinline__ void p_drain(PRegs<C> &R, float (&c)[4][8][4]) {
     for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[2 + k][r], c[2 + k][7][r]);
 }
 
-// keeper half-step on v_mfma_i32_16x16x64_i8 with the interleaved row mapping; each half de-quantised on its own (the contract)
+// the keeper on v_mfma_i32_16x16x64_i8 with the interleaved row mapping: both 64-column halves (two stage slots) in one step, two
+// chained MFMAs per micro-tile, one de-quantisation (the contract)
 template <class C>
-__device__ __forceinline__ void p_keeper(const char *slot, int wm, int wn, int lane, float (&c)[4][8][4]) {
+__device__ __forceinline__ void p_keeper(const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[4][8][4]) {
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 1) & 3;                                       // swizzle key (row >> 2) & 3 of row 2 * l15 + (blk & 1)
-  const char *pw = slot + (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
-  const char *pa = slot + (C::BN + wm * 128 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const int ow = (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const int oa = (C::BN + wm * 128 + 2 * l15) * 64 + ((kb ^ sw) << 4);
   const char *psa = slot + C::KP_SA_OFF + (wm * 128 + 2 * l15) * 4;
   const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
-  v4i af[4];
+  v4i af[4], af1[4];
   v4u sbp[2];
 #pragma unroll
-  for (int fb = 0; fb < 4; ++fb) af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + p_row(fb) * 64));
+  for (int fb = 0; fb < 4; ++fb) {
+    af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + ow + p_row(fb) * 64));
+    af1[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + ow + p_row(fb) * 64));
+  }
   sbp[0] = *reinterpret_cast<const v4u *>(psb);
   sbp[1] = *reinterpret_cast<const v4u *>(psb + 64);
 #pragma unroll
   for (int tb = 0; tb < 8; ++tb) {
-    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(tb) * 64));
+    const v4i b = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot + oa + p_row(tb) * 64));
+    const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa + p_row(tb) * 64));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + p_row(tb) * 4);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
       __builtin_amdgcn_sched_barrier(0);
       v4i a = {0, 0, 0, 0};
       a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[fb], b, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[fb], b1, a, 0, 0, 0);
       const half_t *hv = reinterpret_cast<const half_t *>(&sbp[fb >> 1]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1215,13 +1252,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
   }
   kstamp(4);
   p_drain<C>(R, c);
-  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
-  if constexpr (!(ABL & 128)) p_keeper<C>(slot_of(G), wm, wn, lane, c);
+  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it: both in ONE step once it has landed
   kstamp(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   kstamp(6);
-  if constexpr (!(ABL & 128)) p_keeper<C>(slot_of(G + 1), wm, wn, lane, c);
+  if constexpr (!(ABL & 128)) p_keeper<C>(slot_of(G), slot_of(G + 1), wm, wn, lane, c);
   kstamp(7);
 
   // epilogue: a lane holds 8 consecutive features per token and feature-block pair -> one 16-byte store each
@@ -1408,20 +1444,25 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
   }
 }
 
-// Keeper half-step of the q kernel, pipelined like q_step (round 3; p_keeper above issued MFMA -> convert -> multiply -> FMA per
-// micro-tile with the MFMA's result latency exposed 32 times per half: 4.2 us of the 4096^3 launch for 1/32 of its work):
-//  * pair slots as in q_step -- the two INT8 MFMAs of slot i are issued before the de-quantisation of slot i - 1;
+// The keeper step of the q kernel (round 3): both 64-column halves (two stage slots) in ONE step, pipelined like q_step.  Round 2 ran
+// two half-steps, each MFMA -> convert -> multiply -> FMA per micro-tile with the MFMA's result latency exposed 32 times and a
+// barrier between the halves: 4.2 us of the 4096^3 launch for 1/32 of its work, and two de-quantisations where the reference kernel
+// does one (Dense_layer_gemm_i4_o16.cuh:640-691).  Now:
+//  * pair slots as in q_step -- the four INT8 MFMAs of slot i (two micro-tiles x two chained halves) are issued before the
+//    de-quantisation of slot i - 1;
 //  * the accumulator starts at the bit pattern of 1.5 * 2^23 (the MFMA's C operand), so that the register read as a float is
 //    12582912 + idot exactly and t = fma(acc, sA8, -12582912 * sA8) IS round_f32(idot * sA8) (the INT8 tile kernel's trick,
 //    gemm_w4a4_v2.hip): no v_cvt_f32_i32, and the 8 + 8 VALU of an int4 pair;
-//  * the weight scales are converted to FP32 once per half-step, the token fragment of block tb + 2 is requested behind the last
-//    MFMA that reads block tb's;
-//  * STORE (the second half, plain fp16 output): a token block's 64 x 16 outputs are final once its pair h = 1 is de-quantised;
+//  * the weight scales are converted to FP32 once, the token fragments of block tb + 2 are requested behind the last MFMA that reads
+//    block tb's;
+//  * STORE (plain fp16 output): a token block's 64 x 16 outputs are final once its pair h = 1 is de-quantised;
 //    they are converted and stored (two 16-byte stores per lane) behind the MFMAs of the following slot, so that the kernel's
 //    store tail -- 2-4 us with all 256 workgroups storing 32 MiB at once after the loop -- shrinks to the last block's.
-// Same arithmetic as p_keeper: bit-identical results.
+// Same arithmetic as p_keeper: bit-identical results.  Same-box A/B at 4096^3: two pipelined half-steps 56.6 us, this 55.6.
 template <class C, bool STORE>
-__device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, int wm, int wn, int lane, float (&c)[4][8][4], int m0, int n0) {
+__device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[4][8][4],
+                                         int m0, int n0) {
+  constexpr bool MERGED = true;
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 1) & 3;                                       // swizzle key (row >> 2) & 3 of row 2 * l15 + (blk & 1)
   const char *pw = slot + (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
@@ -1429,6 +1470,8 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
   const char *psa = slot + C::KP_SA_OFF + (wm * 128 + 2 * l15) * 4;
   const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
   v4i af[4], bf[2];
+  v4i af1[4], bf1[2];                                      // the second half's fragments (slot1)
+  const long d1 = slot1 - slot;
   float sb[2][8], sa[2], nms[2];
   v4i acc[2][2];
   const v4i magic = {kMagicBits, kMagicBits, kMagicBits, kMagicBits};
@@ -1436,6 +1479,12 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
   for (int fb = 0; fb < 4; ++fb) af[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + p_row(fb) * 64));
   bf[0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(0) * 64));
   bf[1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(1) * 64));
+  if constexpr (MERGED) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) af1[fb] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pw + d1 + p_row(fb) * 64));
+    bf1[0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + d1 + p_row(0) * 64));
+    bf1[1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + d1 + p_row(1) * 64));
+  }
   half_t sah[2];
   sah[0] = *reinterpret_cast<const half_t *>(psa + p_row(0) * 4);
   sah[1] = *reinterpret_cast<const half_t *>(psa + p_row(1) * 4);
@@ -1488,9 +1537,14 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) acc[i & 1][k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * h + k], bf[tb & 1], magic, 0, 0, 0);
+    if constexpr (MERGED) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc[i & 1][k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[2 * h + k], bf1[tb & 1], acc[i & 1][k], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (h == 1 && tb + 2 < 8) {                                        // the buffer of block tb is free: block tb + 2
       bf[tb & 1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(tb + 2) * 64));
+      if constexpr (MERGED) bf1[tb & 1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + d1 + p_row(tb + 2) * 64));
       sah[tb & 1] = *reinterpret_cast<const half_t *>(psa + p_row(tb + 2) * 4);
     }
     if constexpr (STORE) { if (h == 1 && tb >= 1) store_block(tb - 1); }   // final since slot i - 1's de-quantisation
@@ -1656,14 +1710,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][7][r]);
   }
-  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it
+  // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it: ONE step over both once it has landed
   kstamp(4);
-  q_keeper<C, false>(p, slot_of(G), wm, wn, lane, c, m0, n0);
-  kstamp(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  kstamp(6);
-  q_keeper<C, GU == 0>(p, slot_of(G + 1), wm, wn, lane, c, m0, n0);     // GU == 0: the fp16 output leaves from inside this step
+  kstamp(5); kstamp(6);
+  q_keeper<C, GU == 0>(p, slot_of(G), slot_of(G + 1), wm, wn, lane, c, m0, n0);   // GU == 0: the fp16 output leaves from inside this step
   if constexpr (TR) {
     kstamp(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -156,14 +156,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
         if (tb + 1 < MBLK) load_sa(tb + 1, j);
       }
     }
-    if (keeper) {                                          // INT8 keeper, last, as two 64-column halves (the contract)
-      const float sa8 = opaque_half(sak);
+    if (keeper) {                                          // INT8 keeper, last: both 64-column k-steps into ONE accumulator, one
+      const float sa8 = opaque_half(sak);                  // de-quantisation (the contract; Dense_layer_gemm_i4_o16.cuh:640-691)
+      v4i acc = {0, 0, 0, 0};
 #pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf) {
-        v4i acc = {0, 0, 0, 0};
+      for (int hlf = 0; hlf < 2; ++hlf)
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(v4i, wk[hlf]), __builtin_bit_cast(v4i, ak[hlf]), acc, 0, 0, 0);
-        dequant4(acc, sa8, sbk, c[tb]);
-      }
+      dequant4(acc, sa8, sbk, c[tb]);
       if (tb + 1 < MBLK) load_keeper_act(tb + 1);
     }
   }

@@ -20,7 +20,7 @@
 //    2 VALU ops/element (magic-number trick; the weight scale is consumed as fp16 by v_fma_mix_f32).
 //
 // Arithmetic contract (include/atom_hip.h): per int4 group  t = round_f32(idot*sA[m,g]); c = fma(t, sB[g,n], c);
-// the 128 INT8 keeper columns are processed as two 64-column halves, each dequantised the same way.
+// the 128 INT8 keeper columns arrive as two 64-column stages and are multiplied in one step (one de-quantisation).
 #include "common.h"
 
 namespace atom {
@@ -212,6 +212,53 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
   }
 }
 
+// The keeper: its 128 INT8 columns arrive as TWO stages of 64-byte rows (slot0 = columns 0..63, slot1 = 64..127) and are multiplied
+// in ONE step: four chained MFMAs per 32x32 tile into one accumulator, one de-quantisation -- as the reference kernel does
+// (Dense_layer_gemm_i4_o16.cuh:640-691; rounds 1-2 of this repository de-quantised the two halves separately).
+__device__ __forceinline__ void compute_keeper(const char *slot0, const char *slot1, int wm, int wn, int lane, float (&c)[TN][TM][16]) {
+  const int l31 = lane & 31, h = lane >> 5;
+  v16i magic;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
+  v4i af[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    v4i f0[4], f1[4];
+    load_frag<false, 0>(slot0, wn * 64 + tn * 32 + l31, h, f0);
+    load_frag<false, 0>(slot1, wn * 64 + tn * 32 + l31, h, f1);
+    af[tn][0] = f0[0]; af[tn][1] = f0[1]; af[tn][2] = f1[0]; af[tn][3] = f1[1];
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int ml = wm * 128 + tm * 32 + l31;
+    v4i b0[4], b1[4];
+    load_frag<false, 0>(slot0, 256 + ml, h, b0);
+    load_frag<false, 0>(slot1, 256 + ml, h, b1);
+    const float sa = (float)*reinterpret_cast<const half_t *>(slot0 + SA_OFF + ml * 4);
+    const float nms = -kMagic * sa;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      __builtin_amdgcn_sched_barrier(0);
+      v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], b0[0], magic, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][1], b0[1], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][2], b1[0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][3], b1[1], a, 0, 0, 0);
+      v2u sbp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        sbp[q] = *reinterpret_cast<const v2u *>(slot0 + SB_OFF + (wn * 64 + tn * 32 + 8 * q + 4 * h) * 2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
+        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
+        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        asm volatile("" : "+v"(c[tn][tm][r]));
+      }
+    }
+  }
+}
+
 // Ping-pong variant (ABL bit 64, experimental): the MFMA chain of tile i+1 is issued BEFORE the dequant of tile i, so
 // the 12 wait states after a chain and the dequant's dependency latency are covered by matrix work of the same wave.
 template <bool INT4>
@@ -300,7 +347,7 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
 
-  const int nsteps = p.G + 2;                 // G int4 groups + two 64-column halves of the INT8 keeper
+  const int nsteps = p.G + 2;                 // DMA stages: G int4 groups + the two 64-column halves of the INT8 keeper (ONE compute step)
   // prologue: NS-1 stages in flight.  Steps past the end re-load the last step into a slot nobody reads
   // again, so that the vmcnt bookkeeping below is the same constant on every iteration.
   StageAddr sa_;
@@ -332,8 +379,17 @@ __global__ __launch_bounds__(NT) void gemm_w4a4_v2_kernel(GemmParams p) {
   }
   int step = 0;
   for (; step < p.G; ++step) ATOM_V2_STEP(true)
-  for (; step < nsteps; ++step) ATOM_V2_STEP(false)
 #undef ATOM_V2_STEP
+  {                                           // the keeper: both halves (stages G, G + 1) in one compute step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NS == 2) {                  // (two-stage ring: the second half only fits now that stage G - 1 has been read)
+      issue_stage(p, p.G + 1, lds + ((p.G + 1) % NS) * STAGE_BYTES, wave, sa_);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    compute_keeper(lds + (p.G % NS) * STAGE_BYTES, lds + ((p.G + 1) % NS) * STAGE_BYTES, wm, wn, lane, c);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail DMAs: they still target the LDS ring
   __builtin_amdgcn_s_barrier();                       // nobody reads stage data any more
 

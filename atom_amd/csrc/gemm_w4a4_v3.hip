@@ -295,6 +295,60 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 }
 
 
+// The keeper: its 128 INT8 columns arrive as TWO stages of 64-byte rows (the int4 stage layout; slot0 = columns 0..63, slot1 =
+// 64..127) and are multiplied in ONE step -- four chained MFMAs per 32x32 tile into one accumulator, one de-quantisation -- as the
+// reference kernel does (Dense_layer_gemm_i4_o16.cuh:640-691; rounds 1-2 de-quantised the two halves separately).
+template <class C>
+__device__ __forceinline__ void compute_keeper(const char *slot0, const char *slot1, const LaneOff &lo, float (&c)[TN][C::TM][16]) {
+  constexpr int TM = C::TM;
+  constexpr bool AW = C::AW;
+  constexpr int ASTR = AW ? 4096 : 2048;
+  const char *psa = slot0 + lo.sa, *psb = slot0 + lo.sb;   // (both stages carry the same scales)
+  const int a0 = AW ? lo.ak0 : lo.a0, a1 = AW ? lo.ak1 : lo.a1;
+  v16i magic;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) magic[i] = kMagicBits;
+  v4i af[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    af[tn][0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot0 + lo.w0 + tn * 2048));
+    af[tn][1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot0 + lo.w1 + tn * 2048));
+    af[tn][2] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + lo.w0 + tn * 2048));
+    af[tn][3] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + lo.w1 + tn * 2048));
+  }
+  v4i bf[4];
+  half_t sah;
+  auto request = [&](int tm) {
+    bf[0] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot0 + a0 + tm * ASTR));
+    bf[1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot0 + a1 + tm * ASTR));
+    bf[2] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + a0 + tm * ASTR));
+    bf[3] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + a1 + tm * ASTR));
+    sah = *reinterpret_cast<const half_t *>(psa + tm * 128);
+  };
+  request(0);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_sched_barrier(0);
+    const v4i b0 = bf[0], b1 = bf[1], b2 = bf[2], b3 = bf[3];
+    const float sa = (float)sah;
+    if (tm + 1 < TM) request(tm + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float nms = -kMagic * sa;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      __builtin_amdgcn_sched_barrier(0);
+      v16i a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][0], b0, magic, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][1], b1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][2], b2, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][3], b3, a, 0, 0, 0);
+      v2u sbp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
+      dequant16_magic(a, sa, nms, sbp, c[tn][tm]);
+    }
+  }
+}
+
 template <class C, bool TRACE = false, bool SK = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) {   // <= 256 VGPRs: two waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -325,10 +379,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
 
-  // split-K (SK): blockIdx.y owns the K steps [s_begin, s_end) and writes FP32 partial sums to p.ws
-  const int total_steps = p.G + 2;
-  const int s_begin = SK ? (int)((int64_t)total_steps * blockIdx.y / p.splits) : 0;
-  const int nsteps = SK ? (int)((int64_t)total_steps * (blockIdx.y + 1) / p.splits) : total_steps;   // == s_end
+  // K steps: the G int4 groups, then the keeper = G + 1 compute steps; DMA stages: G + 2 (the keeper's two 64-byte halves).
+  // split-K (SK): blockIdx.y owns the compute steps [cb, ce) and writes FP32 partial sums to p.ws
+  const int csteps = p.G + 1;
+  const int cb = SK ? (int)((int64_t)csteps * blockIdx.y / p.splits) : 0;
+  const int ce = SK ? (int)((int64_t)csteps * (blockIdx.y + 1) / p.splits) : csteps;
+  const bool has_keeper = ce == csteps;
+  const int s_begin = cb, nsteps = ce + (has_keeper ? 1 : 0);   // DMA stages [s_begin, nsteps)
   StageAddr<C> sa_;
   make_stage_addr<C>(p, wave, lane, m0, n0, sa_);
   const LaneOff lo_ = make_lane_off<C>(wm, wn, lane);
@@ -354,8 +411,19 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_v3_kernel(GemmParams p) { 
   }
   int step = s_begin;
   for (; step < min(p.G, nsteps); ++step) ATOM_V3_STEP(true)
-  for (; step < nsteps; ++step) ATOM_V3_STEP(false)
 #undef ATOM_V3_STEP
+  if (has_keeper) {                                        // step == G: both halves (stages G, G + 1) in ONE compute step
+    if (tr) trace[(wave * 64 + step) * 4 + 0] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (C::NS == 2) {                            // two-stage ring: the second half only fits now that stage G - 1 is read
+      issue_stage<C>(p, p.G + 1, lds + ((p.G + 1) % C::NS) * C::STAGE_BYTES, wave, sa_);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    compute_keeper<C>(lds + (p.G % C::NS) * C::STAGE_BYTES, lds + ((p.G + 1) % C::NS) * C::STAGE_BYTES, lo_, c);
+    ++step;
+  }
   if (tr) trace[(wave * 64 + step) * 4 + 0] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();

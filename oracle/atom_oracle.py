@@ -439,20 +439,20 @@ def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
 
 def gemm_w4a4_contract(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8, kgroups: int = 1) -> np.ndarray:
     """The C-ABI arithmetic contract (include/atom_hip.h) in numpy float32, independent of oracle/atom_oracle.c:
-    K steps = the G int4 groups in order, then the keeper as two 64-column halves; per step t = f32(idot * sA),
+    K steps = the G int4 groups in order, then the keeper (ONE dot product over its 128 columns, one de-quantisation, as the
+    reference kernel: Dense_layer_gemm_i4_o16.cuh:640-691); per step t = f32(idot * sA),
     c = fma(t, sB, c) (the fma through float64: the product of two float32 is exact there and one rounding of the sum to
     float32 is the fused result up to double rounding, which the 2^-29 headroom of these operands excludes -- checked against
     the C restatement in tests).  kgroups = 1: one ordered sum (tile kernels).  kgroups = 2 / 4: the K-group tile kernels
-    (gemm_w4a4_f6.hip) -- the steps are cut into ranges [(G+2)k/kg, (G+2)(k+1)/kg), each summed from 0, partial sums added
+    (gemm_w4a4_f6.hip) -- the G + 1 steps are cut into ranges [(G+1)k/kg, (G+1)(k+1)/kg), each summed from 0, partial sums added
     in order.  Returns float16 [M, N]."""
     M, K4 = qa4.shape
     G = K4 // GROUP
     steps = []
     for g in range(G):
         steps.append((_group_int_dots(qa4, qb4, g), sA[:, g].astype(f32), sB[g].astype(f32)))
-    for h in range(2):
-        I8 = qa8[:, 64 * h:64 * h + 64].astype(f32) @ qb8[:, 64 * h:64 * h + 64].astype(f32).T
-        steps.append((I8, sA8.astype(f32), sB8.astype(f32)))
+    I8 = (qa8.astype(np.int32) @ qb8.astype(np.int32).T).astype(f32)       # |idot8| <= 128 * 128 * 127 < 2^24: exact
+    steps.append((I8, sA8.astype(f32), sB8.astype(f32)))
     T = len(steps)
     total = None
     for k in range(kgroups):

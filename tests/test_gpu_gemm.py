@@ -141,13 +141,16 @@ def test_gemm_error_behaviour():
 
 def test_gemm_bit_exact_vs_c_contract():
     """The arithmetic contract of include/atom_hip.h restated in plain C (oracle/atom_oracle.c): exact integer dots,
-    t = round_f32(idot*sA), c = fmaf(t, sB, c), groups in order, keeper as two halves, D = half(c).  Bit-for-bit."""
+    t = round_f32(idot*sA), c = fmaf(t, sB, c), groups in order, then the keeper (one dot product over its 128 columns, one
+    de-quantisation), D = half(c).  Bit-for-bit -- in the summation order of the kernel the shape is dispatched to: one ordered sum
+    for the tile kernels, the G + 1 items dealt to 8 waves for decode batches (2 <= M <= 256 where the decode-batch kernel fits)."""
     from tests import c_oracle as C
     ops = _ops()
-    for (M, N, K) in [(40, 128, 640), (257, 64, 384), (3, 320, 1152)]:
+    for (M, N, K) in [(40, 128, 640), (257, 64, 384), (3, 320, 1152), (300, 128, 640), (600, 192, 640)]:      # (short K: no split-K through the workspace)
         d = rand_gemm_operands(M, N, K, seed=M * 7 + N)
         out = t2n(ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain"))
-        want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"])
+        order = 8 if (1 < M <= 256 and ops.multi_gemm_fits(M, N, 1, K)) else 1      # (== the dispatch's decode-batch condition)
+        want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=order)
         assert np.array_equal(bits16(out), bits16(want)), f"{M}x{N}x{K}: {(bits16(out) != bits16(want)).sum()} elements differ"
 
 
@@ -339,7 +342,7 @@ def test_gemm_wide_full_size_and_errors():
     aw = torch.from_numpy(wide_codes(d["qa4"])).cuda()
     out_w = ops.dense_layer_gemm_i4_fp16(aw, *t[1:], scale_layout="plain", a_wide=True)
     out_p = ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain")
-    assert torch.equal(out_w, out_p)                      # both: per-group FMAs in group order, keeper halves last
+    assert torch.equal(out_w, out_p)                      # both: per-group FMAs in group order, the keeper last
     with pytest.raises(AtomHipError):                     # the u4-epilogue kernel takes packed activations only
         st = ops.L.lib().atom_gemm_w4a4_o4(aw.data_ptr(), *[x.data_ptr() for x in t[1:]], t[0].data_ptr(),
                                            t[2].data_ptr(), 4096, 4096, 4096, 128, 128, 1 | ops.L.A_WIDE, None)
