@@ -81,9 +81,9 @@ extern "C" {
  * still written).  Weights: atom_repack_weight_f6.  M, N >= 1 as usual; tile geometries picked by shape: 256x256 and
  * 128x128 (4 waves) -- results bit-identical to the INT8 kernels -- and, for shapes of at most 256 tiles (one per CU: mid-size
  * prefill batches, 256..1024 rows at Llama widths), 128x128 / 64x128 tiles shared by two groups of 4 waves that split the
- * K steps (the G int4 groups, then the two keeper halves) at (G + 2) / 2: each half is summed in order from 0 and
+ * G + 1 K steps (the G int4 groups, then the keeper) at (G + 1) / 2: each half is summed in order from 0 and
  * D = half(first + second) -- deterministic, same tolerance, 1.4x faster there (1024x4096x4096: 33 -> 23 us); with at most 256
- * tiles of 64x128 and K_total >= 2048, four groups and four ranges [(G + 2) k / 4, (G + 2) (k + 1) / 4), D = half(((p0 + p1) + p2)
+ * tiles of 64x128 and K_total >= 2048, four groups and four ranges [(G + 1) k / 4, (G + 1) (k + 1) / 4), D = half(((p0 + p1) + p2)
  * + p3) (512x4096x4096: 16.7 us).  atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in order, 2 = two halves,
  * 4 = four ranges (0 = unsupported shape).
  * Ahead of the INT8 kernels from 256 rows up (1.5x at 512-1024 rows, 1.35x at 4096^3).
@@ -117,8 +117,10 @@ size_t atom_scale_size(int64_t rows, int scale_layout);
  * D[M,N] (fp16) = sum_g (A4_g . B4_g^T) * sA[m,g] * sB[g,n]  +  (A8 . B8^T) * sA8[m] * sB8[n]
  * Replaces: DenseLayerGEMM_i4_o16 (kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:728-769) and
  *           DenseLayerGEMM_i4<nv_half> (e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4.cu:722-791).
- * Integer dot products are exact (INT8 MFMA); per group c = fma(round_f32(idot*sA), sB, c) in FP32, groups in
- * order, then the keeper as two 64-column halves (each dequantised the same way); D = half(c).  The decode kernels
+ * Integer dot products are exact (INT8 / BF6 MFMA); per group c = fma(round_f32(idot*sA), sB, c) in FP32, groups in
+ * order, then the keeper: ONE dot product over its 128 columns, de-quantised once the same way -- the reference kernel accumulates
+ * both keeper k-steps in int32 before its dequant too (Dense_layer_gemm_i4_o16.cuh:640-691; rounds 1-2 of this library de-quantised
+ * two 64-column halves separately); D = half(c).  The decode kernels
  * (M = 1: dot products along K; 2 <= M <= 256 in the packed format: eight waves own an eighth of the groups each) apply
  * the same per-group arithmetic and add their per-lane / per-wave partial sums in a fixed order: deterministic, within
  * 1 fp16 ulp of the exact value like the tile kernels, but not the same FP32 summation order.
