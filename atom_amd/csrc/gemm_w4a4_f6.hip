@@ -1382,9 +1382,11 @@ __device__ __forceinline__ void q_piece(const QDma &d, const uint8_t *wsrc, cons
 
 // One K step on stage slot SL (next stage in slot (SL + 1) % 3; SL < 0: slots at byte offsets ro / rn).  `mid(i)`, i = 0..7:
 // behind the MFMAs of slots 8..15.
-template <class C, int SL, class FS, class FD>
+struct QNoEarly { __device__ __forceinline__ void operator()(int) const {} };
+// `early(i)`, i = 0..7: behind the MFMAs of slots 0..7 (step 0 issues the LDS-DMA of stage 1 there; published by the same mid-step barrier)
+template <class C, int SL, class FS, class FD, class FE = QNoEarly>
 __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[4][8][4], FS sync, FD mid, int ro = 0, int rn = 0,
-                                       bool LAST = false) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
+                                       bool LAST = false, FE early = FE()) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
   constexpr int NX = SL < 0 ? -1 : (SL + 1) % 3;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1418,6 +1420,7 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
       }
     }
     if (i >= 8) mid(i - 8);
+    else early(i);
     __builtin_amdgcn_sched_barrier(0);
     // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
     {
@@ -1626,9 +1629,16 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
 #pragma unroll
     for (int i = 0; i < 7; ++i) q_piece<C, DS>(d, wsrc0 + g * wstep, asrc0 + g * astep, sbsrc0 + (int64_t)g * p.f6_rows_b, i);
   };
+  // Prologue: stage 0 only where the K loop has a regular first step (G >= 6: s = 0 runs on a compile-time-slot body); stage 1's
+  // LDS-DMA then goes out behind the MFMAs of that step's first half and is published by its mid-step barrier, where its first
+  // reader sits.  (The trace put two stages of DMA issue + landing at 4,500 cycles, the younger wave of each SIMD issuing behind the
+  // older one.)
+  const bool early1 = G >= 6;
   issue_all(std::integral_constant<int, 0>(), 0);
-  if (G >= 2) issue_all(std::integral_constant<int, 1>(), 1);
-  else issue_keeper<C>(p, 0, slot_of(1), wave, lane, m0, n0);
+  if (!early1) {
+    if (G >= 2) issue_all(std::integral_constant<int, 1>(), 1);
+    else issue_keeper<C>(p, 0, slot_of(1), wave, lane, m0, n0);
+  }
   kstamp(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1682,6 +1692,16 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   int s = 0;
+  if (early1) {                                             // step 0: + the LDS-DMA of stage 1 in its first half
+    if constexpr (TR) kstamp(16);
+    const uint8_t *wsrc = wsrc0 + 2 * wstep, *asrc = asrc0 + 2 * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)2 * p.f6_rows_b;
+    q_step<C, 0>(R, lds, c, sync, [&](int i) { q_piece<C, 2>(d, wsrc, asrc, sbsrc, i); }, 0, 0, false,
+                 [&](int i) { q_piece<C, 1>(d, wsrc0 + wstep, asrc0 + astep, sbsrc0 + p.f6_rows_b, i); });
+    reg(S1(), 1);
+    reg(S2(), 2);
+    s = 3;
+  }
   for (; s + 4 < G; s += 3) { reg(S0(), s); reg(S1(), s + 1); reg(S2(), s + 2); }
   // The last 2..4 steps run on ONE generic code body (run-time stage slots): 0..2 regular steps, then the two whose LDS-DMA is a
   // keeper half instead of an int4 stage (the second one has no next int4 stage to prefetch from).  (Round 3 tried compile-time
