@@ -176,9 +176,10 @@ def _workspace(device, nbytes, weight_key=None):
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = t
         _WS_WEIGHT.pop(key, None)
-    cached = weight_key is not None and _WS_WEIGHT.get(key) == weight_key
-    _WS_WEIGHT[key] = weight_key
-    return t, cached
+    prev = _WS_WEIGHT.get(key)
+    cached = weight_key is not None and prev is not None and prev[0] == weight_key[0]
+    _WS_WEIGHT[key] = weight_key                           # (key, storages): the entry keeps the weight's storages alive, so their
+    return t, cached                                       #  addresses cannot be handed to another tensor while it is cached
 
 
 def _gemm_dims(a, b, a_keeper, a_wide=False, b_keeper=None):
@@ -210,7 +211,7 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     # weight (same storage, same version counters) on the same workspace re-codes the activation only
     wkey = None
     if ws_bytes and not a_wide and lib.atom_gemm_w4a4_ws_recodes(m, n, k):
-        wkey = (b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k)
+        wkey = ((b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k), (b.untyped_storage(), b_scale.untyped_storage()))
     ws, cached = _workspace(a.device, ws_bytes, wkey) if ws_bytes else (None, False)
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
@@ -270,7 +271,8 @@ def fuse_projection_weights(mods):
     """Offline, once per layer: the packed weights of 2-3 ``LinearInt4`` modules that read the same activation (q / k / v; gate /
     up) as ONE operand for dense_layer_gemm_i4_multi, concatenated along the output features.  The codes are not duplicated: the
     modules' ``weight_int4`` / ``weight_int8`` parameters become views of the fused buffers (a later in-place load writes through;
-    a re-assigned parameter changes the key and the operand is rebuilt).  The scales (31 x N halves per projection) are copied.
+    a re-assigned parameter changes the key and the operand is rebuilt; serialisers that refuse tensors sharing storage, e.g.
+    safetensors' save_file, want ``.clone()``d parameters).  The scales (31 x N halves per projection) are copied.
     Returns a dict; ``fused_key(mods)`` tells whether it is current."""
     packs = [m.packed() for m in mods]
     n = packs[0][0].shape[0]

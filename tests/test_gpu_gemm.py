@@ -528,7 +528,7 @@ def test_packed_route_weight_cached_in_workspace():
         return ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")
     want1, want2 = fresh(dev1), fresh(dev2)
     ops._WS.clear(); ops._WS_WEIGHT.clear()
-    key = lambda: next(iter(ops._WS_WEIGHT.values()))
+    key = lambda: next(iter(ops._WS_WEIGHT.values()))[0]
     y = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
     k1 = key()
     assert k1 is not None and torch.equal(y, want1)
