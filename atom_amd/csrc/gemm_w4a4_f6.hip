@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6p_kernel(GemmParams
 template <class C>
 struct QC {
   static constexpr int SB_OFF = C::SB_OFF;                  // 256 float32 weight scales (keeper steps: C's fp16 layout)
-  static constexpr int STAGE = C::SB_OFF + 1024;
+  static constexpr int STAGE = C::SB_OFF + C::BN * 4;
   static constexpr int LDS_BYTES = 3 * STAGE;
   static_assert(LDS_BYTES <= 160 * 1024 && STAGE + (32 * 3 + 1) * PITCH + 100 < 65536, "q kernel: stage layout / ds offsets");
 };
@@ -1341,12 +1341,12 @@ __device__ __forceinline__ v8i q_frag(const char *lds, const int (&a)[2][3], int
   asm volatile("" ::: "memory");   // keeps the compiler from pairing this fragment's loads with the next fragment's
   return v8i{(int)x.x, (int)x.y, (int)y.x, (int)y.y, (int)z.x, (int)z.y, 0, 0};
 }
-template <class C, int SL>
-__device__ __forceinline__ float q_scale(const char *lds, const QRegs<C> &R, int off, int ro) {
+template <class C, int SL, class RG>
+__device__ __forceinline__ float q_scale(const char *lds, const RG &R, int off, int ro) {
   return *reinterpret_cast<const float *>(lds + (SL < 0 ? ro : q_imm<C, SL>()) + off + R.aS[q_set<SL>()]);
 }
-template <class C, int SL>
-__device__ __forceinline__ void q_load_sb(const char *lds, QRegs<C> &R, int h, int ro) {   // 8 consecutive features of pair h
+template <class C, int SL, class RG>
+__device__ __forceinline__ void q_load_sb(const char *lds, RG &R, int h, int ro) {   // 8 consecutive features of pair h
   const char *b = lds + (SL < 0 ? ro : q_imm<C, SL>()) + QC<C>::SB_OFF + 128 * h + R.aB[q_set<SL>()];
   const v4f_t lo = *reinterpret_cast<const v4f_t *>(b), hi = *reinterpret_cast<const v4f_t *>(b + 16);
 #pragma unroll
@@ -1462,15 +1462,15 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
 //    they are converted and stored (two 16-byte stores per lane) behind the MFMAs of the following slot, so that the kernel's
 //    store tail -- 2-4 us with all 256 workgroups storing 32 MiB at once after the loop -- shrinks to the last block's.
 // Same arithmetic as p_keeper: bit-identical results.  Same-box A/B at 4096^3: two pipelined half-steps 56.6 us, this 55.6.
-template <class C, bool STORE>
-__device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[4][8][4],
+template <class C, bool STORE, int NTB>
+__device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, const char *slot1, int wm, int wn, int lane, float (&c)[4][NTB][4],
                                          int m0, int n0) {
   constexpr bool MERGED = true;
   const int l15 = lane & 15, kb = lane >> 4;
   const int sw = (l15 >> 1) & 3;                                       // swizzle key (row >> 2) & 3 of row 2 * l15 + (blk & 1)
   const char *pw = slot + (wn * 64 + 2 * l15) * 64 + ((kb ^ sw) << 4);
-  const char *pa = slot + (C::BN + wm * 128 + 2 * l15) * 64 + ((kb ^ sw) << 4);
-  const char *psa = slot + C::KP_SA_OFF + (wm * 128 + 2 * l15) * 4;
+  const char *pa = slot + (C::BN + wm * (16 * NTB) + 2 * l15) * 64 + ((kb ^ sw) << 4);
+  const char *psa = slot + C::KP_SA_OFF + (wm * (16 * NTB) + 2 * l15) * 4;
   const char *psb = slot + C::SB_OFF + (wn * 64 + 8 * kb) * 2;
   v4i af[4], bf[2];
   v4i af1[4], bf1[2];                                      // the second half's fragments (slot1)
@@ -1499,7 +1499,7 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
     for (int j = 0; j < 8; ++j) { sb[h][j] = (float)hv[j]; asm volatile("" : "+v"(sb[h][j])); }   // opaque: no v_fma_mix re-folding
   }
   auto store_block = [&](int tb) {                                     // fp16 outputs of token block tb: 8 consecutive features per pair
-    const int m = m0 + wm * 128 + p_row(tb) + 2 * l15;
+    const int m = m0 + wm * (16 * NTB) + p_row(tb) + 2 * l15;
     if (m >= p.M) return;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1531,7 +1531,7 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
       }
   };
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 2 * NTB; ++i) {
     const int tb = i >> 1, h = i & 1;
     __builtin_amdgcn_sched_barrier(0);
     if (h == 0) {                                                      // this block's token scale arrived with its fragment
@@ -1545,7 +1545,7 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
       for (int k = 0; k < 2; ++k) acc[i & 1][k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[2 * h + k], bf1[tb & 1], acc[i & 1][k], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (h == 1 && tb + 2 < 8) {                                        // the buffer of block tb is free: block tb + 2
+    if (h == 1 && tb + 2 < NTB) {                                        // the buffer of block tb is free: block tb + 2
       bf[tb & 1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + p_row(tb + 2) * 64));
       if constexpr (MERGED) bf1[tb & 1] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(pa + d1 + p_row(tb + 2) * 64));
       sah[tb & 1] = *reinterpret_cast<const half_t *>(psa + p_row(tb + 2) * 4);
@@ -1555,8 +1555,8 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
     if (i > 0) dequant(i - 1);
   }
   __builtin_amdgcn_sched_barrier(0);
-  dequant(15);
-  if constexpr (STORE) store_block(7);
+  dequant(2 * NTB - 1);
+  if constexpr (STORE) store_block(NTB - 1);
 }
 
 // GU != 0: the weight rows are gate_proj / up_proj interleaved per wave (32 gate features, then the same 32 up features), so a
@@ -1839,6 +1839,365 @@ static int launch_q(const GemmParams &p, hipStream_t s) {
   return check_launch();
 }
 
+// ================================================================================================================
+// The K-group kernel, second generation ("qk"): a 128x128 tile shared by TWO groups of 4 waves (wave tiles 64 features x 64 tokens),
+// each group running the q kernel's K step -- compile-time stage slots, fp32 scales from LDS straight into the FMA operands, MFMA of
+// pair slot i issued ahead of the de-quantisation of slot i - 1, address-free LDS-DMA -- on its own 3-stage ring over its own range
+// of the G + 1 compute steps: group k owns [(G + 1) k / 2, (G + 1) (k + 1) / 2), so the result is the x16 K-group kernel's (and
+// atom_gemm_w4a4_f6_order's nsplit = 2) bit for bit.  For shapes with at most one 128x128 tile per CU (512..1024 tokens at N = 4096):
+// the x16 body spent 2,950 cycles per wave and K step on 16 MFMAs.
+//  * stage = 13 + 13 KiB of rows + 128 float32 weight scales (Cfg<128,128,2,3,3,1>'s layout: the keeper stages and its issue_keeper
+//    are reused); per wave and stage: 3 consecutive weight pieces, 3 activation pieces, and one extra -- the 13th weight / activation
+//    piece on waves 0 / 1, 64 scales each (dword LDS-DMA) on waves 2 / 3;
+//  * both groups meet at one barrier per step (a workgroup has one barrier); the group with fewer catches up before the exchange;
+//  * epilogue: group k finishes token blocks 2k, 2k + 1 of every wave tile -- the other two blocks' FP32 sums go to the partner
+//    wave through LDS, lower K range + upper K range, fp16 rows stored straight from registers (16 bytes per lane).
+struct QkDma {
+  unsigned voff, voffX;     // lane offsets from the stage's weight / activation base (the same for both) and of the extra piece
+  int m0W, m0A, m0X;        // LDS byte addresses of the wave's first pieces inside stage slot 0 of its group's ring
+  int xkind;                // extra piece: 1 weight rows, 2 activation rows, 3 weight scales (dword pieces)
+};
+__device__ __forceinline__ void q_dma4(unsigned m0v, unsigned voff, const void *sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+// DMA group i (0: weight pieces, 1: activation pieces, 2: the extra piece) of this wave into the slot at byte offset `so` of the ring
+template <class C>
+__device__ __forceinline__ void qk_piece(const QkDma &d, const uint8_t *wsrc, const uint8_t *asrc, const float *sbsrc, int so, int i) {
+  if (i == 0) q_dma16x3(so + d.m0W, d.voff, wsrc);
+  else if (i == 1) q_dma16x3(so + d.m0A, d.voff, asrc);
+  else if (i == 2) {
+    if (d.xkind == 3) q_dma4(so + d.m0X, d.voffX, sbsrc);
+    else q_dma16(so + d.m0X, d.voffX, d.xkind == 1 ? (const void *)wsrc : (const void *)asrc);
+  }
+}
+
+// TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
+// [0..9] kernel phases, [16 + t] start of the group's K step t, [62], [63] s_memrealtime (100 MHz) at entry and exit
+// The K step of the two-K-group kernel: q_step's MFMA / de-quantisation stream for a 64 x 64 wave tile -- 8 pair slots, slot i =
+// (token block i % 4, feature-block pair i / 4); all four token fragments stay resident (a 64-token tile has the registers), and every
+// LDS load is issued at least four slots ahead of its first reader:
+//   slot 0      fragments fb 2,3 of THIS stage (read from slot 4 on; their previous contents died with slot 7 of the last step);
+//               after the carried de-quantisation (pair 7 of the last step): weight scales of pair 1 and token scale 3 of this stage
+//   slot 4      behind the mid-step barrier that publishes the next stage: its fragments fb 0,1 and token block 0;
+//               after the de-quantisation of pair 3: its weight scales of pair 0
+//   slot 4 + tb its token block tb; slot 5 + tb (tb < 3), after the de-quantisation of pair 4 + tb: its token scale tb
+// (q_step's own slot order on 4 token blocks -- fragments fb 2,3 one slot, token block 3 two slots ahead of their MFMAs -- measured
+// the same: 22.4 vs 22.9 us at 1024x4096x4096.  The step is bound by what a SIMD can issue, not by load latency: 16 MFMA + 128 FMA
+// + 32 LDS reads + 7 LDS-DMA per wave in ~1,800 cycles, each class at its r02 issue cost; profiles/r03_mid_m.txt.)
+template <class C>
+struct QkRegs {
+  v8i af[4], bf[4];
+  float sb[2][8], sa[4];
+  v4f_t acc[2][2];
+  int aW[2][3], aA[2][3], aS[2], aB[2];       // as QRegs
+};
+// ABL (tools build only): 2 = no de-quantisation, 4 = no MFMA, 8 = no fragment / scale re-loads
+// `mid(i)` / `early(i)`, i = 0..3: behind the MFMAs of slots 4..7 / 0..3 (the caller's LDS-DMA)
+template <class C, int SL, int ABL = 0, class FS, class FD, class FE = QNoEarly>
+__device__ __forceinline__ void qk_step(QkRegs<C> &R, const char *lds, float (&c)[4][4][4], FS sync, FD mid, int ro = 0, int rn = 0, bool LAST = false,
+                                        FE early = FE()) {
+  constexpr int NX = SL < 0 ? -1 : (SL + 1) % 3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int tb = i & 3, h = i >> 2;
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 4) sync();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 4)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[tb], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 8)) {
+      if (i == 0) {
+        R.af[2] = q_frag<C, SL>(lds, R.aW, p_row(2) * PITCH, ro);
+        R.af[3] = q_frag<C, SL>(lds, R.aW, p_row(3) * PITCH, ro);
+      }
+      if (!LAST && i >= 4) {
+        if (i == 4) {
+          R.af[0] = q_frag<C, NX>(lds, R.aW, p_row(0) * PITCH, rn);
+          R.af[1] = q_frag<C, NX>(lds, R.aW, p_row(1) * PITCH, rn);
+        }
+        R.bf[tb] = q_frag<C, NX>(lds, R.aA, p_row(tb) * PITCH, rn);
+      }
+    }
+    if (i >= 4) mid(i - 4);
+    else early(i);
+    __builtin_amdgcn_sched_barrier(0);
+    const int j = (i + 7) & 7, dtb = j & 3, dh = j >> 2;      // de-quantisation of the previous slot's pair (i == 0: the carried one)
+    if constexpr (!(ABL & 2)) {
+      const float sa = R.sa[dtb];
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[dh][2 * r + k], c[2 * dh + k][dtb][r]);
+          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 8)) {                              // scales whose last reader was that de-quantisation
+      if (i == 0) {
+        q_load_sb<C, SL>(lds, R, 1, ro);
+        R.sa[3] = q_scale<C, SL>(lds, R, p_row(3) * PITCH, ro);
+      }
+      if (!LAST) {
+        if (i == 4) q_load_sb<C, NX>(lds, R, 0, rn);
+        if (i >= 5) R.sa[dtb] = q_scale<C, NX>(lds, R, p_row(dtb) * PITCH, rn);
+      }
+    }
+  }
+}
+
+// ABL (tools build only): 1 = no LDS-DMA after the prologue, 2 / 4 / 8 as q_step, 16 = no barrier in the K steps (the wait only)
+template <class C, bool TR = false, int ABL = 0>
+__global__ __launch_bounds__(C::NT * 2, 2) void gemm_w4a4_f6qk_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  unsigned *trb = nullptr;
+  auto kstamp = [&](int k) {
+    if constexpr (TR) {
+      if (trb) { const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) trb[k] = t; }
+    }
+  };
+  if constexpr (TR) {
+    if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
+      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 64;
+      if ((threadIdx.x & 63) == 0) trb[62] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
+    kstamp(0);
+  }
+  static_assert(C::BM == 128 && C::BN == 128 && C::WM == 64 && C::NS == 3 && C::NW == 4 && C::FS32, "qk kernel: 128x128, 2 x 4 waves of 64 x 64");
+  using Q = QC<C>;
+  static_assert(Q::STAGE == C::STAGE_BYTES && 6 * Q::STAGE <= 160 * 1024, "qk kernel: stage layout");
+  constexpr int NTB = 4, RING = 3 * Q::STAGE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave_all >= 0 && wave_all < 8);
+  const int kg = wave_all >> 2, wave = wave_all & 3;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ring0 = kg * RING;                             // this group's ring inside the workgroup's LDS (dynamic LDS starts at 0)
+  const char *lds = lds_all;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[4][NTB][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NTB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
+
+  // compute steps of this group: n4 int4 groups from s_begin, then (upper group) the keeper
+  const int G = p.G, csteps = G + 1;
+  const int s_begin = csteps * kg / 2, c_end = csteps * (kg + 1) / 2;
+  const bool has_keeper = kg == 1;
+  const int n4 = min(c_end, G) - s_begin;                  // >= 2 (the dispatch sends G >= 7 here)
+  QkDma d;
+  d.voff = (unsigned)(wave * 3072 + lane * 16);
+  d.m0W = ring0 + wave * 3072;
+  d.m0A = ring0 + C::A_OFF + wave * 3072;
+  d.xkind = wave == 0 ? 1 : (wave == 1 ? 2 : 3);
+  d.voffX = (unsigned)(wave < 2 ? 12 * 1024 + lane * 16 : (wave & 1) * 256 + lane * 4);
+  d.m0X = ring0 + (wave == 0 ? 12 * 1024 : (wave == 1 ? C::A_OFF + 12 * 1024 : Q::SB_OFF + (wave & 1) * 256));
+  const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
+  const uint8_t *wsrc0 = p.B4 + ((int64_t)s_begin * p.f6_rows_b + n0) * PITCH, *asrc0 = p.A4 + ((int64_t)s_begin * p.f6_rows_a + m0) * PITCH;
+  const float *sbsrc0 = p.sB32 + (int64_t)s_begin * p.f6_rows_b + n0;
+  auto slot_of = [&](int stage) { return lds_all + ring0 + (stage % 3) * Q::STAGE; };    // local stage index
+  auto issue_stage = [&](int t, int so) {                  // every piece of this group's int4 stage t into the slot at byte offset so
+#pragma unroll
+    for (int i = 0; i < 3; ++i) qk_piece<C>(d, wsrc0 + t * wstep, asrc0 + t * astep, sbsrc0 + (int64_t)t * p.f6_rows_b, so, i);
+  };
+  // Prologue: stage 0 only where the group has enough steps for the LDS-DMA of stage 1 to go out behind the MFMAs of step 0's first
+  // half (published by that step's mid-step barrier, where its first reader sits), as in the q kernel
+  const bool early1 = n4 >= 5;                             // (steps 0..2 are regular ones)
+  issue_stage(0, 0);
+  if (!early1) issue_stage(1, Q::STAGE);
+  kstamp(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  kstamp(2);
+
+  const int l15 = lane & 15, kb = lane >> 4;
+  QkRegs<C> R;
+  {
+    const int lw = ring0 + wn * 64 * PITCH + l15 * (2 * PITCH) + kb * 24;
+    const int la = ring0 + C::A_OFF + wm * 64 * PITCH + l15 * (2 * PITCH);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        R.aW[st][k] = lw + 8 * k + st * 2 * Q::STAGE;
+        R.aA[st][k] = la + kb * 24 + 8 * k + st * 2 * Q::STAGE;
+        asm volatile("" : "+v"(R.aW[st][k]), "+v"(R.aA[st][k]));
+      }
+      R.aS[st] = la + 100 + st * 2 * Q::STAGE;
+      R.aB[st] = ring0 + (wn * 64 + 8 * kb) * 4 + st * 2 * Q::STAGE;
+      asm volatile("" : "+v"(R.aS[st]), "+v"(R.aB[st]));
+    }
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) R.bf[tb] = q_frag<C, 0>(lds, R.aA, p_row(tb) * PITCH, 0);
+    R.af[0] = q_frag<C, 0>(lds, R.aW, p_row(0) * PITCH, 0);
+    R.af[1] = q_frag<C, 0>(lds, R.aW, p_row(1) * PITCH, 0);
+    R.af[2] = R.af[1];                                      // (slot 0 of every step loads fb 2,3)
+    R.af[3] = R.af[1];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) R.sa[tb] = q_scale<C, 0>(lds, R, p_row(tb) * PITCH, 0);
+    R.sa[3] = 0.f;                                          // the "carried pair" of the first step: zeros x 0
+    q_load_sb<C, 0>(lds, R, 0, 0);
+    q_load_sb<C, 0>(lds, R, 1, 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) R.acc[1][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
+  }
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+  };
+  // local step t on slot SL: the LDS-DMA of this group's int4 stage t + 2 behind the mid-step barrier
+  auto reg = [&](auto sl, int t) {
+    constexpr int SL = decltype(sl)::value;
+    if constexpr (TR) { if (t < 44) kstamp(16 + t); }
+    const int g = t + 2;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    qk_step<C, SL, ABL>(R, lds, c, sync, [&](int i) { if constexpr (!(ABL & 1)) qk_piece<C>(d, wsrc, asrc, sbsrc, ((SL + 2) % 3) * Q::STAGE, i); });
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int t = 0;
+  kstamp(3);
+  if (early1) {                                             // step 0: + the LDS-DMA of stage 1 in its first half
+    if constexpr (TR) kstamp(16);
+    const uint8_t *wsrc = wsrc0 + 2 * wstep, *asrc = asrc0 + 2 * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)2 * p.f6_rows_b;
+    qk_step<C, 0, ABL>(R, lds, c, sync, [&](int i) { if constexpr (!(ABL & 1)) qk_piece<C>(d, wsrc, asrc, sbsrc, 2 * Q::STAGE, i); }, 0, 0, false,
+                       [&](int i) { if constexpr (!(ABL & 1)) qk_piece<C>(d, wsrc0 + wstep, asrc0 + astep, sbsrc0 + p.f6_rows_b, Q::STAGE, i); });
+    reg(S1(), 1);
+    reg(S2(), 2);
+    t = 3;
+  }
+  for (; t + 4 < n4; t += 3) { reg(S0(), t); reg(S1(), t + 1); reg(S2(), t + 2); }
+  // the last 2..4 int4 steps of the group on one generic body (run-time slots): their LDS-DMA is an int4 stage, a keeper half
+  // (upper group) or nothing; the very last one has no next int4 stage to prefetch from.  (Compile-time slots for these too -- three
+  // bodies with wave-uniform branches around the LDS-DMA and the next-stage loads -- spill 287 VGPRs.)
+  for (; t < n4; ++t) {
+    if constexpr (TR) { if (t < 44) kstamp(16 + t); }
+    const int g = t + 2;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    qk_step<C, -1, ABL>(R, lds, c, sync,
+                        [&](int i) {
+                          if constexpr (ABL & 1) return;
+                          if (g < n4) qk_piece<C>(d, wsrc, asrc, sbsrc, (g % 3) * Q::STAGE, i);
+                          else if (has_keeper && i == 0) issue_keeper<C>(p, g - n4, slot_of(g), wave, lane, m0, n0);
+                        },
+                        (t % 3) * Q::STAGE, ((t + 1) % 3) * Q::STAGE, t + 1 == n4);
+  }
+  {                                                         // the carried pair (last slot) of the last int4 step
+    const float sa = R.sa[3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[2 + k][NTB - 1][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][NTB - 1][r]);
+  }
+  int nbar = 1 + ((ABL & 16) ? 0 : n4);
+  kstamp(4);
+  if (has_keeper) {                                         // half 0 was published by the last mid-step barrier; half 1 was issued behind it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ++nbar;
+    kstamp(5);
+    q_keeper<C, false>(p, slot_of(n4), slot_of(n4 + 1), wm, wn, lane, c, m0, n0);
+  }
+  kstamp(6);
+  // barriers so far: prologue + one per int4 step (+ the keeper's); the other group's count, from its range
+  {
+    const int ob = csteps * (1 - kg) / 2, oe = csteps * (2 - kg) / 2;
+    const int other = 1 + ((ABL & 16) ? 0 : min(oe, G) - ob) + (kg == 0 ? 1 : 0);
+    for (; nbar < other; ++nbar) __builtin_amdgcn_s_barrier();
+  }
+  __builtin_amdgcn_s_barrier();                             // every wave is done with the rings
+  kstamp(7);
+
+  // ---- exchange: 2 token blocks x 4 feature blocks x 4 = 32 floats per lane to the partner wave (same wm, wn) of the other group
+  float *xw = reinterpret_cast<float *>(lds_all) + (kg * 4 + wave) * (32 * 64) + lane;
+  const float *xr = reinterpret_cast<const float *>(lds_all) + ((1 - kg) * 4 + wave) * (32 * 64) + lane;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = kg == 0 ? c[fb][2 + tt][r] : c[fb][tt][r];
+        xw[((tt * 4 + fb) * 4 + r) * 64] = v;
+      }
+  __builtin_amdgcn_s_barrier();
+  kstamp(8);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    float mine[4][4], other[4][4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        other[fb][r] = xr[((tt * 4 + fb) * 4 + r) * 64];
+        mine[fb][r] = kg == 0 ? c[fb][tt][r] : c[fb][2 + tt][r];
+      }
+    const int tb = 2 * kg + tt;
+    const int m = m0 + wm * 64 + p_row(tb) + 2 * l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + wn * 64 + 32 * h + 8 * kb;
+      if (n >= p.N) continue;
+      v4u o;
+      half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float lo = kg == 0 ? mine[2 * h + k][r] : other[2 * h + k][r], hi = kg == 0 ? other[2 * h + k][r] : mine[2 * h + k][r];
+          ov[2 * r + k] = f2h(lo + hi);
+        }
+      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n) = o;
+    }
+  }
+  if constexpr (TR) {
+    kstamp(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    kstamp(10);
+    if (trb && (threadIdx.x & 63) == 0) trb[63] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  }
+}
+
+template <class C, bool TR = false, int ABL = 0>
+static int launch_qk(const GemmParams &p, hipStream_t s) {
+  static std::atomic<uint64_t> attr_done{0};
+  constexpr int LDS = 6 * QC<C>::STAGE;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6qk_kernel<C, TR, ABL>), LDS, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6qk_kernel<C, TR, ABL>), dim3((unsigned)(nbm * nbn)), dim3(C::NT * 2), LDS, s, p);
+  return check_launch();
+}
+
 template <class C, int ABL = 0>
 static int launch_p(const GemmParams &p, hipStream_t s) {
   constexpr int lds_bytes = C::LDS_BYTES + ((ABL & 16) ? 8 * 80 * 4 : 0);
@@ -1913,6 +2272,19 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (cfg == 1005) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2, false, true>(q, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, false, true>(q, s);
   }
+  switch (cfg) {   // 2100 + ablation mask on the two-K-group q-step kernel
+#define ATOM_ABL(a) case 2100 + a: return p.sB32 ? f6::launch_qk<f6::Cfg<128, 128, 2, 3, 3, 1>, false, a>(p, s) : ATOM_ERR_INVALID_ARG;
+    ATOM_ABL(0) ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(4) ATOM_ABL(8) ATOM_ABL(16) ATOM_ABL(17) ATOM_ABL(6) ATOM_ABL(14) ATOM_ABL(15) ATOM_ABL(31)
+    ATOM_ABL(3) ATOM_ABL(5) ATOM_ABL(9) ATOM_ABL(7) ATOM_ABL(11) ATOM_ABL(13)
+#undef ATOM_ABL
+  }
+  if (cfg == 2017) {   // traced run of the two-K-group q-step kernel (tools/trace_f6q.cpp qk)
+    const char *e = getenv("ATOM_TRACE_PTR");
+    if (!e || !p.sB32) return ATOM_ERR_INVALID_ARG;
+    GemmParams q = p;
+    q.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+    return f6::launch_qk<f6::Cfg<128, 128, 2, 3, 3, 1>, true>(q, s);
+  }
   if (cfg == 2016) {   // traced run of the q kernel (tools/trace_f6q.cpp)
     const char *e = getenv("ATOM_TRACE_PTR");
     if (!e || !p.sB32) return ATOM_ERR_INVALID_ARG;
@@ -1956,6 +2328,8 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   }
   // two K groups of 4 waves per workgroup: for shapes that put at most one tile on a CU (f6_pick_cfg)
   if (cfg == 5 || cfg == 6) {                                                  // 128x128; 2 (tuning) / 3 stages per group
+    // float32 weight scales (ATOM_B_F6S) and a K long enough for its unrolled loop: the q kernel's K step per group (same sums)
+    if (cfg == 6 && p.sB32 && p.G >= 7 && ATOM_TUNE("ATOM_QK", 1)) return f6::launch_qk<f6::Cfg<128, 128, 2, 3, 3, 1>>(p, s);
     if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
                                 : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
     return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);

@@ -510,6 +510,29 @@ def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
     assert seen == {1, 2, 4}
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 4096), (1000, 4096, 1152), (700, 3968, 2176), (1024, 4096, 1024), (130, 16384, 1280)])
+def test_gemm_f6_two_k_group_kernel_bit_exact(M, N, K):
+    """Shapes with at most one 128x128 tile per CU run the two-K-group kernel with the q kernel's K step (gemm_w4a4_f6qk_kernel:
+    odd / even numbers of int4 groups, the shortest K it takes, ragged tiles in both dimensions): the whole output bit for bit
+    against the C restatement with the K steps summed in two ordered ranges (atom_gemm_w4a4_f6_order == 2)."""
+    from tests import c_oracle
+    from tests.helpers import f6_codes
+    ops = _ops()
+    assert ops.L.lib().atom_gemm_w4a4_f6_order(M, N, K) == 2
+    d = rand_gemm_operands(M, N, K, seed=77)
+    t = to_device(d, "plain")
+    a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+    b6 = ops.repack_weight_f6(t[1], t[3])
+    out = ops.dense_layer_gemm_i4_fp16(a6, b6, *t[2:], scale_layout="plain", a_wide="f6")
+    assert_gemm_close(t2n(out), _exact(d), f"qk {M}x{N}x{K}")
+    rows = np.unique(np.r_[0:M:7, M - 70:M])
+    want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-2)
+    assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
+    if ops.L.lib().atom_gemm_w4a4_ws_recodes(M, N, K):                        # the reference's operand format: re-coded, same kernel
+        assert torch.equal(ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"), out)
+
+
 def test_packed_route_weight_cached_in_workspace():
     """ATOM_WS_WEIGHT_CACHED: on the re-coding route of atom_gemm_w4a4_f16_ws (packed operands of prefill size) the weight's F6 form
     stays at the start of the caller's workspace; atom_amd.ops passes the flag when the same weight (storage + version counters)

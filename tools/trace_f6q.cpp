@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <random>
 #include "../include/atom_hip.h"
 int main(int argc, char **argv) {
   int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
+  const bool qk = argc > 4 && !strcmp(argv[4], "qk");       // the two-K-group kernel (ATOM_F6_CFG=2017)
   int K4 = K - 128, G = K4 / 128;
   std::mt19937_64 rng(1);
   auto sc = [&]() { return (_Float16)(0.005f + 0.045f * ((rng() >> 11) * (1.0 / 9007199254740992.0))); };
@@ -27,7 +29,7 @@ int main(int argc, char **argv) {
   void *D; (void)hipMalloc(&D, (size_t)M * N * 2);
   const size_t TR = 2 * 8 * 64;
   unsigned *tr; (void)hipMalloc(&tr, TR * 4); (void)hipMemset(tr, 0, TR * 4);
-  char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)tr); setenv("ATOM_TRACE_PTR", buf, 1); setenv("ATOM_F6_CFG", "2016", 1);
+  char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)tr); setenv("ATOM_TRACE_PTR", buf, 1); setenv("ATOM_F6_CFG", qk ? "2017" : "2016", 1);
   const int layout = ATOM_AB_F6 | ATOM_B_F6S | ATOM_SCALE_LAYOUT_PLAIN;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 300; ++i) { int st = atom_gemm_w4a4_f16(A6, B6, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout, nullptr); if (st) { printf("err %d\n", st); return 1; } }
@@ -38,6 +40,27 @@ int main(int argc, char **argv) {
   printf("traced build: %.2f us per launch (200 launches)\n", ms * 1e3 / 200);
   std::vector<unsigned> h(TR); (void)hipMemcpy(h.data(), tr, TR * 4, hipMemcpyDeviceToHost);
   auto d = [&](unsigned a, unsigned b) { return (int)(a - b); };
+  if (qk) {
+    for (int wg = 0; wg < 2; ++wg) {
+      const unsigned t00 = h[wg * 8 * 64];
+      printf("workgroup %s\n", wg ? "last" : "0");
+      for (int w = 0; w < 8; ++w) {
+        unsigned *e = &h[(wg * 8 + w) * 64];
+        printf(" group %d wave %d: entry %+d | dma issued +%d | stages 0,1 landed +%d | first fragments +%d | int4 loop +%d | keeper barrier +%d | keeper +%d | "
+               "catch-up + ring barrier +%d | exchange written + barrier +%d | sums + stores issued +%d | stores done +%d | total %d cycles = %.2f us, %.0f MHz\n",
+               w / 4, w % 4, d(e[0], t00), d(e[1], e[0]), d(e[2], e[1]), d(e[3], e[2]), d(e[4], e[3]), w < 4 ? 0 : d(e[5], e[4]), w < 4 ? d(e[6], e[4]) : d(e[6], e[5]),
+               d(e[7], e[6]), d(e[8], e[7]), d(e[9], e[8]), d(e[10], e[9]), d(e[10], e[0]), d(e[63], e[62]) / 100.0, 100.0 * d(e[10], e[0]) / (double)d(e[63], e[62]));
+      }
+      for (int w = 0; w < 8; w += 4) {
+        unsigned *e = &h[(wg * 8 + w) * 64];
+        const int n4 = w == 0 ? (G + 1) / 2 : G - (G + 1) / 2;
+        printf(" group %d wave 0, K steps (cycles):", w / 4);
+        for (int s2 = 0; s2 + 1 < n4 && s2 < 43; ++s2) printf(" %d", d(e[16 + s2 + 1], e[16 + s2]));
+        printf(" | last %d\n", d(e[4], e[16 + n4 - 1]));
+      }
+    }
+    return 0;
+  }
   for (int wg = 0; wg < 2; ++wg) {
     const unsigned t00 = h[wg * 8 * 64];
     printf("workgroup %s\n", wg ? "last" : "0");
