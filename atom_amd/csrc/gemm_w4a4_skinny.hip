@@ -26,6 +26,8 @@
 // block loop is bound by what a wave ISSUES per block (widening both operands, the scale loads, address arithmetic: ~170
 // instructions at ~5.5 cycles each with two waves per SIMD), not by memory: the next step for 64+ tokens is a tile kernel whose
 // operands arrive widened (the F6 K-group kernels already take over at 256 rows), not another variant of this loop.
+// Nor is it instruction fetch of the unrolled copies: the token blocks as a run-time loop (one block's code, a block's sums parked
+// in LDS as soon as it is done, 114 VGPRs) measured 7.1 / 11.0 / 18.7 us at 64 / 128 / 256 tokens against 6.4 / 9.5 / 15.5 (same box).
 // Replaces the M = 16..256 rows of the reference's NVBench sweep (kernels/src/GEMM/bench_dense_layer_gemm_i4_o16.cu:64-69),
 // which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
 #include <cstdlib>
