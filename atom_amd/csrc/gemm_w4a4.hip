@@ -59,6 +59,10 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   if (steps >= 16 && t64 <= 256) return 12;               // ... four groups on a 64x128 tile (K = 4096: 17.9 -> 15.0 us at 256 rows)
   if (steps >= 8 && t64 <= 256) return 9;
   if (steps >= 8 && t128 <= 256) return 6;
+  // more 128x128 tiles than CUs, but at most one 256x128 tile per CU and more than half of them busy: the 256x128 q-step kernel
+  // (ATOM_B_F6S weights; launch_gemm_f6 runs the 128x128 geometry otherwise -- same K order)
+  const int64_t t2 = ((M + 255) / 256) * ((N + 127) / 128);
+  if (steps >= 6 && t2 > 128 && t2 <= 256 && ATOM_TUNE("ATOM_Q2", 1)) return 8;
   return 3;
 }
 

@@ -2096,8 +2096,9 @@ __global__ __launch_bounds__(C::NT * 2, 2) void gemm_w4a4_f6qk_kernel(GemmParams
   }
   for (; t + 4 < n4; t += 3) { reg(S0(), t); reg(S1(), t + 1); reg(S2(), t + 2); }
   // the last 2..4 int4 steps of the group on one generic body (run-time slots): their LDS-DMA is an int4 stage, a keeper half
-  // (upper group) or nothing; the very last one has no next int4 stage to prefetch from.  (Compile-time slots for these too -- three
-  // bodies with wave-uniform branches around the LDS-DMA and the next-stage loads -- spill 287 VGPRs.)
+  // (upper group) or nothing; the very last one has no next int4 stage to prefetch from.  (Compile-time slots for these too spill:
+  // three bodies with wave-uniform branches around the LDS-DMA and the next-stage loads 287 VGPRs, one straight-line sequence of
+  // compile-time bodies per remainder n4 % 3 -- no condition inside a step -- 237: it is the joins of the big register state.)
   for (; t < n4; ++t) {
     if constexpr (TR) { if (t < 44) kstamp(16 + t); }
     const int g = t + 2;
@@ -2195,6 +2196,178 @@ static int launch_qk(const GemmParams &p, hipStream_t s) {
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6qk_kernel<C, TR, ABL>), LDS, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
   hipLaunchKernelGGL((gemm_w4a4_f6qk_kernel<C, TR, ABL>), dim3((unsigned)(nbm * nbn)), dim3(C::NT * 2), LDS, s, p);
+  return check_launch();
+}
+
+// ================================================================================================================
+// The 256x128 kernel ("q2"): 256 tokens x 128 features, 8 waves of 64 x 64 on ONE 3-stage ring, qk_step as its K step, the K steps in
+// order (the q kernel's sums, atom_gemm_w4a4_f6_order = 1), fp16 rows stored from inside the keeper step.  For shapes between the
+// two-K-group kernels and the 256x256 kernel: more than 128 but at most 256 tiles of 256x128 (2048 x 4096: 128 tiles of 256x256 leave
+// half of the CUs idle).  Per wave and stage: 3 consecutive activation pieces, 1 weight piece, and one extra -- the remaining five
+// weight pieces on waves 0-4, the remaining two activation pieces on waves 5, 6, the 128 float32 weight scales (two dword pieces) on 7.
+struct Q2Dma {
+  unsigned voffA, voffW, voffX;   // lane offsets from the stage's activation / weight / extra base
+  int m0A, m0W, m0X;              // LDS byte offsets of the wave's pieces inside a stage
+  int xkind;                      // extra: 1 weight rows, 2 activation rows, 3 weight scales
+};
+template <class C>
+__device__ __forceinline__ void q2_piece(const Q2Dma &d, const uint8_t *wsrc, const uint8_t *asrc, const float *sbsrc, int so, int i) {
+  if (i == 0) q_dma16x3(so + d.m0A, d.voffA, asrc);
+  else if (i == 1) q_dma16(so + d.m0W, d.voffW, wsrc);
+  else if (i == 2) {
+    if (d.xkind == 3) {
+      q_dma4(so + d.m0X, d.voffX, sbsrc);
+      q_dma4(so + d.m0X + 256, d.voffX + 256, sbsrc);
+    } else {
+      q_dma16(so + d.m0X, d.voffX, d.xkind == 1 ? (const void *)wsrc : (const void *)asrc);
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6q2_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(C::BM == 256 && C::BN == 128 && C::WM == 64 && C::NS == 3 && C::NW == 8 && C::FS32, "q2 kernel: 256x128, 8 waves of 64 x 64");
+  using Q = QC<C>;
+  static_assert(Q::STAGE == C::STAGE_BYTES, "q2 kernel: stage layout");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 8);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + C::BN - 1) / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+  const int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  constexpr int GM = 4;
+  const int band = id / (GM * nbn), inband = id % (GM * nbn);
+  const int rows_in_band = min(GM, nbm - band * GM);
+  const int bm = band * GM + inband % rows_in_band, bn = inband / rows_in_band;
+  const int m0 = bm * C::BM, n0 = bn * C::BN;
+
+  float c[4][4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[a][b][r] = 0.f;
+
+  const int G = p.G;                                        // stages 0..G-1: int4 groups; G, G+1: keeper halves
+  Q2Dma d;
+  d.voffA = (unsigned)(wave * 3072 + lane * 16);
+  d.m0A = C::A_OFF + wave * 3072;
+  d.voffW = (unsigned)(wave * 1024 + lane * 16);
+  d.m0W = wave * 1024;
+  d.xkind = wave < 5 ? 1 : (wave < 7 ? 2 : 3);
+  d.voffX = (unsigned)(wave < 5 ? (8 + wave) * 1024 + lane * 16 : (wave < 7 ? (24 + wave - 5) * 1024 + lane * 16 : lane * 4));
+  d.m0X = wave < 5 ? (8 + wave) * 1024 : (wave < 7 ? C::A_OFF + (24 + wave - 5) * 1024 : Q::SB_OFF);
+  const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
+  const uint8_t *wsrc0 = p.B4 + (int64_t)n0 * PITCH, *asrc0 = p.A4 + (int64_t)m0 * PITCH;
+  const float *sbsrc0 = p.sB32 + n0;
+  auto slot_of = [&](int stage) { return lds + (stage % 3) * Q::STAGE; };
+  auto issue_stage = [&](int g, int so) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q2_piece<C>(d, wsrc0 + g * wstep, asrc0 + g * astep, sbsrc0 + (int64_t)g * p.f6_rows_b, so, i);
+  };
+  const bool early1 = G >= 5;                               // (steps 0..2 are regular ones)
+  issue_stage(0, 0);
+  if (!early1) {
+    if (G >= 2) issue_stage(1, Q::STAGE);
+    else issue_keeper<C>(p, 0, slot_of(1), wave, lane, m0, n0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int l15 = lane & 15, kb = lane >> 4;
+  QkRegs<C> R;
+  {
+    const int lw = wn * 64 * PITCH + l15 * (2 * PITCH) + kb * 24;
+    const int la = C::A_OFF + wm * 64 * PITCH + l15 * (2 * PITCH);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        R.aW[st][k] = lw + 8 * k + st * 2 * Q::STAGE;
+        R.aA[st][k] = la + kb * 24 + 8 * k + st * 2 * Q::STAGE;
+        asm volatile("" : "+v"(R.aW[st][k]), "+v"(R.aA[st][k]));
+      }
+      R.aS[st] = la + 100 + st * 2 * Q::STAGE;
+      R.aB[st] = (wn * 64 + 8 * kb) * 4 + st * 2 * Q::STAGE;
+      asm volatile("" : "+v"(R.aS[st]), "+v"(R.aB[st]));
+    }
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) R.bf[tb] = q_frag<C, 0>(lds, R.aA, p_row(tb) * PITCH, 0);
+    R.af[0] = q_frag<C, 0>(lds, R.aW, p_row(0) * PITCH, 0);
+    R.af[1] = q_frag<C, 0>(lds, R.aW, p_row(1) * PITCH, 0);
+    R.af[2] = R.af[1];
+    R.af[3] = R.af[1];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) R.sa[tb] = q_scale<C, 0>(lds, R, p_row(tb) * PITCH, 0);
+    R.sa[3] = 0.f;
+    q_load_sb<C, 0>(lds, R, 0, 0);
+    q_load_sb<C, 0>(lds, R, 1, 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) R.acc[1][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
+  }
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto reg = [&](auto sl, int s) {
+    constexpr int SL = decltype(sl)::value;
+    const int g = s + 2;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    qk_step<C, SL>(R, lds, c, sync, [&](int i) { q2_piece<C>(d, wsrc, asrc, sbsrc, ((SL + 2) % 3) * Q::STAGE, i); });
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int s = 0;
+  if (early1) {                                             // step 0: + the LDS-DMA of stage 1 in its first half
+    const uint8_t *wsrc = wsrc0 + 2 * wstep, *asrc = asrc0 + 2 * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)2 * p.f6_rows_b;
+    qk_step<C, 0>(R, lds, c, sync, [&](int i) { q2_piece<C>(d, wsrc, asrc, sbsrc, 2 * Q::STAGE, i); }, 0, 0, false,
+                  [&](int i) { q2_piece<C>(d, wsrc0 + wstep, asrc0 + astep, sbsrc0 + p.f6_rows_b, Q::STAGE, i); });
+    reg(S1(), 1);
+    reg(S2(), 2);
+    s = 3;
+  }
+  for (; s + 4 < G; s += 3) { reg(S0(), s); reg(S1(), s + 1); reg(S2(), s + 2); }
+  for (; s < G; ++s) {                                      // the last 2..4 steps: one generic body (see the q kernel)
+    const int g = s + 2;
+    const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
+    const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
+    qk_step<C, -1>(R, lds, c, sync,
+                   [&](int i) {
+                     if (g < G) q2_piece<C>(d, wsrc, asrc, sbsrc, (g % 3) * Q::STAGE, i);
+                     else if (i == 0) issue_keeper<C>(p, g - G, slot_of(g), wave, lane, m0, n0);
+                   },
+                   (s % 3) * Q::STAGE, ((s + 1) % 3) * Q::STAGE, s + 1 == G);
+  }
+  {                                                         // the carried pair (last slot) of the last int4 step
+    const float sa = R.sa[3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[2 + k][3][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][3][r]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  q_keeper<C, true>(p, slot_of(G), slot_of(G + 1), wm, wn, lane, c, m0, n0);
+}
+
+template <class C>
+static int launch_q2(const GemmParams &p, hipStream_t s) {
+  static std::atomic<uint64_t> attr_done{0};
+  constexpr int LDS = 3 * QC<C>::STAGE;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q2_kernel<C>), LDS, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
+  hipLaunchKernelGGL((gemm_w4a4_f6q2_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), LDS, s, p);
   return check_launch();
 }
 
@@ -2333,6 +2506,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
                                 : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
     return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
+  }
+  if (cfg == 8) {                                                              // 256x128, qk_step, K steps in order
+    if (p.sB32 && p.G >= 2) return f6::launch_q2<f6::Cfg<256, 128, 2, 3, 2, 1>>(p, s);
+    cfg = 3;                                                                   // fp16 weight scales: the 128x128 geometry (same order)
   }
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);

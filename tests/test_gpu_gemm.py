@@ -533,6 +533,29 @@ def test_gemm_f6_two_k_group_kernel_bit_exact(M, N, K):
         assert torch.equal(ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"), out)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 1152), (1500, 4096, 4096), (2048, 3968, 896), (520, 13824, 1280), (1030, 8192, 2176)])
+def test_gemm_f6_256x128_kernel_bit_exact(M, N, K):
+    """Shapes with more 128x128 tiles than CUs but at most 256 tiles of 256x128 run the 256x128 q-step kernel when the weight carries
+    its fp32 scales (gemm_w4a4_f6q2_kernel; ragged tiles in both dimensions, 6..33 int4 groups): the K steps in order -- bit for bit
+    against the C restatement on sampled rows, and the whole output against the same weight without the appended scales (the
+    128x128 geometry, same order)."""
+    from tests import c_oracle
+    from tests.helpers import f6_codes
+    ops = _ops()
+    assert ops.L.lib().atom_gemm_w4a4_f6_order(M, N, K) == 1
+    d = rand_gemm_operands(M, N, K, seed=78)
+    t = to_device(d, "plain")
+    a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
+    out = ops.dense_layer_gemm_i4_fp16(a6, ops.repack_weight_f6(t[1], t[3]), *t[2:], scale_layout="plain", a_wide="f6")
+    assert_gemm_close(t2n(out), _exact(d), f"q2 {M}x{N}x{K}")
+    rows = np.unique(np.r_[0:M:11, M - 70:M])
+    want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"])
+    assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
+    plain = ops.dense_layer_gemm_i4_fp16(a6, ops.repack_weight_f6(t[1]), *t[2:], scale_layout="plain", a_wide="f6")
+    assert torch.equal(plain, out)
+
+
 def test_packed_route_weight_cached_in_workspace():
     """ATOM_WS_WEIGHT_CACHED: on the re-coding route of atom_gemm_w4a4_f16_ws (packed operands of prefill size) the weight's F6 form
     stays at the start of the caller's workspace; atom_amd.ops passes the flag when the same weight (storage + version counters)
