@@ -199,12 +199,17 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
 }
 
 // Packed operands of prefill size: re-code both into the F6 format (one bandwidth-bound launch, ~12 us with its launch gap at
-// N = K = 4096) and run the block-scaled-MFMA kernels: 65-68 instead of 92 us at 4096^3.  From 768 rows since the two-K-group
-// kernels (tools/r02/packed_route_probe.py: 1024x4096x4096 36.6 us against 44.9 on the INT8 tile kernels, 768x..: 35.6 / 42.7;
-// 512x..: 31.6 against 31.1 for the INT8 kernel with split-K -- break-even, left there).
+// N = K = 4096; the activation alone, 3-6 us, once the weight's form is cached in the caller's workspace: ATOM_WS_WEIGHT_CACHED) and
+// run the block-scaled-MFMA kernels: 59-68 instead of 106 us at 4096^3.  From 257 rows, and from 129 where the decode-batch kernel
+// does not take the shape (profiles/r03_packed_route.txt, INT8 kernels | route, weight cached | not cached, us: 384x4096x4096 28.5 |
+// 20.6 | 27.6, 512x.. 29.6 | 21.6 | 29.1, 768x.. 37.4 | 26.3 | 32.3, 512x11008x4096 49.9 | 35.5 | 44.3, 256x11008x4096 36.2 | 25.3 |
+// 34.8; at 256x4096x4096 the decode-batch kernel's 15.8 stands against 19.6 | 25.3).  Round 2 drew the line at 768 rows, with the
+// weight re-coded by every call.
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
   const int off = ATOM_TUNE("ATOM_NO_F6_ROUTE", 0);
-  return !off && M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 768) && N >= 2048 && K_total >= 1024;
+  if (off || N < 2048 || K_total < 1024) return false;
+  if (M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 257)) return true;
+  return M > 128 && !skinny_fits(M, N, K_total);
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;

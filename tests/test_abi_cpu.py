@@ -71,6 +71,22 @@ def test_f6_summation_order_query():
     assert order(16, 4096, 4000) == 0 and order(0, 4096, 4096) == 0 and order(16, 32, 4096) == 0
 
 
+def test_packed_route_query():
+    """atom_gemm_w4a4_ws_recodes / atom_gemm_w4a4_workspace_bytes are host-side functions of the shape: packed operands are re-coded to
+    the F6 format in the caller's workspace from 257 rows (N >= 2048, K >= 1024), from 129 where the decode-batch kernel does not
+    take the shape; the workspace holds the weight's records + fp32 scales first, then the activation's records."""
+    from atom_amd import _lib
+    L = _lib.lib()
+    rec, wsb = L.atom_gemm_w4a4_ws_recodes, L.atom_gemm_w4a4_workspace_bytes
+    assert rec(4096, 4096, 4096) == 1 and rec(768, 4096, 4096) == 1 and rec(257, 4096, 4096) == 1 and rec(300, 11008, 4096) == 1
+    assert rec(256, 4096, 4096) == 0 and rec(16, 4096, 4096) == 0 and rec(128, 11008, 4096) == 0
+    assert rec(256, 11008, 4096) == 1                         # 129..256 rows outside the decode-batch kernel's shapes
+    assert rec(4096, 1024, 4096) == 0 and rec(4096, 4096, 896) == 0
+    G = (4096 - 128) // 128
+    assert wsb(300, 4096, 4096) == G * 512 * 104 + G * 4096 * 108
+    assert rec(0, 4096, 4096) == 0 and rec(300, 4096, 4000) == 0
+
+
 def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):
     """Guard against a code-generation trap of hipcc (ROCm 7.2): v_cvt_scalef32_2xpk16_bf6_f32 reads two 16-register sources over
     several passes and writes a 6-register result; the register allocator may place the result INSIDE a source at an offset

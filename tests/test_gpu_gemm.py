@@ -118,7 +118,7 @@ def test_gemm_properties_full_size():
     order = ops.L.lib().atom_gemm_w4a4_f6_order
     assert order(M, N, K) == order(2500, N, K) == 1 and order(1000, N, K) == order(900, N, K) == 2
     assert torch.equal(rows(2500), base[:2500])                 # same summation order (K steps in order): same bits
-    sub = rows(1000)                                            # mid-size batches (packed operands are re-coded to F6 from 768
+    sub = rows(1000)                                            # mid-size batches (packed operands are re-coded to F6 from 257
     assert torch.equal(rows(900), sub[:900])                    # rows): two ordered halves of the K steps
     assert_gemm_close(t2n(sub), t2n(base[:1000]).astype(np.float64), "rows 0..999 in the other summation order")
     r = to_device(d, "ref")

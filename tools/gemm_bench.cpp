@@ -143,6 +143,7 @@ int main(int argc, char **argv) {
   }
 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (getenv("ATOM_WS_CACHED")) layout2 |= ATOM_WS_WEIGHT_CACHED;   // the weight's re-coded form is in `ws` since the call above
   for (int i = 0; i < 5; ++i) atom_gemm_w4a4_f16(Ain, Bin, sA, sB, A8, B8, sA8, sB8, D, M, N, K, 128, 128, layout2, nullptr);
   CK(hipDeviceSynchronize());
   float best = 1e30f, tot = 0;
