@@ -52,7 +52,9 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int64_t t64 = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t rounds = (t256 + 255) / 256, steps = (K_total - kKeeper) / kGroup + 2;
-  if (t256 >= 144 && 5 * t256 >= 3 * rounds * 256) return 0;
+  // (one round: from 129 tiles -- 768x11008x4096, 129 tiles: 47.7 us against 51.6 on 128x128 tiles; with 128 or fewer the 256x128
+  // kernel below has a tile for every CU.  Several rounds: only while >= 60 % of the slots are busy.  profiles/r03_f6_dispatch.txt)
+  if (t256 >= 129 && (rounds == 1 || 5 * t256 >= 3 * rounds * 256)) return 0;
   // at most one tile per CU: a lone 4-wave workgroup is latency-bound (barrier, fragment loads: ~1 us per K step), so two
   // groups of 4 waves share the tile and its K steps (profiles/r02_mid_m.txt: 1024x4096x4096 33.1 -> 23.4 us, 512x..: 26.3 ->
   // 18.4).  The result is the sum of two (four) ordered ranges of the K steps (atom_gemm_w4a4_f6_order).
