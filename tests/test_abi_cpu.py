@@ -116,3 +116,31 @@ def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):
                 overlap = not (d1 < s0 or s1 < d0)
                 assert not overlap or d0 == s0, f"{m.group(0)} in {o.name}: result overlaps a source at an offset"
     assert seen >= 100          # the quantisers, the re-coding kernel and the fused gate/up epilogue all use it
+
+
+def test_no_kernel_keeps_its_tile_in_scratch_memory(tmp_path):
+    """hipcc may demote a register array to scratch (private) memory without reporting a spill -- round 3 met it on the two-K-group GEMM
+    kernel: 134 VGPRs + 272 B of scratch per lane, 8x slower, vgpr_spill_count 0.  The code objects carry the size
+    (.private_segment_fixed_size): none for the tile kernels the dispatch uses, at most a few spilled registers anywhere."""
+    import re
+    import shutil
+    import subprocess
+    from atom_amd import _lib
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not found")
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    sizes = {}
+    for o in sorted(p for p in tmp_path.iterdir() if "gfx950" in p.name):
+        notes = subprocess.run([readelf, "--notes", str(o)], check=True, capture_output=True, text=True).stdout
+        for name, size in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            sizes[name] = int(size)
+    assert len(sizes) > 100
+    for name, size in sizes.items():
+        assert size <= 64, f"{name}: {size} B of scratch per lane"
+        if any(k in name for k in ("gemm_w4a4_f6q_kernel", "gemm_w4a4_f6qk_kernel", "gemm_w4a4_f6q2_kernel", "gemm_w4a4_f6x16_kernel",
+                                   "gemv_w4a4", "act_quant2_kernel", "batch_decode_kernel")):
+            assert size == 0, f"{name}: {size} B of scratch per lane"
