@@ -533,10 +533,11 @@ def test_gemm_f6_two_k_group_kernel_bit_exact(M, N, K):
         assert torch.equal(ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"), out)
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 4096, 1152), (1500, 4096, 4096), (2048, 3968, 896), (520, 13824, 1280), (1030, 8192, 2176)])
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 1152), (1500, 4096, 4096), (2048, 3968, 896), (520, 13824, 1280), (1030, 8192, 2176),
+                                   (2048, 4096, 640)])
 def test_gemm_f6_256x128_kernel_bit_exact(M, N, K):
     """Shapes with more 128x128 tiles than CUs but at most 256 tiles of 256x128 run the 256x128 q-step kernel when the weight carries
-    its fp32 scales (gemm_w4a4_f6q2_kernel; ragged tiles in both dimensions, 6..33 int4 groups): the K steps in order -- bit for bit
+    its fp32 scales (gemm_w4a4_f6q2_kernel; ragged tiles in both dimensions, 4..33 int4 groups): the K steps in order -- bit for bit
     against the C restatement on sampled rows, and the whole output against the same weight without the appended scales (the
     128x128 geometry, same order)."""
     from tests import c_oracle
