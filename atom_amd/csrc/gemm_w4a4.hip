@@ -43,9 +43,11 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   return N * items <= 420000;
 }
 
-// Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt).  256x256 (one workgroup per CU, the q kernel)
-// when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles' work in
-// ~2.4x their time; else 128x128 (three workgroups per CU); 64x128 + split-K only for very few tiles with a long K.
+// Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt, profiles/r03_f6_dispatch.txt -- every geometry forced
+// on a 48-shape grid: this pick is within 1-3 % of the best one).  256x256 (one workgroup per CU, the q kernel) from 129 tiles in one
+// round, or when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles'
+// work in ~2.4x their time; K-group kernels (two / four groups of 4 waves per tile) while a shape yields at most 256 tiles of
+// 128x128 / 64x128; the 256x128 kernel for 129..256 of its tiles; else 128x128 with 4 waves (several workgroups per CU).
 static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   const int force = ATOM_TUNE("ATOM_F6_CFG", -1);
   if (force >= 0) return force;

@@ -1871,8 +1871,6 @@ __device__ __forceinline__ void qk_piece(const QkDma &d, const uint8_t *wsrc, co
   }
 }
 
-// TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
-// [0..9] kernel phases, [16 + t] start of the group's K step t, [62], [63] s_memrealtime (100 MHz) at entry and exit
 // The K step of the two-K-group kernel: q_step's MFMA / de-quantisation stream for a 64 x 64 wave tile -- 8 pair slots, slot i =
 // (token block i % 4, feature-block pair i / 4); all four token fragments stay resident (a 64-token tile has the registers), and every
 // LDS load is issued at least four slots ahead of its first reader:
@@ -1955,7 +1953,9 @@ __device__ __forceinline__ void qk_step(QkRegs<C> &R, const char *lds, float (&c
   }
 }
 
-// ABL (tools build only): 1 = no LDS-DMA after the prologue, 2 / 4 / 8 as q_step, 16 = no barrier in the K steps (the wait only)
+// TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
+// [0..10] kernel phases, [16 + t] start of the group's K step t, [62], [63] s_memrealtime (100 MHz) at entry and exit
+// ABL (tools build only): 1 = no LDS-DMA after the prologue, 2 / 4 / 8 as qk_step, 16 = no barrier in the K steps (the wait only)
 template <class C, bool TR = false, int ABL = 0>
 __global__ __launch_bounds__(C::NT * 2, 2) void gemm_w4a4_f6qk_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
@@ -2421,7 +2421,8 @@ int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s) {
 }
 
 // cfg: 0 = 256x256 (8 waves, the pipelined kernel) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA
-// micro-tiles, 2 = 64x128 (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128,
+// micro-tiles, 5 / 6 / 9 / 12 = the K-group kernels (128x128 / 64x128 tiles, two or four groups of 4 waves), 8 = 256x128 (8 waves,
+// qk_step; ATOM_B_F6S weights, else 3), 2 = 64x128 (2 waves, 32x32x64 MFMA; split-K when p.splits > 1 and p.ws is set); tuning only: 1 = 256x128,
 // 10 / 13 = 256x256 / 128x128 on the 32x32x64 MFMA, 40 = 256x256 first-generation micro-tile kernel
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
 #ifdef ATOM_TOOLS
@@ -2487,6 +2488,10 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
+  if (cfg == 8) {                                                              // 256x128, qk_step, K steps in order
+    if (p.sB32 && p.G >= 2) return f6::launch_q2<f6::Cfg<256, 128, 2, 3, 2, 1>>(p, s);
+    cfg = 3;                                                                   // fp16 weight scales: the 128x128 geometry (same order)
+  }
   if (cfg == 3) {                                                              // 128x128, 4 waves
     // float32 weight scales staged (ATOM_B_F6S): 8 % fewer cycles per tile, but 54,272 B of LDS = two workgroups per CU (the LDS
     // granule makes it 55,040); fp16 scales staged and converted once per step: 53,760 B = three.  The former unless the third
@@ -2506,10 +2511,6 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
                                 : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
     return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
-  }
-  if (cfg == 8) {                                                              // 256x128, qk_step, K steps in order
-    if (p.sB32 && p.G >= 2) return f6::launch_q2<f6::Cfg<256, 128, 2, 3, 2, 1>>(p, s);
-    cfg = 3;                                                                   // fp16 weight scales: the 128x128 geometry (same order)
   }
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
