@@ -59,7 +59,13 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
 // OUT: 0 = fp16 D [M, N]; 1 = FP32 sums to p.ws [M, N] (the u4-epilogue path); 2 = segmented (atom_gemm_w4a4_multi): the features are
 // p.N / p.seg_n segments with their own [M, seg_n] outputs, fp16 or float32 per segment, segment 0 optionally + an fp16 addend
-template <int NW, int MBLK, int CNT, int OUT = 0>
+// NT: the weight loads are non-temporal (global_load ... nt).  Every weight byte is read once, by one CU; with the default policy the
+// stream still allocates in the caches it passes.  For one or two tokens (profiles/r03_decode.txt item 6; HBM-cold, same box, us):
+// 1 x 4096 x 4096 5.33 -> 4.95, 1 x 11008 x 4096 8.6 -> 8.3, the Llama-7B decode layer 70.7 -> 66.4 at batch 1 and 73.6 -> 70.1 at
+// batch 2.  From 4 tokens the large shapes measure 3-8 % SLOWER with it (4 x 11008 x 4096 7.9 -> 8.4, 16 x 11008 x 4096 9.15 -> 9.53)
+// and the layer is unchanged, so larger batches keep the default.  (A weight set that fits the 256 MB Infinity Cache and is replayed
+// -- the "hot" columns -- loses its residency with nt: hot becomes cold.)
+template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
   constexpr bool OUT32 = OUT == 1;
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]
@@ -98,7 +104,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     if (j < ng) {
-      w[j] = *reinterpret_cast<const v4u *>(wbase + j * 64 + woff);
+      const v4u *wp = reinterpret_cast<const v4u *>(wbase + j * 64 + woff);
+      w[j] = NT ? __builtin_nontemporal_load(wp) : *wp;
       sb[j] = *reinterpret_cast<const v2u *>(sbbase + (int64_t)j * p.N * 2 + 8 * kb);
     }
   }
@@ -106,8 +113,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   v2u sbk = {};
   if (keeper) {
     const char *kp = reinterpret_cast<const char *>(p.B8) + (int64_t)n0 * kKeeper + (unsigned)(row * kKeeper + kb * 16);
-    wk[0] = *reinterpret_cast<const v4u *>(kp);
-    wk[1] = *reinterpret_cast<const v4u *>(kp + 64);
+    wk[0] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp)) : *reinterpret_cast<const v4u *>(kp);
+    wk[1] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp + 64)) : *reinterpret_cast<const v4u *>(kp + 64);
     sbk = *reinterpret_cast<const v2u *>(reinterpret_cast<const char *>(p.sB8 + n0) + 8 * kb);
   }
   // ---- token block 0
@@ -214,22 +221,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   }
 }
 
-template <int NW, int MBLK, int CNT, int OUT = 0>
+template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false>
 static int launch(const GemmParams &p, hipStream_t s) {
   constexpr size_t lds = (size_t)NW * MBLK * 64 * 16;
   if constexpr (lds > 64 * 1024) {
     static std::atomic<uint64_t> attr_done{0};
-    if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT>), (int)lds, attr_done) != ATOM_OK)
+    if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT, NT>), (int)lds, attr_done) != ATOM_OK)
       return ATOM_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, MBLK, CNT, OUT, NT>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
 
 template <int NW, int CNT, int OUT = 0>
 static int launch_m(const GemmParams &p, hipStream_t s) {
   const int mblk = (p.M + 15) / 16;
-  if (mblk <= 1) return launch<NW, 1, CNT, OUT>(p, s);
+  if (mblk <= 1) return p.M <= ATOM_TUNE("ATOM_SKINNY_NT_MAXM", 2) ? launch<NW, 1, CNT, OUT, true>(p, s) : launch<NW, 1, CNT, OUT>(p, s);
   if constexpr (!(NW == 8 && CNT == 14)) {              // (that instance spills 14 VGPRs; the 4-block one does not)
     if (mblk <= 2) return launch<NW, 2, CNT, OUT>(p, s);
   }

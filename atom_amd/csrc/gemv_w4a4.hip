@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
           w[r][u] = v4i{0, 0, 0, 0};
           sbh[r][u] = (half_t)0;
           if (ok) {
-            w[r][u] = *reinterpret_cast<const v4i *>(p.B4 + (int64_t)n * K4h + c * 16);
+            w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)n * K4h + c * 16));   // nt: read once, by this CU only (gemm_w4a4_skinny.hip, NT)
             if (leader) sbh[r][u] = p.sB[(int64_t)(c >> 2) * p.N + n];
           }
         }
