@@ -25,6 +25,7 @@ AB_F6 = 0x200              # ATOM_AB_F6
 O4_REF_EXTREMA = 0x800     # ATOM_O4_REF_EXTREMA
 B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
 WS_WEIGHT_CACHED = 0x1000  # ATOM_WS_WEIGHT_CACHED: the workspace already holds this weight's F6 form
+Q_REORDER, Q_RMSNORM, Q_ADD_RMSNORM, Q_SILU_MUL = 1, 2, 3, 4     # atom_gemm_w4a4_multi_q: q_op
 F6_PITCH = 104
 
 _vp = ctypes.c_void_p
@@ -43,6 +44,8 @@ SIGNATURES = {
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_multi_fits": (_int, [_i64, _i64, _int, _i64]),
     "atom_gemm_w4a4_multi": (_int, [_vp] * 11 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _int, _vp]),
+    "atom_gemm_w4a4_multi_q_fits": (_int, [_i64, _i64, _int, _i64]),
+    "atom_gemm_w4a4_multi_q": (_int, [_int] + [_vp] * 5 + [_f32, _f32] + [_vp] * 7 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _vp]),
     "atom_gemm_w4a4_o4": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_o4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_o4_ws": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),

@@ -90,6 +90,14 @@ struct GemmParams {
   const half_t *seg_add;          // optional fp16 [M, seg_n] added to segment 0's fp16 output (the residual stream)
   int seg_n;
   unsigned seg_f32;
+  // atom_gemm_w4a4_multi_q (decode, one or two tokens): the activation operand is produced inside the launch from the fp16 input of
+  // the quantiser that precedes the GEMM (q_op != 0); A4 / sA / A8 / sA8 are not read
+  int q_op;                       // 1 reorder, 2 rmsnorm + reorder, 3 residual add + rmsnorm + reorder, 4 silu(x) * x2
+  const half_t *q_x, *q_x2;       // [M, K_total] input; q_x2: rmsnorm weight [K_total] (2, 3) or the second factor [M, K_total] (4)
+  const half_t *q_res;            // 3: residual [M, K_total]
+  half_t *q_res_out;              // 3: x + residual [M, K_total] (written by workgroup 0; may alias q_res)
+  const int16_t *q_idx;           // reorder index [K_total] or null (1, 2, 3)
+  float q_eps, q_clip;
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
@@ -100,6 +108,7 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
 int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmented outputs (p.seg_*): q/k/v, gate/up, down + residual
+int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s);   // ... + the preceding quantiser inside the launch (p.q_*)
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s);   // ... 256x256 kernel + fused SiLU x up -> quant epilogue
 

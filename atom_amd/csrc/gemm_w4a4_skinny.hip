@@ -32,6 +32,7 @@
 // which runs the 128x128 tensor-core tile kernel for every M (26.7-27.2 us on the RTX 4090).
 #include <cstdlib>
 #include "common.h"
+#include "quant_math.h"
 
 namespace atom {
 namespace skinny {
@@ -56,6 +57,9 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
   for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], (float)hv[r], c[r]);
 }
 
+// fused quantiser (QOP): byte offset of red[4] (then the row buffer) behind the packed operand of MQ = 2 rows in LDS
+__host__ __device__ inline int q_red_offset(int K4h, int G) { return (2 * K4h + 2 * kKeeper + 2 * G * 2 + 2 * 2 + 15) & ~15; }
+
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
 // OUT: 0 = fp16 D [M, N]; 1 = FP32 sums to p.ws [M, N] (the u4-epilogue path); 2 = segmented (atom_gemm_w4a4_multi): the features are
 // p.N / p.seg_n segments with their own [M, seg_n] outputs, fp16 or float32 per segment, segment 0 optionally + an fp16 addend
@@ -65,10 +69,17 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 // batch 2.  From 4 tokens the large shapes measure 3-8 % SLOWER with it (4 x 11008 x 4096 7.9 -> 8.4, 16 x 11008 x 4096 9.15 -> 9.53)
 // and the layer is unchanged, so larger batches keep the default.  (A weight set that fits the 256 MB Infinity Cache and is replayed
 // -- the "hot" columns -- loses its residency with nt: hot becomes cold.)
-template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false>
+// QOP != 0 (one or two tokens, MBLK == 1; atom_gemm_w4a4_multi_q): the kernel starts with the quantiser that feeds this GEMM in the
+// reference's call order -- reorder (1), RMSNorm + reorder (2), residual add + RMSNorm + reorder (3), SiLU x up (4); punica/models/
+// llama.py:259-292, :85-87 -- run by EVERY workgroup on its own copy of the token rows, behind the weight loads (which are in flight
+// while it runs), and its packed operand stays in LDS.  Same arithmetic as quant_kernels.hip slot by slot (kernel-flavoured mode:
+// Reorder.cuh:137-178, RMSNorm.cuh:112-151, Activate.cuh:112-167) including the fixed-shape FP32 tree of the sum of squares (256
+// threads, chunk c -> wave (c / 64) % 4, lane c % 64): bit-identical to the separate launch, which costs a launch boundary and a
+// round trip through HBM more than the GEMM itself at this size.
+template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false, int QOP = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
   constexpr bool OUT32 = OUT == 1;
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]; QOP: + the quantiser's buffers
   float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -98,34 +109,211 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
     koff[tb] = (unsigned)(m * kKeeper + kb * 16);
   }
 
-  // ---- everything this wave will ever read of the weights, in flight at once
+  // ---- QOP: everything the fused quantiser reads is requested FIRST (one memory round trip for the whole prologue, and its waits
+  // then count only the weight loads issued behind it): the thread's chunks of the token rows / residual rows / norm weights and the
+  // reorder indices (4: the gate / up values) of its slot tasks
+  constexpr int MQ = 2;                                     // rows the fused quantiser handles
+  constexpr int TPT = QOP == 4 ? 3 : 2, XC = 3;             // slot tasks / row chunks per thread at most (checked by the launcher)
+  const int H = 2 * K4h + kKeeper;
+  const int q_nchunks = H >> 3, q_nslots = H >> 4;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  v4u q_ri[QOP ? TPT : 1][2], q_rb[QOP == 4 ? TPT : 1][2];
+  h8 q_xr[QOP && QOP <= 3 ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[QOP == 2 || QOP == 3 ? 2 : 1];
+  if constexpr (QOP != 0) {
+    const int tid = threadIdx.x, ntask = p.M * q_nslots;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      const int task = min(tid + t * NW * 64, ntask - 1), m = task / q_nslots, e0 = (task - m * q_nslots) * 16;
+      if constexpr (QOP == 4) {
+        const half_t *arow = p.q_x + (int64_t)m * H, *brow = p.q_x2 + (int64_t)m * H;
+        q_ri[t][0] = *reinterpret_cast<const v4u *>(arow + e0);
+        q_ri[t][1] = *reinterpret_cast<const v4u *>(arow + e0 + 8);
+        q_rb[t][0] = *reinterpret_cast<const v4u *>(brow + e0);
+        q_rb[t][1] = *reinterpret_cast<const v4u *>(brow + e0 + 8);
+      } else {
+        const int16_t *ip = p.q_idx ? p.q_idx + e0 : reinterpret_cast<const int16_t *>(p.q_x);   // (no index: any readable address)
+        q_ri[t][0] = *reinterpret_cast<const v4u *>(ip);
+        q_ri[t][1] = *reinterpret_cast<const v4u *>(ip + 8);
+      }
+    }
+    if constexpr (QOP <= 3) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        const int c = min(tid + i * NW * 64, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+        q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
+        if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
+      }
+      if constexpr (QOP >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          q_wr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x2) + min(tid + i * NW * 64, q_nchunks - 1) * 16);
+      }
+    }
+  }
+
+  if constexpr (QOP != 0) __builtin_amdgcn_sched_barrier(0);   // (the requests above are issued before the weight loads below)
+  // ---- everything this wave will ever read of the weights, in flight at once (QOP: the same number of loads in every wave --
+  // slots past the wave's groups re-read its last one -- so that the waits above them are exact counts)
   v4u w[CNT];
   v2u sb[CNT];
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
-    if (j < ng) {
-      const v4u *wp = reinterpret_cast<const v4u *>(wbase + j * 64 + woff);
+    if (QOP != 0 || j < ng) {
+      const int jj = QOP != 0 ? max(min(j, ng - 1), -i0) : j;
+      const v4u *wp = reinterpret_cast<const v4u *>(wbase + jj * 64 + woff);
       w[j] = NT ? __builtin_nontemporal_load(wp) : *wp;
-      sb[j] = *reinterpret_cast<const v2u *>(sbbase + (int64_t)j * p.N * 2 + 8 * kb);
+      sb[j] = *reinterpret_cast<const v2u *>(sbbase + (int64_t)jj * p.N * 2 + 8 * kb);
     }
   }
   v4u wk[2] = {};
   v2u sbk = {};
-  if (keeper) {
+  if (QOP != 0 || keeper) {
     const char *kp = reinterpret_cast<const char *>(p.B8) + (int64_t)n0 * kKeeper + (unsigned)(row * kKeeper + kb * 16);
     wk[0] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp)) : *reinterpret_cast<const v4u *>(kp);
     wk[1] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp + 64)) : *reinterpret_cast<const v4u *>(kp + 64);
     sbk = *reinterpret_cast<const v2u *>(reinterpret_cast<const char *>(p.sB8 + n0) + 8 * kb);
   }
   // ---- token block 0
+  // ---- QOP: the token rows' packed operand, built in LDS while the weight loads are in flight (its barriers wait for LDS only)
+  if constexpr (QOP != 0) {
+    // nothing of the quantiser moves up between the loads above, and none of its requests sinks into a branch below (hipcc moves a
+    // load whose only use is conditional into that branch -- behind the weight loads, with a full wait in front of its use)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      asm volatile("" : "+v"(q_ri[t][0]), "+v"(q_ri[t][1]));
+      if constexpr (QOP == 4) asm volatile("" : "+v"(q_rb[t][0]), "+v"(q_rb[t][1]));
+    }
+    if constexpr (QOP <= 3) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        asm volatile("" : "+v"(q_xr[i]));
+        if constexpr (QOP == 3) asm volatile("" : "+v"(q_rr[i]));
+      }
+      if constexpr (QOP >= 2) asm volatile("" : "+v"(q_wr[0]), "+v"(q_wr[1]));
+    }
+  }
+  char *qbase = lds_raw + (size_t)NW * MBLK * 64 * 16;      // behind the partial-sum area
+  uint8_t *qa4 = reinterpret_cast<uint8_t *>(qbase);                                     // [MQ][K4h]
+  uint8_t *qa8 = qa4 + MQ * K4h;                                                        // [MQ][128]
+  half_t *qsa = reinterpret_cast<half_t *>(qa8 + MQ * kKeeper);                         // [G][MQ]
+  half_t *qsa8 = qsa + (size_t)G * MQ;                                                  // [MQ]; then, 16-byte aligned: red, rows, norm weights
+  if constexpr (QOP != 0) {
+    static_assert(MBLK == 1, "fused quantiser: one token block");
+    auto lds_barrier = [] {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    const int tid = threadIdx.x;
+    float *red = reinterpret_cast<float *>(qbase + q_red_offset(K4h, G));               // [MQ][4] partial sums of squares
+    char *rowbuf = reinterpret_cast<char *>(red + 8);                                   // [MQ][H] halves, then the norm weights [H]
+    char *wbuf = rowbuf + MQ * H * 2;
+    const int nchunks = q_nchunks, nslots = q_nslots, Gt = H >> 7;
+    const int ntask = p.M * nslots;                          // slot tasks: (row, slot), 16 channels each
+    if constexpr (QOP <= 3) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
+        // workgroup 0 writes the residual stream)
+        const int c = tid + i * NW * 64;
+        if (c < p.M * nchunks) {
+          const int m = c / nchunks, cc = c - m * nchunks;
+          h8 v = q_xr[i];
+          if constexpr (QOP == 3) {
+            v = v + q_rr[i];
+            if (blockIdx.x == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
+          }
+          *reinterpret_cast<h8 *>(rowbuf + m * H * 2 + cc * 16) = v;
+        }
+      }
+      if constexpr (QOP >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (tid + i * NW * 64 < nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NW * 64) * 16) = q_wr[i];
+      }
+      lds_barrier();
+    }
+    float rinv[MQ] = {0.f, 0.f};
+    if constexpr (QOP == 2 || QOP == 3) {
+      const int m = tid >> 8, t8 = tid & 255;               // the stand-alone kernel's 4-wave tree, one per row
+      if (m < p.M) {
+        float ss = 0.f;
+        for (int c = t8; c < nchunks; c += 256) {            // chunk (i * 4 + wave) * 64 + lane, i ascending
+          const h8 v = *reinterpret_cast<const h8 *>(rowbuf + m * H * 2 + c * 16);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)v[k], (float)v[k], ss);
+        }
+        ss = wave_sum_butterfly(ss);
+        if (lane == 0) red[m * 4 + (wave & 3)] = ss;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int m2 = 0; m2 < MQ; ++m2) {
+        const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
+        const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
+        rinv[m2] = 1.0f / sqrtf(var + p.q_eps);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      const int task = tid + t * NW * 64;
+      if (task < ntask) {                                    // (ntask is a multiple of 8: whole octets for max8)
+        const int m = task / nslots, slot = task - m * nslots;
+        const int e0 = slot * 16, g = slot >> 3, j = slot & 7;
+        const bool keeper = g == Gt - 1;
+        float v[16];
+        if constexpr (QOP == 4) {
+          const half_t *av = reinterpret_cast<const half_t *>(q_ri[t]), *bv = reinterpret_cast<const half_t *>(q_rb[t]);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = silu_mul<false>((float)av[k], (float)bv[k]);
+        } else {
+          const uint16_t *iv = reinterpret_cast<const uint16_t *>(q_ri[t]);
+          const float rv = m == 0 ? rinv[0] : rinv[1];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int off = p.q_idx ? (int)iv[k] : e0 + k;
+            const half_t xh = *reinterpret_cast<const half_t *>(rowbuf + m * H * 2 + off * 2);
+            if constexpr (QOP >= 2) {
+              const half_t wg = *reinterpret_cast<const half_t *>(wbuf + off * 2);
+              v[k] = (float)(half_t)(((float)xh * (float)wg) * rv);                    // RMSNorm.cuh:145-151
+            } else {
+              v[k] = (float)xh;
+            }
+          }
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+        amax = max8(amax);
+        const GroupScale gs = group_scale<false>(amax, keeper, p.q_clip);
+        float tr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tr[i] = group_code<false>(v[i], gs);
+        const v4u w = pack_codes16(tr, keeper);
+        if (keeper) *reinterpret_cast<v4u *>(qa8 + m * kKeeper + j * 16) = w;
+        else *reinterpret_cast<v2u *>(qa4 + m * K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
+        if (j == 0) {
+          if (keeper) qsa8[m] = f2h(gs.s_store);
+          else qsa[g * MQ + m] = f2h(gs.s_store);
+        }
+      }
+    }
+    lds_barrier();
+  }
   v4u a[CNT];
   // token scales stay RAW (the 16 loaded bits) until their use: declared as half_t the compiler converts each one to float right
   // behind its load -- `global_load_ushort; global_load_dwordx4; s_waitcnt vmcnt(1); v_cvt_f32_f16` per group -- i.e. it waits for
   // everything issued so far before it issues the next group's loads: CNT dependent round trips instead of one (round 2 shipped
   // that: 0.1-0.2 us of every launch with the operands in L2).  opaque_half() is the use-site conversion the scheduler cannot hoist.
   unsigned sa[CNT];
-  auto load_act = [&](int tb, int j) { a[j] = *reinterpret_cast<const v4u *>(abase + j * 64 + aoff[tb]); };
-  auto load_sa = [&](int tb, int j) { sa[j] = *reinterpret_cast<const unsigned short *>(sabase + (int64_t)j * p.ldA * 2 + soff[tb]); };
+  const int mq = min(row, p.M - 1);                         // QOP: my token's row in the LDS operand
+  auto load_act = [&](int tb, int j) {
+    if constexpr (QOP != 0) a[j] = *reinterpret_cast<const v4u *>(qa4 + mq * K4h + (i0 + j) * 64 + kb * 16);
+    else a[j] = *reinterpret_cast<const v4u *>(abase + j * 64 + aoff[tb]);
+  };
+  auto load_sa = [&](int tb, int j) {
+    if constexpr (QOP != 0) sa[j] = __builtin_bit_cast(unsigned short, qsa[(i0 + j) * MQ + mq]);
+    else sa[j] = *reinterpret_cast<const unsigned short *>(sabase + (int64_t)j * p.ldA * 2 + soff[tb]);
+  };
   auto opaque_half = [](unsigned raw) {
     asm volatile("" : "+v"(raw));
     return (float)__builtin_bit_cast(half_t, (unsigned short)raw);
@@ -136,6 +324,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   v4u ak[2] = {};
   unsigned sak = 0;
   auto load_keeper_act = [&](int tb) {
+    if constexpr (QOP != 0) {
+      const uint8_t *kp = qa8 + mq * kKeeper + kb * 16;
+      ak[0] = *reinterpret_cast<const v4u *>(kp);
+      ak[1] = *reinterpret_cast<const v4u *>(kp + 64);
+      sak = __builtin_bit_cast(unsigned short, qsa8[mq]);
+      return;
+    }
     const char *kp = reinterpret_cast<const char *>(p.A8) + koff[tb];
     ak[0] = *reinterpret_cast<const v4u *>(kp);
     ak[1] = *reinterpret_cast<const v4u *>(kp + 64);
@@ -233,6 +428,31 @@ static int launch(const GemmParams &p, hipStream_t s) {
   return check_launch();
 }
 
+// one or two tokens with the preceding quantiser inside the launch (p.q_op)
+template <int NW, int CNT, int OUT, int QOP>
+static int launch_q1(const GemmParams &p, hipStream_t s) {
+  const int H = 2 * p.K4h + kKeeper;
+  const size_t lds = (size_t)NW * 64 * 16 + q_red_offset(p.K4h, p.G) + 32 + (QOP <= 3 ? (size_t)H * 2 * 3 : 0);   // rows of 2 tokens + the norm weights
+  if ((int64_t)p.M * (H >> 4) > (QOP == 4 ? 3 : 2) * NW * 64) return ATOM_ERR_SHAPE;                             // slot tasks per thread
+  if (QOP <= 3 && ((int64_t)p.M * (H >> 3) > 3 * NW * 64 || (H >> 3) > 2 * NW * 64)) return ATOM_ERR_SHAPE;       // row / weight chunks per thread
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), 96 * 1024, attr_done) != ATOM_OK)
+    return ATOM_ERR_LAUNCH;
+  if (lds > 96 * 1024) return ATOM_ERR_SHAPE;
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
+  return check_launch();
+}
+template <int NW, int CNT, int OUT>
+static int launch_q(const GemmParams &p, hipStream_t s) {
+  switch (p.q_op) {
+    case 1: return launch_q1<NW, CNT, OUT, 1>(p, s);
+    case 2: return launch_q1<NW, CNT, OUT, 2>(p, s);
+    case 3: return launch_q1<NW, CNT, OUT, 3>(p, s);
+    case 4: return launch_q1<NW, CNT, OUT, 4>(p, s);
+  }
+  return ATOM_ERR_INVALID_ARG;
+}
+
 template <int NW, int CNT, int OUT = 0>
 static int launch_m(const GemmParams &p, hipStream_t s) {
   const int mblk = (p.M + 15) / 16;
@@ -307,6 +527,16 @@ int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
 // Segmented outputs (atom_gemm_w4a4_multi): one launch for the projections that share an activation operand -- q / k / v, gate / up
 // -- or for one projection + the residual add.  Per-feature arithmetic and summation order are those of launch_gemm_skinny /
 // launch_gemm_skinny_f32 (a workgroup owns 16 features of ONE segment): bit-identical to the separate launches.
+// ... with the quantiser that precedes the GEMM inside the launch (p.q_op; 1 or 2 tokens)
+int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s) {
+  if (p.M > 2 || p.q_op < 1 || p.q_op > 4 || (p.N % 16) != 0 || p.seg_n < 16 || (p.seg_n % 16) != 0 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3)
+    return ATOM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p.sB) & 7u) != 0 || (reinterpret_cast<uintptr_t>(p.sB8) & 7u) != 0) return ATOM_ERR_SHAPE;
+  const int per = (p.G + 1 + 7) / 8;
+  if (per > skinny::CNT_MAX) return ATOM_ERR_SHAPE;
+  return per <= 4 ? skinny::launch_q<8, 4, 2>(p, s) : (per <= 8 ? skinny::launch_q<8, 8, 2>(p, s) : skinny::launch_q<8, 14, 2>(p, s));
+}
+
 int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s) {
   if (p.M > 256 || p.a_wide || p.f6_rows_a || (p.N % 16) != 0 || p.seg_n < 16 || (p.seg_n % 16) != 0 || (p.N % p.seg_n) != 0 ||
       p.N / p.seg_n > 3)

@@ -58,17 +58,6 @@ struct ActQuantParams {
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float max8(float a) {   // max over the aligned 8 lanes this lane belongs to
-  a = fmaxf(a, dpp_f<0xB1>(a));                      // quad_perm [1,0,3,2]
-  a = fmaxf(a, dpp_f<0x4E>(a));                      // quad_perm [2,3,0,1]
-  a = fmaxf(a, dpp_f<0x141>(a));                     // row_half_mirror
-  return a;
-}
-
 // Quantise + store the 16 values of slot (row r, group g, octet lane j).  e0 = first (reordered) channel of the slot.
 template <bool SIM, bool DQ>
 __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantParams &p, int64_t r, int g, int j,
@@ -83,30 +72,10 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
   for (int i = 0; i < 16; ++i) tr[i] = group_code<SIM>(v[i], gs);
   const float s_store = gs.s_store, s_dq = gs.s_dq;
 
+  const v4u w = pack_codes16(tr, keeper);
   if (keeper) {
-    unsigned w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float lo = __builtin_fmaf(tr[4 * k + 1], 256.f, tr[4 * k] + 32896.f);        // (c0+128) + (c1+128)*256
-      const float hi = __builtin_fmaf(tr[4 * k + 3], 256.f, tr[4 * k + 2] + 32896.f);
-      w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
-    }
-    *reinterpret_cast<v4u *>(p.o8 + r * kKeeper + j * 16) = v4u{w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<v4u *>(p.o8 + r * kKeeper + j * 16) = w;
   } else {
-    unsigned w[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      float lo = 34952.f, hi = 34952.f;                                                  // sum 8*16^i, i<4
-      lo = __builtin_fmaf(tr[8 * k + 0], 1.f, lo);
-      lo = __builtin_fmaf(tr[8 * k + 1], 16.f, lo);
-      lo = __builtin_fmaf(tr[8 * k + 2], 256.f, lo);
-      lo = __builtin_fmaf(tr[8 * k + 3], 4096.f, lo);
-      hi = __builtin_fmaf(tr[8 * k + 4], 1.f, hi);
-      hi = __builtin_fmaf(tr[8 * k + 5], 16.f, hi);
-      hi = __builtin_fmaf(tr[8 * k + 6], 256.f, hi);
-      hi = __builtin_fmaf(tr[8 * k + 7], 4096.f, hi);
-      w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x88888888u;
-    }
     if (p.f6_rows) {
       // BF6 (E3M2) holds every INT4 code exactly; v_cvt_scalef32_2xpk16_bf6_f32 converts AND packs 32 floats into 6-bit
       // fields, interleaving its two sources (field 2i = a[i], 2i+1 = b[i]; tools/probes): my 16 codes are fields 0..15

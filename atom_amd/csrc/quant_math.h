@@ -67,6 +67,47 @@ __device__ __forceinline__ float group_code(float v, const GroupScale &g) {
   }
 }
 
+// 16 codes (integer-valued floats) of one slot -> packed words, exact integer arithmetic in FP32: INT4 two's-complement nibbles,
+// channel k of the slot at bits 4 (k % 8) of word k / 8 (2 words); INT8 keeper bytes, channel k at byte k % 4 of word k / 4 (4 words)
+__device__ __forceinline__ v4u pack_codes16(const float (&tr)[16], bool keeper) {
+  if (keeper) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = __builtin_fmaf(tr[4 * k + 1], 256.f, tr[4 * k] + 32896.f);        // (c0+128) + (c1+128)*256
+      const float hi = __builtin_fmaf(tr[4 * k + 3], 256.f, tr[4 * k + 2] + 32896.f);
+      w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
+    }
+    return v4u{w[0], w[1], w[2], w[3]};
+  }
+  unsigned w[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float lo = 34952.f, hi = 34952.f;                                                    // sum 8*16^i, i<4
+    lo = __builtin_fmaf(tr[8 * k + 0], 1.f, lo);
+    lo = __builtin_fmaf(tr[8 * k + 1], 16.f, lo);
+    lo = __builtin_fmaf(tr[8 * k + 2], 256.f, lo);
+    lo = __builtin_fmaf(tr[8 * k + 3], 4096.f, lo);
+    hi = __builtin_fmaf(tr[8 * k + 4], 1.f, hi);
+    hi = __builtin_fmaf(tr[8 * k + 5], 16.f, hi);
+    hi = __builtin_fmaf(tr[8 * k + 6], 256.f, hi);
+    hi = __builtin_fmaf(tr[8 * k + 7], 4096.f, hi);
+    w[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x88888888u;
+  }
+  return v4u{w[0], w[1], 0u, 0u};
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float max8(float a) {   // max over the aligned 8 lanes this lane belongs to
+  a = fmaxf(a, dpp_f<0xB1>(a));                      // quad_perm [1,0,3,2]
+  a = fmaxf(a, dpp_f<0x4E>(a));                      // quad_perm [2,3,0,1]
+  a = fmaxf(a, dpp_f<0x141>(a));                     // row_half_mirror
+  return a;
+}
+
 // silu(a) * b for fp16 inputs given as floats.  Activate.cuh:28  x / (1 + expf(-x)) with the hardware exp2 / rcp (1 ulp each):
 // 5 instructions instead of ~20; expf differs by ulps between libraries anyway (the parity tests allow codes +-1 on < 0.2 %)
 template <bool SIM>

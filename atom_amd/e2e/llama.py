@@ -19,6 +19,12 @@ GROUP = 128
 
 
 _FUSED_KV_APPEND = os.environ.get("ATOM_FUSED_KV_APPEND", "1") != "0"   # 0: the reference's op sequence in decode steps too
+_FUSED_Q_DECODE = os.environ.get("ATOM_FUSED_Q_DECODE", "1") != "0"      # one or two tokens: quantisers inside their consumers
+# ... which of the four (LlamaDecoderLayer._decode_fused_q).  Default 2 = reorder -> o_proj only: every workgroup of the GEMM repeats the
+# quantiser, which pays while the projection has one workgroup per CU (N = 4096: 6.4 -> 5.3 us for the pair; the decode layer 66.4 ->
+# 64.9 us cold at batch 1) and loses once it has several rounds of them (q / k / v: 11.3 -> 13.8 us, gate / up: 16.0 -> 23.3);
+# SiLU x up -> down_proj measures even (profiles/r03_decode.txt item 7)
+_FUSED_Q_MASK = int(os.environ.get("ATOM_FUSED_Q_MASK", "2"))
 _FUSED_DECODE = os.environ.get("ATOM_FUSED_DECODE", "1") != "0"         # 0: one launch per projection in decode steps (round 2)
 
 
@@ -85,18 +91,22 @@ class LinearInt4(nn.Module):
         return f(norms, self.weight_int4, norm_scales, self.scale_int4, outlier, self.weight_int8, outlier_scales,
                  self.scale_int8)
 
+    def single(self):
+        """this projection as an operand of dense_layer_gemm_i4_multi / _multi_q (one segment)"""
+        key = ops.fused_key([self])
+        if getattr(self, "_single", None) is None or self._single["key"] != key:
+            b4, b8, sb, sb8 = self.packed()
+            self._single = {"b4": b4.view(torch.uint8), "b8": b8, "sb": sb.contiguous(), "sb8": sb8.contiguous(), "n_seg": self.out_features,
+                            "nseg": 1, "k": self.in_features, "key": key}
+        return self._single
+
     def forward_add(self, input, residual):
         """residual + forward(input): decode batches run the add inside the projection's launch (same bits as the torch add)."""
         outlier, norms, outlier_scales, norm_scales = input
         rows = outlier.size(0)
         if (norms.dim() == 2 and self.out_dtype == "fp16" and _FUSED_DECODE and residual.is_contiguous()
                 and ops.multi_gemm_fits(rows, self.out_features, 1, self.in_features)):
-            key = ops.fused_key([self])
-            if getattr(self, "_single", None) is None or self._single["key"] != key:
-                b4, b8, sb, sb8 = self.packed()
-                self._single = {"b4": b4.view(torch.uint8), "b8": b8, "sb": sb.contiguous(), "sb8": sb8.contiguous(), "n_seg": self.out_features,
-                                "nseg": 1, "k": self.in_features, "key": key}
-            return ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self._single,
+            return ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self.single(),
                                                  add=residual.view(rows, self.out_features))[0].view(residual.shape)
         return residual + self.forward(input)
 
@@ -292,7 +302,43 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
 
+    def _decode_fused_q(self, hidden_states, decode_kv, mask):
+        """One or two tokens, pure decode: quantisers inside the GEMM that consumes their output (atom_gemm_w4a4_multi_q), per bit of
+        ``mask`` -- 1 input_layernorm -> q / k / v, 2 reorder -> o_proj, 4 residual add + post_attention_layernorm -> gate / up,
+        8 SiLU x up -> down_proj; the same bits as separate launches either way (reference call order llama.py:259-292)."""
+        at, mlp = self.self_attn, self.mlp
+        rows, hs = hidden_states.shape
+        il, pl = self.input_layernorm, self.post_attention_layernorm
+        if mask & 1:
+            (q, k32, v32), _ = ops.dense_layer_gemm_i4_multi_q("rmsnorm", hidden_states, at._decode_qkv(), x2=il.weight, reorder_index=il.reorder_index,
+                                                               eps=il.variance_epsilon, f32_mask=0b110)
+        else:
+            outlier, norms, outlier_scales, norm_scales = il(hidden_states)
+            q, k32, v32 = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, at._decode_qkv(), f32_mask=0b110)
+        ops.quant_append_kv_i4(decode_kv, k32, v32, at.layer_idx)
+        o = ops.batch_decode_i4(q.view(rows, at.num_heads, at.head_dim), decode_kv, at.layer_idx, rope_theta=at.rope_theta).view(rows, hs)
+        if mask & 2:
+            (attn,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o, at.o_proj.single(), reorder_index=at.reorder_index)
+        else:
+            attn = at.o_proj(ops.reorder_fp16_i4(o, at.reorder_index))
+        if mask & 4:
+            (gate, up), residual = ops.dense_layer_gemm_i4_multi_q("add_rmsnorm", attn, mlp._decode_gate_up(), residual=hidden_states, x2=pl.weight,
+                                                                   reorder_index=pl.reorder_index, eps=pl.variance_epsilon)
+        else:
+            residual, (outlier, norms, outlier_scales, norm_scales) = pl.forward_add(attn, hidden_states)
+            gate, up = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, mlp._decode_gate_up())
+        if mask & 8:
+            (out,), _ = ops.dense_layer_gemm_i4_multi_q("silu_mul", gate, mlp.down_proj.single(), x2=up, add=residual)
+            return out
+        return mlp.down_proj.forward_add(ops.activate_fp16_i4(gate, up), residual)
+
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
+        rows = hidden_states.size(0) if torch.is_tensor(hidden_states) else 0
+        hs, inter = self.hidden_size, self.mlp.intermediate_size
+        if (_FUSED_Q_DECODE and _FUSED_Q_MASK and _FUSED_DECODE and _FUSED_KV_APPEND and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
+                and len(blen.prefills) == 0 and blen.decode == rows and decode_kv is not None
+                and ops.multi_q_gemm_fits(rows, hs, 3, hs) and ops.multi_q_gemm_fits(rows, inter, 2, hs) and ops.multi_q_gemm_fits(rows, hs, 1, inter)):
+            return self._decode_fused_q(hidden_states, decode_kv, _FUSED_Q_MASK)
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
         return self.mlp(normed, residual=residual)                                           # ... and the second one (decode: in down_proj's launch)

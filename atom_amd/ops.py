@@ -319,6 +319,44 @@ def dense_layer_gemm_i4_multi(a, a_scale, a_keeper, a_keeper_scale, fused, *, f3
     return tuple(outs)
 
 
+def multi_q_gemm_fits(m: int, n_seg: int, nseg: int, k: int) -> bool:
+    return bool(L.lib().atom_gemm_w4a4_multi_q_fits(m, n_seg, nseg, k))
+
+
+def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, reorder_index=None, eps=0.0, clip=1.0, f32_mask=0, add=None):
+    """NEW (decode steps of one or two tokens; no reference counterpart): dense_layer_gemm_i4_multi with the quantiser that precedes
+    it in the reference's call order INSIDE the launch -- ``q_op`` "reorder" (reorder_fp16_i4), "rmsnorm" (rmsnorm_fp16_i4, ``x2`` = the
+    norm weight), "add_rmsnorm" (add_rmsnorm_fp16_i4: returns x + residual as well) or "silu_mul" (activate_fp16_i4, ``x2`` = the second
+    factor); kernel-flavoured quantiser arithmetic.  ``x`` fp16 [M, K].  Returns (outs, residual_out): bit-identical to the quantiser op
+    followed by dense_layer_gemm_i4_multi."""
+    _require_cuda_half(x, "x")
+    code = {"reorder": L.Q_REORDER, "rmsnorm": L.Q_RMSNORM, "add_rmsnorm": L.Q_ADD_RMSNORM, "silu_mul": L.Q_SILU_MUL}[q_op]
+    m = x.size(0)
+    n, nseg, k = fused["n_seg"], fused["nseg"], fused["k"]
+    assert x.shape == (m, k) and x.is_contiguous()
+    outs = [torch.empty((m, n), dtype=torch.float32 if (f32_mask >> i) & 1 else torch.float16, device=x.device) for i in range(nseg)]
+    res_out = None
+    if code == L.Q_ADD_RMSNORM:
+        _require_cuda_half(residual, "residual")
+        assert residual.shape == x.shape and residual.is_contiguous()
+        res_out = torch.empty_like(x)                    # (never in place: every workgroup reads the residual, one writes the sum)
+    if x2 is not None:
+        _require_cuda_half(x2, "x2")
+        assert x2.is_contiguous() and (x2.shape == x.shape if code == L.Q_SILU_MUL else x2.numel() == k)
+    if reorder_index is not None:
+        assert reorder_index.dtype == torch.int16 and reorder_index.numel() == k and reorder_index.is_cuda
+    if add is not None:
+        _require_cuda_half(add, "add")
+        assert add.shape == (m, n) and add.is_contiguous()
+    st = L.lib().atom_gemm_w4a4_multi_q(code, x.data_ptr(), L.ptr(x2), L.ptr(residual), L.ptr(res_out), L.ptr(reorder_index), float(eps),
+                                        float(clip), fused["b4"].data_ptr(), fused["sb"].data_ptr(), fused["b8"].data_ptr(),
+                                        fused["sb8"].data_ptr(), outs[0].data_ptr(), outs[1].data_ptr() if nseg > 1 else None,
+                                        outs[2].data_ptr() if nseg > 2 else None, int(f32_mask), L.ptr(add), m, n, nseg, k,
+                                        GROUP_SIZE, GROUP_SIZE, L.current_stream(x.device))
+    L.check(st, "atom_gemm_w4a4_multi_q")
+    return tuple(outs), res_out
+
+
 def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: int = 2, return_fake_quant=False):
     """NEW (no reference counterpart): quantise + pack a (column-reordered) FP16 weight [N,K] the
     way QLinearLayer.quant does (qLinearLayer.py:42-78).  Returns (B4 u8[N,K4/2], B8 i8[N,128], sB f16[G,N],

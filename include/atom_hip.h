@@ -184,6 +184,30 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
                          int scale_layout, void *stream);
 
 /*
+ * atom_gemm_w4a4_multi with the quantiser that PRECEDES the GEMM inside the launch: one or two tokens of a decode step
+ * (atom_gemm_w4a4_multi_q_fits).  The reference runs the two as separate ops -- punica/models/llama.py:259-263 input_layernorm
+ * (rmsnorm_fp16_i4) -> :110-119 q / k / v; :176 reorder_fp16_i4 -> o_proj; :266-282 residual add + post_attention_layernorm -> :85
+ * gate / up; :86 activate_fp16_i4 -> :87 down_proj -- and so does this library from three tokens on; at one or two tokens a
+ * quantiser launch costs more than its arithmetic (a launch boundary, its own round trip through HBM, 3-5 us against the GEMM's 5-9), so
+ * every workgroup of the GEMM quantises its own copy of the token rows into LDS behind its weight loads instead.
+ *   q_op   ATOM_Q_REORDER      x [M, K_total] fp16, reorder_index (or NULL)           = atom_reorder_quant_f16
+ *          ATOM_Q_RMSNORM      + x2 = the RMSNorm weight [K_total], eps               = atom_rmsnorm_reorder_quant_f16
+ *          ATOM_Q_ADD_RMSNORM  + residual, residual_out [M, K_total] (x + residual)   = atom_add_rmsnorm_reorder_quant_f16
+ *          ATOM_Q_SILU_MUL     x2 = the second factor [M, K_total]; no reorder index  = atom_silu_mul_quant_f16
+ * in the kernel-flavoured arithmetic (quant_mode 0), clip as there.  Outputs, segments, f32_mask, add0_f16 as atom_gemm_w4a4_multi.
+ * Bit-identical to the quantiser op followed by atom_gemm_w4a4_multi (tests/test_gpu_gemm.py).
+ */
+#define ATOM_Q_REORDER 1
+#define ATOM_Q_RMSNORM 2
+#define ATOM_Q_ADD_RMSNORM 3
+#define ATOM_Q_SILU_MUL 4
+int atom_gemm_w4a4_multi_q_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total);
+int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *residual, void *residual_out,
+                           const int16_t *reorder_index, float eps, float clip, const void *B4, const void *sB, const void *B8,
+                           const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask, const void *add0_f16, int64_t M,
+                           int64_t N_seg, int nseg, int64_t K_total, int group, int keeper, void *stream);
+
+/*
  * Same result contract, with an optional caller-owned scratch buffer for DECODE batches (the k/v projections of a
  * serving step; the shapes the decode-batch GEMM takes, M <= 256 at most).  The plain entry point runs the 256-row
  * tile kernel whatever M is (88 us at M = 16, N = K = 4096); with

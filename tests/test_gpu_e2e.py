@@ -124,6 +124,8 @@ def test_decoder_layer_prefill_then_decode_is_consistent():
     def fresh_pool():
         return KvPoolInt4(num_layers=2, num_heads=4, head_dim=128, capacity=16, block_len=16, device=dev)
 
+    import atom_amd.e2e.llama as E
+    fq0, E._FUSED_Q_DECODE = E._FUSED_Q_DECODE, False   # (the spy hooks the stand-alone reorder op: keep it a separate launch here)
     ops.reorder_fp16_i4 = spy
     # path A: prefill S, then one decode step
     pool = fresh_pool()
@@ -138,6 +140,7 @@ def test_decoder_layer_prefill_then_decode_is_consistent():
     cs2 = [KvCacheInt4(pool2, n + 1) for n in lens]
     y_full = layer(torch.cat(x), BatchLenInfo([n + 1 for n in lens], 0, dev), BatchedKvCacheInt4(cs2), None)
     ops.reorder_fp16_i4 = orig_reorder
+    E._FUSED_Q_DECODE = fq0
     rows = [lens[0], lens[0] + 1 + lens[1]]
     a_dec, a_full = attn_in[1].float(), attn_in[2][rows].float()
     assert (a_dec - a_full).abs().max().item() <= 2e-3 * a_full.abs().max().item()
@@ -192,6 +195,94 @@ def test_multi_projection_launch_equals_separate_launches(M, N, K, nseg):
     assert all(torch.equal(o, w.half()) for o, w in zip(outs, want32))
     if M >= 2:                                                    # (M = 1 goes to the dot-product kernel behind the plain entry point)
         assert torch.equal(outs[0], ops.dense_layer_gemm_i4_fp16(a[0], devs[0][1], a[2], devs[0][3], a[4], devs[0][5], a[6], devs[0][7]))
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("op,N,K,nseg", [("rmsnorm", 4096, 4096, 3), ("reorder", 4096, 4096, 1), ("add_rmsnorm", 11008, 4096, 2), ("silu_mul", 4096, 11008, 1),
+                                         ("rmsnorm", 1408, 640, 2), ("silu_mul", 512, 1408, 1), ("add_rmsnorm", 256, 5120, 3), ("reorder", 64, 256, 1)])
+def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, nseg, M):
+    """atom_gemm_w4a4_multi_q (one or two tokens of a decode step): the quantiser that precedes the projections -- reorder, RMSNorm,
+    residual add + RMSNorm, SiLU x up -- runs inside the GEMM launch, every workgroup on its own copy of the rows.  Every output
+    (fp16, FP32 sums, fp16 + addend, the residual stream) bit-identical to the quantiser op followed by atom_gemm_w4a4_multi."""
+    import types
+    from atom_amd import ops
+    from tests.helpers import rand_gemm_operands, to_device
+    assert ops.multi_q_gemm_fits(M, N, nseg, K)
+    devs = [to_device(rand_gemm_operands(4, N, K, seed=51 + i), "ref") for i in range(nseg)]
+    mods = [types.SimpleNamespace(weight_int4=torch.nn.Parameter(dv[1], requires_grad=False), weight_int8=torch.nn.Parameter(dv[5], requires_grad=False),
+                                  scale_int4=torch.nn.Parameter(dv[3], requires_grad=False), scale_int8=torch.nn.Parameter(dv[7], requires_grad=False),
+                                  packed=None) for dv in devs]
+    for md in mods:
+        md.packed = (lambda md=md: (md.weight_int4.data, md.weight_int8.data, md.scale_int4.data, md.scale_int8.data))
+    fused = ops.fuse_projection_weights(mods)
+    g = torch.Generator(device="cuda").manual_seed(1000 * M + N + K)
+    x = (torch.randn((M, K), device="cuda", generator=g) * 1.3).half()
+    x2 = (torch.randn((M, K), device="cuda", generator=g) * 0.8).half()
+    w = (1 + 0.1 * torch.randn(K, device="cuda", generator=g)).half()
+    idx = torch.randperm(K, device="cuda", generator=g).to(torch.int16)
+    res = (torch.randn((M, K), device="cuda", generator=g) * 2).half()
+    add = (torch.randn((M, N), device="cuda", generator=g) * 3).half()
+    eps = 1e-5
+    res_want = None
+    if op == "reorder":
+        qt = ops.reorder_fp16_i4(x, idx)
+        kw = dict(reorder_index=idx)
+    elif op == "rmsnorm":
+        qt = ops.rmsnorm_fp16_i4(x, w, idx, eps)
+        kw = dict(x2=w, reorder_index=idx, eps=eps)
+    elif op == "add_rmsnorm":
+        out = ops.add_rmsnorm_fp16_i4(x, res, w, idx, eps)
+        res_want, qt = out[0], out[1:]
+        kw = dict(x2=w, residual=res, reorder_index=idx, eps=eps)
+    else:
+        qt = ops.activate_fp16_i4(x, x2)
+        kw = dict(x2=x2)
+    outlier, norms, outlier_scales, norm_scales = qt
+    for mask, ad in ((0, None), (0b110 & ((1 << nseg) - 1), add)):
+        want = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, fused, f32_mask=mask, add=ad)
+        got, res_out = ops.dense_layer_gemm_i4_multi_q(op, x, fused, f32_mask=mask, add=ad, **kw)
+        for i in range(nseg):
+            assert got[i].dtype == want[i].dtype and torch.equal(got[i], want[i]), (op, M, i, mask)
+        if op == "add_rmsnorm":
+            assert torch.equal(res_out, res_want)
+        else:
+            assert res_out is None
+
+
+@pytest.mark.parametrize("bsz", [1, 2])
+def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
+    """A decode step of one or two tokens with the four quantisers inside their consumers' launches (7 launches) against the same
+    step with separate quantiser launches (11): same cache contents, same output, bit for bit."""
+    import atom_amd.e2e.llama as E
+    from atom_amd.e2e import LlamaDecoderLayer
+    from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    torch.manual_seed(5)
+    cfg = _attn_cfg()
+    dev = torch.device("cuda")
+    layer = LlamaDecoderLayer(cfg, layer_idx=0).cuda()
+    _load_layer(layer, 8)
+    ctx = 40
+    x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
+    outs, caches = [], []
+    mask0 = E._FUSED_Q_MASK
+    try:
+        E._FUSED_Q_MASK = 15                                   # all four quantisers fused (the default fuses reorder -> o_proj only)
+        for fq in (False, True):
+            E._FUSED_Q_DECODE = fq
+            pool = KvPoolInt4(num_layers=1, num_heads=4, head_dim=128, capacity=bsz * 4, block_len=16, device=dev)
+            g = torch.Generator(device="cuda").manual_seed(9)
+            pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
+            pool.param.copy_((torch.rand(pool.param.shape, device=dev, generator=g) * 0.05 + 0.01).half())
+            cs = [KvCacheInt4(pool, ctx) for _ in range(bsz)]
+            for c in cs:
+                c.acquire_one()
+            outs.append(layer(x, BatchLenInfo([], bsz, dev), None, BatchedKvCacheInt4(cs)))
+            caches.append((pool.buf.clone(), pool.param.clone()))
+    finally:
+        E._FUSED_Q_DECODE = True
+        E._FUSED_Q_MASK = mask0
+    assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("bsz", [1, 3, 16])
