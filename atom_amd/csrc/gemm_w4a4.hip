@@ -344,7 +344,7 @@ int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *
                            int64_t N_seg, int nseg, int64_t K_total, int group, int keeper, void *stream) {
   if (q_op < ATOM_Q_REORDER || q_op > ATOM_Q_SILU_MUL || !x) return ATOM_ERR_INVALID_ARG;
   if ((q_op == ATOM_Q_RMSNORM || q_op == ATOM_Q_ADD_RMSNORM || q_op == ATOM_Q_SILU_MUL) && !x2) return ATOM_ERR_INVALID_ARG;
-  if (q_op == ATOM_Q_ADD_RMSNORM && (!residual || !residual_out)) return ATOM_ERR_INVALID_ARG;
+  if (q_op == ATOM_Q_ADD_RMSNORM && (!residual || !residual_out || residual_out == residual || residual_out == x)) return ATOM_ERR_INVALID_ARG;
   if (q_op == ATOM_Q_SILU_MUL && reorder_index) return ATOM_ERR_INVALID_ARG;
   if (nseg < 1 || nseg > 3 || !out0 || (nseg > 1 && !out1) || (nseg > 2 && !out2)) return ATOM_ERR_INVALID_ARG;
   if (N_seg < 16 || (N_seg % 16) != 0) return ATOM_ERR_SHAPE;

@@ -193,6 +193,7 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
  *   q_op   ATOM_Q_REORDER      x [M, K_total] fp16, reorder_index (or NULL)           = atom_reorder_quant_f16
  *          ATOM_Q_RMSNORM      + x2 = the RMSNorm weight [K_total], eps               = atom_rmsnorm_reorder_quant_f16
  *          ATOM_Q_ADD_RMSNORM  + residual, residual_out [M, K_total] (x + residual)   = atom_add_rmsnorm_reorder_quant_f16
+ *                              (NOT in place: every workgroup reads x and residual, workgroup 0 writes residual_out)
  *          ATOM_Q_SILU_MUL     x2 = the second factor [M, K_total]; no reorder index  = atom_silu_mul_quant_f16
  * in the kernel-flavoured arithmetic (quant_mode 0), clip as there.  Outputs, segments, f32_mask, add0_f16 as atom_gemm_w4a4_multi.
  * Bit-identical to the quantiser op followed by atom_gemm_w4a4_multi (tests/test_gpu_gemm.py).

@@ -79,6 +79,17 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.atom_reorder_quant_f16(p, None, 4, 32768, 0, 1.0, 1, p, p, p, p, None, None) == -33 # hidden too large
     assert lib.atom_quant_weight_w4(p, 3, 256, 0.85, 2, p, p, p, p, None, None) == -33             # odd N
     assert lib.atom_quant_weight_w4(p, 4, 256, 0.85, 3, p, p, p, p, None, None) == -22             # channel_group 3
+    # atom_gemm_w4a4_multi_q(q_op, x, x2, residual, residual_out, reorder_index, eps, clip, B4, sB, B8, sB8, out0..2, mask, add, M, N_seg, nseg, K, ...)
+    q = p + (1 << 15)
+    mq = lambda op, x2, res, res_out, M=1, idx=None: lib.atom_gemm_w4a4_multi_q(op, p, x2, res, res_out, idx, 1e-5, 1.0, p, p, p, p, q, None, None, 0, None,
+                                                                                 M, 64, 1, 256, 128, 128, None)
+    assert mq(1, None, None, None) == 0
+    assert mq(5, None, None, None) == -22                                                          # unknown quantiser op
+    assert mq(2, None, None, None) == -22                                                          # RMSNorm without its weight
+    assert mq(3, p, p, p) == -22                                                                   # residual add in place
+    assert mq(3, p, p, q) == 0
+    assert mq(4, p, None, None, idx=p) == -22                                                      # SiLU x up takes no reorder index
+    assert mq(1, None, None, None, M=3) == -33                                                     # one or two tokens only
     assert lib.atom_strerror(-33).startswith(b"unsupported")
     torch.cuda.synchronize()
 
