@@ -87,6 +87,18 @@ def test_packed_route_query():
     assert rec(0, 4096, 4096) == 0 and rec(300, 4096, 4000) == 0
 
 
+def test_fused_quantiser_shape_query():
+    """atom_gemm_w4a4_multi_q_fits: one or two tokens, the shapes atom_gemm_w4a4_multi takes, at most three slot tasks per thread of the
+    quantiser (K_total / 16 slots per row over 512 threads)."""
+    from atom_amd import _lib
+    L = _lib.lib()
+    fq, fm = L.atom_gemm_w4a4_multi_q_fits, L.atom_gemm_w4a4_multi_fits
+    assert fq(1, 4096, 3, 4096) == 1 and fq(2, 4096, 1, 4096) == 1 and fq(1, 11008, 2, 4096) == 1 and fq(2, 4096, 1, 11008) == 1
+    assert fq(3, 4096, 1, 4096) == 0 and fq(0, 4096, 1, 4096) == 0 and fm(3, 4096, 1, 4096) == 1
+    assert fq(2, 5120, 1, 13824) == 0 and fq(1, 5120, 1, 13824) == 1          # 2 x 864 slots > 3 x 512
+    assert fq(1, 4096, 4, 4096) == 0 and fq(1, 24, 1, 4096) == 0 and fq(1, 4096, 1, 4000) == 0
+
+
 def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):
     """Guard against a code-generation trap of hipcc (ROCm 7.2): v_cvt_scalef32_2xpk16_bf6_f32 reads two 16-register sources over
     several passes and writes a 6-register result; the register allocator may place the result INSIDE a source at an offset
