@@ -332,12 +332,21 @@ class LlamaDecoderLayer(nn.Module):
             return out
         return mlp.down_proj.forward_add(ops.activate_fp16_i4(gate, up), residual)
 
+    def _fused_q_fits(self, rows):
+        """every projection of the layer is a shape atom_gemm_w4a4_multi_q takes at this batch size (asked once per batch size)"""
+        ok = getattr(self, "_fq_ok", None)
+        if ok is None:
+            ok = self._fq_ok = {}
+        if rows not in ok:
+            hs, inter = self.hidden_size, self.mlp.intermediate_size
+            ok[rows] = (ops.multi_q_gemm_fits(rows, hs, 3, hs) and ops.multi_q_gemm_fits(rows, hs, 1, hs) and ops.multi_q_gemm_fits(rows, inter, 2, hs)
+                        and ops.multi_q_gemm_fits(rows, hs, 1, inter))
+        return ok[rows]
+
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
         rows = hidden_states.size(0) if torch.is_tensor(hidden_states) else 0
-        hs, inter = self.hidden_size, self.mlp.intermediate_size
         if (_FUSED_Q_DECODE and _FUSED_Q_MASK and _FUSED_DECODE and _FUSED_KV_APPEND and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
-                and len(blen.prefills) == 0 and blen.decode == rows and decode_kv is not None
-                and ops.multi_q_gemm_fits(rows, hs, 3, hs) and ops.multi_q_gemm_fits(rows, inter, 2, hs) and ops.multi_q_gemm_fits(rows, hs, 1, inter)):
+                and len(blen.prefills) == 0 and blen.decode == rows and decode_kv is not None and self._fused_q_fits(rows)):
             return self._decode_fused_q(hidden_states, decode_kv, _FUSED_Q_MASK)
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
