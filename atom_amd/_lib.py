@@ -44,7 +44,7 @@ SIGNATURES = {
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_multi_fits": (_int, [_i64, _i64, _int, _i64]),
     "atom_gemm_w4a4_multi": (_int, [_vp] * 11 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _int, _vp]),
-    "atom_gemm_w4a4_multi_q_fits": (_int, [_i64, _i64, _int, _i64]),
+    "atom_gemm_w4a4_multi_q_fits": (_int, [_int, _i64, _i64, _int, _i64]),
     "atom_gemm_w4a4_multi_q": (_int, [_int] + [_vp] * 5 + [_f32, _f32] + [_vp] * 7 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _vp]),
     "atom_gemm_w4a4_o4": (_int, [_vp] * 10 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_o4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),

@@ -108,6 +108,7 @@ int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch
 int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmented outputs (p.seg_*): q/k/v, gate/up, down + residual
+bool skinny_q_fits(int q_op, int64_t M, int64_t K_total);             // ... the shapes its quantiser-in-front variant takes
 int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s);   // ... + the preceding quantiser inside the launch (p.q_*)
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s);   // ... 256x256 kernel + fused SiLU x up -> quant epilogue

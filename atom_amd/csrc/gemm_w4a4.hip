@@ -333,8 +333,8 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
   return launch_gemm_skinny_multi(p, reinterpret_cast<hipStream_t>(stream));
 }
 
-int atom_gemm_w4a4_multi_q_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total) {
-  if (M < 1 || M > 2 || M * (K_total / 16) > 3 * 512) return 0;      // slot tasks of the quantiser: at most 2 (SiLU x up: 3) per thread
+int atom_gemm_w4a4_multi_q_fits(int q_op, int64_t M, int64_t N_seg, int nseg, int64_t K_total) {
+  if (!skinny_q_fits(q_op, M, K_total)) return 0;                    // the launcher's own predicate (gemm_w4a4_skinny.hip)
   return atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total);
 }
 
@@ -354,7 +354,7 @@ int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *
   // (the packed activation operand does not exist: the kernel builds it in LDS; x / sB stand in for the pointer checks)
   const int st = fill_params(p, x, B4, sB, sB, x, B8, sB, sB8, M, N_seg * nseg, K_total, group, keeper, ATOM_SCALE_LAYOUT_PLAIN);
   if (st != ATOM_OK) return st;
-  if (!atom_gemm_w4a4_multi_q_fits(M, N_seg, nseg, K_total)) return ATOM_ERR_SHAPE;
+  if (!atom_gemm_w4a4_multi_q_fits(q_op, M, N_seg, nseg, K_total)) return ATOM_ERR_SHAPE;
   if (!aligned16(out0) || (out1 && !aligned16(out1)) || (out2 && !aligned16(out2)) || (add0_f16 && !aligned16(add0_f16))) return ATOM_ERR_ALIGN;
   if (!aligned16(x) || (q_op == ATOM_Q_SILU_MUL && !aligned16(x2)) || (residual && !aligned16(residual)) ||
       (residual_out && !aligned16(residual_out)) || (reorder_index && !aligned16(reorder_index)))

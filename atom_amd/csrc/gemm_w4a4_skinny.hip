@@ -59,6 +59,14 @@ __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb
 
 // fused quantiser (QOP): byte offset of red[4] (then the row buffer) behind the packed operand of MQ = 2 rows in LDS
 __host__ __device__ inline int q_red_offset(int K4h, int G) { return (2 * K4h + 2 * kKeeper + 2 * G * 2 + 2 * 2 + 15) & ~15; }
+constexpr int kQWaves = 8;                 // the quantiser-in-front variant runs 8-wave workgroups only (launch_gemm_skinny_multi_q)
+constexpr int kQLdsMax = 96 * 1024;
+// LDS of a quantiser-in-front launch: the partial sums of the 8 waves, the packed operand built in place, the reduction scratch, and
+// (ops 1-3) the fp16 rows of up to two tokens + the norm weights
+inline size_t q_lds_bytes(int q_op, int K4h, int G) {
+  const int H = 2 * K4h + kKeeper;
+  return (size_t)kQWaves * 64 * 16 + q_red_offset(K4h, G) + 32 + (q_op <= 3 ? (size_t)H * 2 * 3 : 0);
+}
 
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
 // OUT: 0 = fp16 D [M, N]; 1 = FP32 sums to p.ws [M, N] (the u4-epilogue path); 2 = segmented (atom_gemm_w4a4_multi): the features are
@@ -431,14 +439,12 @@ static int launch(const GemmParams &p, hipStream_t s) {
 // one or two tokens with the preceding quantiser inside the launch (p.q_op)
 template <int NW, int CNT, int OUT, int QOP>
 static int launch_q1(const GemmParams &p, hipStream_t s) {
-  const int H = 2 * p.K4h + kKeeper;
-  const size_t lds = (size_t)NW * 64 * 16 + q_red_offset(p.K4h, p.G) + 32 + (QOP <= 3 ? (size_t)H * 2 * 3 : 0);   // rows of 2 tokens + the norm weights
-  if ((int64_t)p.M * (H >> 4) > (QOP == 4 ? 3 : 2) * NW * 64) return ATOM_ERR_SHAPE;                             // slot tasks per thread
-  if (QOP <= 3 && ((int64_t)p.M * (H >> 3) > 3 * NW * 64 || (H >> 3) > 2 * NW * 64)) return ATOM_ERR_SHAPE;       // row / weight chunks per thread
+  static_assert(NW == kQWaves, "skinny_q_fits() is written for the 8-wave workgroup");
+  if (!skinny_q_fits(QOP, p.M, 2 * p.K4h + kKeeper)) return ATOM_ERR_SHAPE;
+  const size_t lds = q_lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), 96 * 1024, attr_done) != ATOM_OK)
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), kQLdsMax, attr_done) != ATOM_OK)
     return ATOM_ERR_LAUNCH;
-  if (lds > 96 * 1024) return ATOM_ERR_SHAPE;
   hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
@@ -528,6 +534,18 @@ int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s) {
 // -- or for one projection + the residual add.  Per-feature arithmetic and summation order are those of launch_gemm_skinny /
 // launch_gemm_skinny_f32 (a workgroup owns 16 features of ONE segment): bit-identical to the separate launches.
 // ... with the quantiser that precedes the GEMM inside the launch (p.q_op; 1 or 2 tokens)
+// THE shape predicate of the quantiser-in-front launch, shared by atom_gemm_w4a4_multi_q_fits and the launcher (round 3 had two, and the
+// query was looser than the launch for ops 1-3): per thread of the 512 at most 2 slot tasks of 16 channels (SiLU x up: 3), at most 3
+// 16-byte chunks of the token rows and 2 of the norm weight (ops 1-3), and everything within 96 KiB of LDS.
+bool skinny_q_fits(int q_op, int64_t M, int64_t H) {
+  if (q_op < 1 || q_op > 4 || M < 1 || M > 2 || H < 2 * kKeeper || ((H - kKeeper) % kGroup) != 0) return false;
+  const int64_t threads = skinny::kQWaves * 64;
+  if (M * (H >> 4) > (q_op == 4 ? 3 : 2) * threads) return false;
+  if (q_op <= 3 && (M * (H >> 3) > 3 * threads || (H >> 3) > 2 * threads)) return false;
+  const int K4h = (int)((H - kKeeper) / 2), G = (int)((H - kKeeper) / kGroup);
+  return skinny::q_lds_bytes(q_op, K4h, G) <= (size_t)skinny::kQLdsMax;
+}
+
 int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s) {
   if (p.M > 2 || p.q_op < 1 || p.q_op > 4 || (p.N % 16) != 0 || p.seg_n < 16 || (p.seg_n % 16) != 0 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3)
     return ATOM_ERR_SHAPE;

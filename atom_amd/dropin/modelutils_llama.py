@@ -1,0 +1,8 @@
+"""Top-level ``modelutils_llama`` module for the reference's driver (main.py: ``from modelutils_llama import ...``): with this directory ahead of
+/path/to/Atom/model on PYTHONPATH the driver's flow functions are the MI355X-resident ones of atom_amd.model.modelutils_llama (same names and
+positional arguments).  Leave this file out of the path (load the reference's own modelutils_llama by file) to drive OUR classes with the
+reference's UNMODIFIED flow code instead -- both are tested (tests/test_flow_reference_cpu.py, tests/test_gpu_flow.py)."""
+from atom_amd.model.modelutils_llama import *  # noqa: F401,F403
+from atom_amd.model import modelutils_llama as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

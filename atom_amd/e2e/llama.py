@@ -339,8 +339,11 @@ class LlamaDecoderLayer(nn.Module):
             ok = self._fq_ok = {}
         if rows not in ok:
             hs, inter = self.hidden_size, self.mlp.intermediate_size
-            ok[rows] = (ops.multi_q_gemm_fits(rows, hs, 3, hs) and ops.multi_q_gemm_fits(rows, hs, 1, hs) and ops.multi_q_gemm_fits(rows, inter, 2, hs)
-                        and ops.multi_q_gemm_fits(rows, hs, 1, inter))
+            # only the ops the mask selects have to fit (each with ITS quantiser's bounds); the others run as separate launches
+            need = (("rmsnorm", hs, 3, hs), ("reorder", hs, 1, hs), ("add_rmsnorm", inter, 2, hs), ("silu_mul", hs, 1, inter))
+            ok[rows] = all(ops.multi_q_gemm_fits(q, rows, n, nseg, k) for bit, (q, n, nseg, k) in enumerate(need) if (_FUSED_Q_MASK >> bit) & 1)
+            # the launches that take the un-fused operands in _decode_fused_q
+            ok[rows] = ok[rows] and ops.multi_gemm_fits(rows, hs, 3, hs) and ops.multi_gemm_fits(rows, inter, 2, hs) and ops.multi_gemm_fits(rows, hs, 1, inter)
         return ok[rows]
 
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
@@ -351,3 +354,54 @@ class LlamaDecoderLayer(nn.Module):
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
         return self.mlp(normed, residual=residual)                                           # ... and the second one (decode: in down_proj's launch)
+
+
+class LlamaRMSNorm(nn.Module):
+    """The final, un-quantised norm (reference llama.py:316 takes transformers' LlamaRMSNorm: fp32 statistics, weight applied after
+    the cast back)."""
+
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size, dtype=torch.float16), requires_grad=False)
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        h = x.float()
+        h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * h.to(x.dtype)
+
+
+class LlamaModel(nn.Module):
+    """reference llama.py:306-340: embedding -> decoder layers -> final norm over a flat [tokens, hidden] batch (prefill requests
+    first, then one row per decode request).  Plain ``nn.Module`` (the reference derives from transformers' PreTrainedModel only for
+    ``from_pretrained``; here ``load_state_dict(model.export.load_packed(path))`` fills it) and every layer gets its own
+    ``layer_idx`` (the reference passes 0 to all of them, "Hack for memory", :313-314)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, getattr(config, "pad_token_id", None), dtype=torch.float16)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    @torch.no_grad()
+    def forward(self, input_ids, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
+        hidden_states = self.embed_tokens(input_ids)
+        for layer in self.layers:
+            hidden_states = layer(hidden_states, blen, prefill_kv, decode_kv)
+        return self.norm(hidden_states)
+
+
+class LlamaForCausalLM(nn.Module):
+    """reference llama.py:343-364: returns (logits, hidden_states)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = LlamaModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False, dtype=torch.float16)
+
+    @torch.no_grad()
+    def forward(self, input_ids, blen: BatchLenInfo, prefill_kv, decode_kv):
+        hidden_states = self.model(input_ids, blen, prefill_kv, decode_kv)
+        return self.lm_head(hidden_states), hidden_states

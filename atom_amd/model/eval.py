@@ -1,0 +1,61 @@
+"""HIP-path mirror of the reference's ``model/eval.py:14-86`` (``llama_eval``): perplexity of a (quantised) Llama over a token
+stream, layer by layer.
+
+Same arithmetic per sample as the reference -- every layer is called on ``inps[j].unsqueeze(0)`` with the attention mask / position
+ids captured from the model's own forward, the loss is ``CrossEntropyLoss`` over the shifted logits, the result
+``exp(sum(nll) / (nsamples * seqlen))`` -- so the number is comparable to the reference's.  What differs is residency: the layers
+stay on ``dev`` (an MI355X holds the model; ``offload=True`` restores the reference's per-layer GPU <-> CPU bounce), and
+``rows_per_call`` > 1 stacks that many samples into one layer call (tokens are quantised per token and GEMM rows are independent, so
+this only changes which tile kernel -- and hence which fixed K order -- the W4A4 GEMMs take; default 1 = the reference's calls).
+``return_details=True`` also returns the per-sample NLLs and the final hidden states (what the flow tests compare).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .modelutils_llama import capture_first_layer_inputs
+
+
+def _for_batch(kw, n):
+    """The captured layer keyword arguments ([1, ...] mask / position ids / (cos, sin)) broadcast to n samples."""
+    wide = lambda t: t.expand(n, *t.shape[1:])
+    return {k: None if v is None else wide(v) if torch.is_tensor(v) else tuple(wide(t) for t in v) for k, v in kw.items()}
+
+
+@torch.no_grad()
+def llama_eval(model, testenc, dev, offload: bool = False, rows_per_call: int = 1, return_details: bool = False):
+    testenc = testenc.input_ids
+    seqlen = model.seqlen
+    nsamples = testenc.numel() // seqlen
+    layers = model.model.layers
+    batches = (testenc[:, i * seqlen:(i + 1) * seqlen] for i in range(nsamples))
+    inps, kw = capture_first_layer_inputs(model, batches, nsamples, dev, offload)
+    outs = torch.zeros_like(inps)
+    step = max(1, int(rows_per_call))
+    for i in range(len(layers)):
+        layer = layers[i].to(dev)
+        for j in range(0, nsamples, step):
+            n = min(step, nsamples - j)
+            outs[j:j + n] = layer(inps[j:j + n], **(kw if n == 1 else _for_batch(kw, n)))[0]
+        layers[i] = layer.cpu() if offload else layer
+        inps, outs = outs, inps
+    if model.model.norm is not None:
+        model.model.norm = model.model.norm.to(dev)
+    model.lm_head = model.lm_head.to(dev)
+    testenc = testenc.to(dev)
+    loss_fct = nn.CrossEntropyLoss()
+    nlls = []
+    for i in range(nsamples):
+        h = inps[i].unsqueeze(0)
+        if model.model.norm is not None:
+            h = model.model.norm(h)
+        logits = model.lm_head(h)
+        shift_logits = logits[:, :-1, :].contiguous()
+        shift_labels = testenc[:, i * seqlen:(i + 1) * seqlen][:, 1:]
+        loss = loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.reshape(-1))
+        nlls.append(loss.float() * seqlen)
+    ppl = torch.exp(torch.stack(nlls).sum() / (nsamples * seqlen)).item()
+    if return_details:
+        return ppl, torch.stack(nlls).cpu(), inps
+    return ppl

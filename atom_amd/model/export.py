@@ -50,6 +50,14 @@ def packed_state_dict(module: torch.nn.Module, prefix: str = "") -> dict:
         norm = getattr(mod, "originalNorm", None)
         if norm is not None and hasattr(norm, "weight"):
             out[f"{dot}weight"] = norm.weight.detach().to(torch.float16)
+    # what the quantisation flow leaves untouched (embedding, final norm, lm_head of a whole model): as they are.  Everything that lives
+    # under a QLinearLayer / a wrapped norm is already there in its packed form; rotary tables are recomputed by the kernels.
+    covered = tuple(f"{prefix}{name}." for name, mod in module.named_modules()
+                    if type(mod) is QLinearLayer or hasattr(mod, "originalNorm") or "rotary_emb" in name.split("."))
+    for k, v in module.state_dict().items():
+        full = f"{prefix}{k}"
+        if full not in out and not full.startswith(covered) and torch.is_tensor(v) and not k.endswith("reorder_index"):
+            out[full] = v
     return {k: v.detach().contiguous().cpu() for k, v in out.items()}
 
 

@@ -16,6 +16,8 @@ Keyword-only extras (defaults reproduce the reference CUDA kernels exactly):
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 
 from . import _lib as L
@@ -155,19 +157,16 @@ def reorder_fp16_i4(hidden_states: torch.Tensor, reorder_index, *, quant_mode="k
 
 _WS = {}
 _WS_RETIRED = []               # buffers replaced during a graph capture: launches captured earlier still point at them
-_WS_WEIGHT = {}                # (device, stream) -> identity of the weight whose F6 form the workspace starts with
 
 
-def _workspace(device, nbytes, weight_key=None):
+def _workspace(device, nbytes):
     """Scratch for split-K partial sums / re-coded operands / decode partials, per (device, stream): calls on one stream reuse it
     in stream order; calls on different streams never share a buffer.  Grown on demand (the old buffer is returned to the caching
     allocator, which keeps it alive for work already queued on its stream).  During HIP-graph capture a too small buffer is not
     freed -- launches captured earlier (also of an earlier graph captured on the same stream) reference it -- but retired, and
-    the new one comes out of the capturing graph's memory pool like every other tensor allocated during capture.
-    ``weight_key``: identity of the weight whose re-coded (F6) form this call leaves at the start of the buffer (the re-coding route
-    of atom_gemm_w4a4_f16_ws); the buffer remembers it, and the next call with the same key on the same buffer gets ``cached`` =
-    True (ATOM_WS_WEIGHT_CACHED: only the activation is re-coded).  Every other use of the buffer forgets the key.
-    Returns (buffer, cached)."""
+    the new one comes out of the capturing graph's memory pool like every other tensor allocated during capture.  Nothing is ever
+    expected to SURVIVE in this buffer from one call to the next (round 3 kept a weight's re-coded form at its head and trusted
+    that no other call had touched it -- unsafe under graph capture, and useless for a model whose projections share the buffer)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
@@ -175,11 +174,73 @@ def _workspace(device, nbytes, weight_key=None):
             _WS_RETIRED.append(t)
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = t
-        _WS_WEIGHT.pop(key, None)
-    prev = _WS_WEIGHT.get(key)
-    cached = weight_key is not None and prev is not None and prev[0] == weight_key[0]
-    _WS_WEIGHT[key] = weight_key                           # (key, storages): the entry keeps the weight's storages alive, so their
-    return t, cached                                       #  addresses cannot be handed to another tensor while it is cached
+    return t
+
+
+# ---- re-coded (F6) forms of PACKED weights that meet prefill-size batches through the reference-format entry points -------------------
+# A caller of the reference's operator surface hands dense_layer_gemm_i4_fp16 the packed INT4 weight on every call (llama.py:61-68).
+# From 257 rows on the fastest kernels want the F6 form; re-coding the weight on every call costs as much as re-coding the activation
+# (12 vs 6 us at 4096 x 4096).  So the F6 form of every weight seen here is kept -- per WEIGHT (its own tensor, nothing shares it), keyed
+# by the storage addresses and version counters of the packed weight and its scales, least recently used first out under a byte cap.
+# A Llama-7B's 224 projections are 5.5 GB in this form (0.84 B per weight) next to 288 GB of HBM.
+#   * an entry holds references to the packed tensors' storages, so a cached address cannot be handed to another tensor;
+#   * a weight rewritten in place bumps its version counter -> miss (writes through a `.data` / `.detach()` alias do NOT bump it:
+#     call forget_weight_f6(b) after such a write);
+#   * HIP-graph capture: nothing executes during capture, so an entry is never CREATED there (the call takes the workspace route and
+#     re-codes both operands inside the captured graph -- always right); a HIT during capture pins the entry for good, because the
+#     captured launch keeps pointing at it.
+_F6W = collections.OrderedDict()      # key -> [f6s tensor, storages kept alive, bytes, pinned]
+_F6W_STATE = {"limit": 32 << 30, "bytes": 0, "hits": 0, "misses": 0}
+
+
+def set_weight_f6_cache_bytes(limit: int):
+    """Byte cap of the re-coded-weight cache (0 disables it: every call re-codes both operands in the workspace)."""
+    _F6W_STATE["limit"] = int(limit)
+    _evict_f6w()
+
+
+def clear_weight_f6_cache():
+    _F6W.clear()
+    _F6W_STATE.update(bytes=0, hits=0, misses=0)
+
+
+def forget_weight_f6(b: torch.Tensor):
+    """Drop the cached F6 form(s) of the packed weight ``b`` (after writing it through an alias that keeps the version counter)."""
+    for key in [k for k in _F6W if k[1] == b.data_ptr() and k[0] == b.device]:
+        _F6W_STATE["bytes"] -= _F6W.pop(key)[2]
+
+
+def _evict_f6w():
+    for key in list(_F6W):
+        if _F6W_STATE["bytes"] <= _F6W_STATE["limit"]:
+            break
+        if not _F6W[key][3]:
+            _F6W_STATE["bytes"] -= _F6W.pop(key)[2]
+
+
+def _weight_f6s(b, b_scale, n, k):
+    """The cached F6 form (codes + float32 scales, ATOM_B_F6S) of a packed weight, or None when there is none and none may be made."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (b.device, b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k)
+    e = _F6W.get(key)
+    if e is not None:
+        _F6W.move_to_end(key)
+        _F6W_STATE["hits"] += 1
+        if capturing:
+            e[3] = True
+        return e[0]
+    if capturing or _F6W_STATE["limit"] <= 0:
+        return None
+    _F6W_STATE["misses"] += 1
+    g = k // GROUP_SIZE - 1
+    f6 = repack_weight_f6(b.view(torch.uint8), b_scale.reshape(-1)[:g * n])      # b_scale is read flat as [G][N] whatever its shape
+    nbytes = f6.atom_f6s.numel()
+    if nbytes > _F6W_STATE["limit"]:
+        return f6
+    _F6W[key] = [f6, (b.untyped_storage(), b_scale.untyped_storage()), nbytes, False]
+    _F6W_STATE["bytes"] += nbytes
+    _evict_f6w()
+    return f6
 
 
 def _gemm_dims(a, b, a_keeper, a_wide=False, b_keeper=None):
@@ -207,18 +268,20 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     # > 0 for skinny shapes that gain from split-K, and for packed operands of prefill size (re-coded to F6 in the workspace);
     # operands that are F6 already need none (the F6 kernels take no workspace)
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide == "f6" or (a_wide and m >= 2048)) else 0
-    # packed operands on the re-coding route: the weight's F6 form stays at the start of the workspace; a repeat call with the same
-    # weight (same storage, same version counters) on the same workspace re-codes the activation only
-    wkey = None
+    # packed operands of prefill size (the re-coding route): with the weight's F6 form cached (per weight, _weight_f6s) only the
+    # activation is re-coded, into a fresh tensor, and the F6 kernel runs on the two -- the kernel and the bits of the workspace route
     if ws_bytes and not a_wide and lib.atom_gemm_w4a4_ws_recodes(m, n, k):
-        wkey = ((b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k), (b.untyped_storage(), b_scale.untyped_storage()))
-    ws, cached = _workspace(a.device, ws_bytes, wkey) if ws_bytes else (None, False)
+        f6w = _weight_f6s(b, b_scale, n, k)
+        if f6w is not None:
+            a6 = repack_act_f6(a.view(torch.uint8), a_scale, scale_layout=scale_layout)
+            return dense_layer_gemm_i4_fp16(a6, f6w, a_scale, b_scale, a_keeper, b_keeper, a_keeper_scale, b_keeper_scale,
+                                            scale_layout=scale_layout, a_wide="f6")
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
     st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
                                    _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0))
-                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0)
-                                   | (L.WS_WEIGHT_CACHED if cached else 0),
+                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0),
                                    L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
@@ -238,7 +301,7 @@ def dense_layer_gemm_i4_o4(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keeper_
     d_scale = torch.empty((m, n // 128 * 2), dtype=torch.float16, device=a.device)
     lib = L.lib()
     ws_bytes = lib.atom_gemm_w4a4_o4_workspace_bytes(m, n, k) if use_workspace else 0
-    ws = _workspace(a.device, ws_bytes)[0] if ws_bytes else None
+    ws = _workspace(a.device, ws_bytes) if ws_bytes else None
     st = lib.atom_gemm_w4a4_o4_ws(a.data_ptr(), b.data_ptr(), a_scale.data_ptr(), b_scale.data_ptr(),
                                   a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                   b_keeper_scale.data_ptr(), d.data_ptr(), d_scale.data_ptr(), m, n, k, GROUP_SIZE,
@@ -319,8 +382,12 @@ def dense_layer_gemm_i4_multi(a, a_scale, a_keeper, a_keeper_scale, fused, *, f3
     return tuple(outs)
 
 
-def multi_q_gemm_fits(m: int, n_seg: int, nseg: int, k: int) -> bool:
-    return bool(L.lib().atom_gemm_w4a4_multi_q_fits(m, n_seg, nseg, k))
+_Q_OPS = {"reorder": L.Q_REORDER, "rmsnorm": L.Q_RMSNORM, "add_rmsnorm": L.Q_ADD_RMSNORM, "silu_mul": L.Q_SILU_MUL}
+
+
+def multi_q_gemm_fits(q_op: str, m: int, n_seg: int, nseg: int, k: int) -> bool:
+    """True when dense_layer_gemm_i4_multi_q(q_op, ...) takes the shape (the launcher's own predicate)."""
+    return bool(L.lib().atom_gemm_w4a4_multi_q_fits(_Q_OPS[q_op], int(m), int(n_seg), int(nseg), int(k)))
 
 
 def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, reorder_index=None, eps=0.0, clip=1.0, f32_mask=0, add=None):
@@ -330,7 +397,7 @@ def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, 
     factor); kernel-flavoured quantiser arithmetic.  ``x`` fp16 [M, K].  Returns (outs, residual_out): bit-identical to the quantiser op
     followed by dense_layer_gemm_i4_multi."""
     _require_cuda_half(x, "x")
-    code = {"reorder": L.Q_REORDER, "rmsnorm": L.Q_RMSNORM, "add_rmsnorm": L.Q_ADD_RMSNORM, "silu_mul": L.Q_SILU_MUL}[q_op]
+    code = _Q_OPS[q_op]
     m = x.size(0)
     n, nseg, k = fused["n_seg"], fused["nseg"], fused["k"]
     assert x.shape == (m, k) and x.is_contiguous()
@@ -462,7 +529,7 @@ def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 
     lib = L.lib()
     max_pages = int(getattr(kv, "max_pages", 0))
     ws_bytes = lib.atom_batch_decode_i4_workspace_bytes(batch, num_heads, page_size, max_pages)
-    ws = _workspace(q.device, ws_bytes)[0] if ws_bytes else None
+    ws = _workspace(q.device, ws_bytes) if ws_bytes else None
     st = lib.atom_batch_decode_i4(o.data_ptr(), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
                                   kv.indptr.data_ptr(), kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), batch,
                                   num_layers, int(layer_idx), num_heads, page_size, head_dim, float(rope_theta),

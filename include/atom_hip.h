@@ -202,7 +202,9 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
 #define ATOM_Q_RMSNORM 2
 #define ATOM_Q_ADD_RMSNORM 3
 #define ATOM_Q_SILU_MUL 4
-int atom_gemm_w4a4_multi_q_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total);
+/* 1 when atom_gemm_w4a4_multi_q takes (q_op, M, N_seg, nseg, K_total): the launcher's own predicate.  ATOM_Q_SILU_MUL allows three
+ * 16-channel slots per thread of the 512, the other three ops two (they also stage the fp16 rows and the norm weight in LDS). */
+int atom_gemm_w4a4_multi_q_fits(int q_op, int64_t M, int64_t N_seg, int nseg, int64_t K_total);
 int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *residual, void *residual_out,
                            const int16_t *reorder_index, float eps, float clip, const void *B4, const void *sB, const void *B8,
                            const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask, const void *add0_f16, int64_t M,

@@ -88,15 +88,23 @@ def test_packed_route_query():
 
 
 def test_fused_quantiser_shape_query():
-    """atom_gemm_w4a4_multi_q_fits: one or two tokens, the shapes atom_gemm_w4a4_multi takes, at most three slot tasks per thread of the
-    quantiser (K_total / 16 slots per row over 512 threads)."""
+    """atom_gemm_w4a4_multi_q_fits(q_op, ...): one or two tokens, the shapes atom_gemm_w4a4_multi takes, and the launcher's own bounds
+    per quantiser (gemm_w4a4_skinny.hip skinny_q_fits): per thread of the 512 at most two 16-channel slot tasks (SiLU x up: three), at
+    most three 16-byte chunks of the fp16 rows and two of the norm weight (ops 1-3)."""
     from atom_amd import _lib
     L = _lib.lib()
     fq, fm = L.atom_gemm_w4a4_multi_q_fits, L.atom_gemm_w4a4_multi_fits
-    assert fq(1, 4096, 3, 4096) == 1 and fq(2, 4096, 1, 4096) == 1 and fq(1, 11008, 2, 4096) == 1 and fq(2, 4096, 1, 11008) == 1
-    assert fq(3, 4096, 1, 4096) == 0 and fq(0, 4096, 1, 4096) == 0 and fm(3, 4096, 1, 4096) == 1
-    assert fq(2, 5120, 1, 13824) == 0 and fq(1, 5120, 1, 13824) == 1          # 2 x 864 slots > 3 x 512
-    assert fq(1, 4096, 4, 4096) == 0 and fq(1, 24, 1, 4096) == 0 and fq(1, 4096, 1, 4000) == 0
+    RE, RN, AR, SM = _lib.Q_REORDER, _lib.Q_RMSNORM, _lib.Q_ADD_RMSNORM, _lib.Q_SILU_MUL
+    assert fq(RN, 1, 4096, 3, 4096) == 1 and fq(RE, 2, 4096, 1, 4096) == 1 and fq(AR, 1, 11008, 2, 4096) == 1 and fq(SM, 2, 4096, 1, 11008) == 1
+    assert fq(RE, 3, 4096, 1, 4096) == 0 and fq(RE, 0, 4096, 1, 4096) == 0 and fm(3, 4096, 1, 4096) == 1
+    assert fq(0, 1, 4096, 1, 4096) == 0 and fq(5, 1, 4096, 1, 4096) == 0
+    assert fq(SM, 2, 5120, 1, 13824) == 0 and fq(SM, 1, 5120, 1, 13824) == 1          # 2 x 864 slots > 3 x 512
+    assert fq(RE, 1, 4096, 4, 4096) == 0 and fq(RE, 1, 24, 1, 4096) == 0 and fq(RE, 1, 4096, 1, 4000) == 0
+    # the round-3 advisor's cases: two tokens at hidden 6656 / 8192 / 11008 -- only SiLU x up fits (no rows staged in LDS)
+    for h in (6656, 8192, 11008):
+        assert fq(RE, 2, 4096, 1, h) == 0 and fq(RN, 2, 4096, 1, h) == 0 and fq(AR, 2, 4096, 1, h) == 0 and fq(SM, 2, 4096, 1, h) == 1
+        assert fq(RE, 1, 4096, 1, h) == (1 if h <= 8192 else 0)                      # one row: h / 8 chunks <= 2 x 512
+    assert fq(RE, 2, 4096, 1, 6144) == 1 and fq(RE, 2, 4096, 1, 6272) == 0                # M * K / 8 <= 1536
 
 
 def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):

@@ -28,7 +28,15 @@ def test_reference_callers_resolve_to_our_modules(tmp_path):
         sys.path.append({REF!r})
         import quant, qLinearLayer, qLlamaLayer
         assert quant.__file__.startswith({ROOT!r}) and qLlamaLayer.__file__.startswith({ROOT!r})
-        import gptq, outlier, modelutils_llama
+        import gptq, outlier
+        import importlib.util                       # the reference's OWN modelutils_llama (dropin/ carries a mirror of that name too)
+        spec = importlib.util.spec_from_file_location("ref_modelutils_llama", {REF!r} + "/modelutils_llama.py")
+        modelutils_llama = importlib.util.module_from_spec(spec); spec.loader.exec_module(modelutils_llama)
+        import modelutils_llama as mirror, eval as mirror_eval
+        assert mirror.__file__.startswith({ROOT!r}) and mirror_eval.__file__.startswith({ROOT!r})
+        for f in ("reorder_model_llama", "add_act_quant_wrapper_llama", "quantize_model_llama", "quantize_model_gptq_llama"):
+            assert callable(getattr(mirror, f)) and callable(getattr(modelutils_llama, f))
+        assert callable(mirror_eval.llama_eval)
         import atom_amd.model.qLinearLayer as ours
         assert gptq.QLinearLayer is ours.QLinearLayer and outlier.QLinearLayer is ours.QLinearLayer
         assert modelutils_llama.QLlamaDecoderLayer.__module__ == 'atom_amd.model.qLlamaLayer'

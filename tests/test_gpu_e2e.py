@@ -218,7 +218,7 @@ def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, n
     import types
     from atom_amd import ops
     from tests.helpers import rand_gemm_operands, to_device
-    assert ops.multi_q_gemm_fits(M, N, nseg, K)
+    assert ops.multi_q_gemm_fits(op, M, N, nseg, K)
     devs = [to_device(rand_gemm_operands(4, N, K, seed=51 + i), "ref") for i in range(nseg)]
     mods = [types.SimpleNamespace(weight_int4=torch.nn.Parameter(dv[1], requires_grad=False), weight_int8=torch.nn.Parameter(dv[5], requires_grad=False),
                                   scale_int4=torch.nn.Parameter(dv[3], requires_grad=False), scale_int8=torch.nn.Parameter(dv[7], requires_grad=False),
@@ -331,3 +331,41 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     else:
         assert (caches[0][0] != caches[1][0]).float().mean().item() == 0        # k / v take the same kernel either way
         assert (outs[0].float() - outs[1].float()).abs().max().item() <= 0.05 * outs[0].float().abs().max().item()
+
+
+def test_fused_quantiser_query_is_the_launchers_predicate_at_wide_hidden_sizes():
+    """Round-3 advisor item: at two tokens and hidden 8192 the reorder / RMSNorm variants of atom_gemm_w4a4_multi_q do not fit (their
+    fp16 rows and norm weights are staged in LDS by 512 threads) while SiLU x up does; the query used to say yes for all of them and
+    the decode step then failed inside the launch.  The query and the launcher now share one predicate: what the query accepts
+    launches, what it refuses raises, and a decode layer at that width takes the separate launches instead."""
+    import atom_amd.e2e.llama as E
+    from atom_amd import ops
+    from atom_amd._lib import AtomHipError
+    from atom_amd.e2e import LlamaDecoderLayer
+    from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    assert ops.multi_q_gemm_fits("reorder", 1, 8192, 1, 8192) and not ops.multi_q_gemm_fits("reorder", 2, 8192, 1, 8192)
+    assert not ops.multi_q_gemm_fits("rmsnorm", 2, 6656, 3, 6656) and ops.multi_q_gemm_fits("silu_mul", 2, 4096, 1, 8192)
+    assert not ops.multi_q_gemm_fits("reorder", 2, 4096, 1, 11008) and ops.multi_q_gemm_fits("silu_mul", 2, 4096, 1, 11008)
+    dev = torch.device("cuda")
+    cfg = _attn_cfg(H=8192, heads=64)
+    layer = LlamaDecoderLayer(cfg, layer_idx=0).cuda()
+    _load_layer(layer, 21)
+    x = (torch.randn(2, 8192) * 0.7).half().cuda()
+    with pytest.raises(AtomHipError):
+        ops.dense_layer_gemm_i4_multi_q("reorder", x, layer.self_attn.o_proj.single(), reorder_index=layer.self_attn.reorder_index)
+    outs = []
+    for fq in (True, False):
+        E._FUSED_Q_DECODE = fq
+        try:
+            pool = KvPoolInt4(num_layers=1, num_heads=64, head_dim=128, capacity=8, block_len=16, device=dev)
+            g = torch.Generator(device="cuda").manual_seed(9)
+            pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
+            pool.param.copy_((torch.rand(pool.param.shape, device=dev, generator=g) * 0.05 + 0.01).half())
+            cs = [KvCacheInt4(pool, 20) for _ in range(2)]
+            for c in cs:
+                c.acquire_one()
+            outs.append(layer(x, BatchLenInfo([], 2, dev), None, BatchedKvCacheInt4(cs)))
+        finally:
+            E._FUSED_Q_DECODE = True
+    assert layer._fused_q_fits(2) is False and layer._fused_q_fits(1) is True
+    assert torch.equal(outs[0], outs[1])

@@ -557,11 +557,12 @@ def test_gemm_f6_256x128_kernel_bit_exact(M, N, K):
     assert torch.equal(plain, out)
 
 
-def test_packed_route_weight_cached_in_workspace():
-    """ATOM_WS_WEIGHT_CACHED: on the re-coding route of atom_gemm_w4a4_f16_ws (packed operands of prefill size) the weight's F6 form
-    stays at the start of the caller's workspace; atom_amd.ops passes the flag when the same weight (storage + version counters)
-    meets the same workspace again.  Results must not depend on it: repeat calls, another batch size, another weight in between, and a
-    weight rewritten in place all give the bits of a fresh workspace."""
+def test_packed_route_weight_f6_cache():
+    """Packed (reference-format) operands of prefill size: atom_amd.ops keeps the weight's re-coded F6 form per WEIGHT (least recently
+    used out under a byte cap) and re-codes only the activation on later calls.  Results must not depend on it: repeat calls, another
+    batch size, other weights in between (a 7-projection layer walks them in turn: every one must hit from the second pass on),
+    eviction, a split-K / o4 / decode user of the scratch workspace in between, and a weight rewritten in place all give the bits of the
+    uncached workspace route."""
     from atom_amd import ops
     lib = ops.L.lib()
     N, K = 2048, 1152
@@ -569,32 +570,121 @@ def test_packed_route_weight_cached_in_workspace():
     d2 = rand_gemm_operands(1024, N, K, seed=12)
     assert lib.atom_gemm_w4a4_ws_recodes(1024, N, K) == 1 and lib.atom_gemm_w4a4_ws_recodes(256, N, K) == 0
     dev1, dev2 = to_device(d1, "plain"), to_device(d2, "plain")
+    st = ops._F6W_STATE
 
-    def fresh(dev):
-        ops._WS.clear(); ops._WS_WEIGHT.clear()
-        return ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")
-    want1, want2 = fresh(dev1), fresh(dev2)
-    ops._WS.clear(); ops._WS_WEIGHT.clear()
-    key = lambda: next(iter(ops._WS_WEIGHT.values()))[0]
-    y = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
-    k1 = key()
-    assert k1 is not None and torch.equal(y, want1)
-    y = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")            # cached: activation re-coded only
-    assert key() == k1 and torch.equal(y, want1)
-    # same weight, other activations and another batch size (the weight region does not move with M)
+    def uncached(dev):
+        ops.set_weight_f6_cache_bytes(0)
+        try:
+            return ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain")
+        finally:
+            ops.set_weight_f6_cache_bytes(32 << 30)
+    want1, want2 = uncached(dev1), uncached(dev2)
+    ops.clear_weight_f6_cache()
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1) and (st["hits"], st["misses"]) == (0, 1)
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1) and (st["hits"], st["misses"]) == (1, 1)
+    # same weight, other activations and another batch size
     mixed = [dev2[0][:800], dev1[1], dev2[2][:, :800].contiguous(), dev1[3], dev2[4][:800], dev1[5], dev2[6][:800], dev1[7]]
     y = ops.dense_layer_gemm_i4_fp16(*mixed, scale_layout="plain")
-    ops._WS.clear(); ops._WS_WEIGHT.clear()
-    assert torch.equal(y, ops.dense_layer_gemm_i4_fp16(*mixed, scale_layout="plain"))
-    # another weight in between, a split-K call in between (partials over the weight region), then the first weight again
-    ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
-    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev2, scale_layout="plain"), want2)
+    assert st["hits"] == 2 and torch.equal(y, uncached(mixed))
+    # several weights in turn, twice: the second pass hits every one of them (what a layer's projections do to the cache)
+    more = [to_device(rand_gemm_operands(512, N, K, seed=20 + i), "plain") for i in range(5)]
+    wants = [uncached(d) for d in more]
+    for rep in range(2):
+        h0 = st["hits"]
+        for d, w in zip(more, wants):
+            assert torch.equal(ops.dense_layer_gemm_i4_fp16(*d, scale_layout="plain"), w)
+        assert st["hits"] - h0 == (0 if rep == 0 else 5)
+    # users of the scratch workspace in between (split-K partial sums, the decode-batch o4 route): nothing of the cache lives there
+    assert lib.atom_gemm_w4a4_workspace_bytes(136, 512, 4224) > 0 and lib.atom_gemm_w4a4_ws_recodes(136, 512, 4224) == 0       # split-K route
+    sk = to_device(rand_gemm_operands(136, 512, 4224, seed=13), "plain")
+    ops.dense_layer_gemm_i4_fp16(*sk, scale_layout="plain")
+    ops.dense_layer_gemm_i4_o4(*[t[:16] if i in (0, 4, 6) else (t[:, :16].contiguous() if i == 2 else t) for i, t in enumerate(dev2)], scale_layout="plain")
     assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1)
-    small = [dev1[0][:300], dev1[1], dev1[2][:, :300].contiguous(), dev1[3], dev1[4][:300], dev1[5], dev1[6][:300], dev1[7]]
-    ops.dense_layer_gemm_i4_fp16(*small, scale_layout="plain")
+    # eviction under a byte cap that holds two weights: results unchanged, the footprint stays under the cap
+    one = ops._F6W[next(iter(ops._F6W))][2]
+    ops.set_weight_f6_cache_bytes(2 * one)
+    assert len(ops._F6W) == 2 and st["bytes"] == 2 * one
+    for d, w in zip(more, wants):
+        assert torch.equal(ops.dense_layer_gemm_i4_fp16(*d, scale_layout="plain"), w) and st["bytes"] <= 2 * one
+    ops.set_weight_f6_cache_bytes(32 << 30)
+    # the weight rewritten IN PLACE: the version counter changes, the entry does not match
     assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), want1)
-    # the weight rewritten IN PLACE: the version counter changes, the cache entry does not match
     dev1[1].copy_(dev2[1]); dev1[3].copy_(dev2[3]); dev1[5].copy_(dev2[5]); dev1[7].copy_(dev2[7])
     got = ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain")
-    ops._WS.clear(); ops._WS_WEIGHT.clear()
-    assert torch.equal(got, ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"))
+    assert torch.equal(got, uncached(dev1))
+    # ... and through an alias that keeps the counter: forget_weight_f6 is the documented way
+    dev1[1].data.copy_(dev2[1].flip(0)); dev1[3].data.copy_(dev2[3])
+    ops.forget_weight_f6(dev1[1])
+    assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), uncached(dev1))
+    ops.clear_weight_f6_cache()
+
+
+def test_packed_route_under_hip_graph_capture():
+    """Round-3 advisor / verdict item: a cached weight must never make a captured graph depend on what other calls left behind.
+    (a) capture with the weight NOT cached: nothing executes during capture, so no entry may be created -- the captured call re-codes
+    both operands inside the graph; (b) capture with the weight cached: the captured launch points at the entry, which is pinned.
+    In both cases: capture(weight A) -> eager calls with weight B (and eviction pressure) -> replay == the uncached result, and an
+    eager call right after a capture is right too."""
+    from atom_amd import ops
+    N, K = 2048, 1152
+    A = to_device(rand_gemm_operands(512, N, K, seed=31), "plain")
+    B = to_device(rand_gemm_operands(512, N, K, seed=32), "plain")
+    ops.set_weight_f6_cache_bytes(0)
+    wantA = ops.dense_layer_gemm_i4_fp16(*A, scale_layout="plain")
+    wantB = ops.dense_layer_gemm_i4_fp16(*B, scale_layout="plain")
+    ops.set_weight_f6_cache_bytes(32 << 30)
+    for precached in (False, True):
+        ops.clear_weight_f6_cache()
+        if precached:
+            ops.dense_layer_gemm_i4_fp16(*A, scale_layout="plain")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = ops.dense_layer_gemm_i4_fp16(*A, scale_layout="plain")
+        entries = list(ops._F6W.values())
+        assert len(entries) == (1 if precached else 0) and all(e[3] for e in entries)         # created never, pinned if hit
+        # an eager call right after the capture (the captured launches have not run yet)
+        assert torch.equal(ops.dense_layer_gemm_i4_fp16(*A, scale_layout="plain"), wantA)
+        # another weight on the same stream / scratch workspace, then eviction pressure
+        assert torch.equal(ops.dense_layer_gemm_i4_fp16(*B, scale_layout="plain"), wantB)
+        ops.set_weight_f6_cache_bytes(1)
+        ops.set_weight_f6_cache_bytes(32 << 30)
+        assert len(ops._F6W) == (1 if precached else 0)                                       # the pinned entry survives
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, wantA)
+        # a second graph captured on the same capture stream, starting with the same weight (the advisor's scenario)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            y2 = ops.dense_layer_gemm_i4_fp16(*A, scale_layout="plain")
+        ops.dense_layer_gemm_i4_fp16(*B, scale_layout="plain")
+        g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y2, wantA)
+        del g, g2
+    ops.clear_weight_f6_cache()
+
+
+def test_c_abi_ws_weight_cached_flag():
+    """ATOM_WS_WEIGHT_CACHED of the C ABI (include/atom_hip.h; the contract a foreign caller that owns its workspace gets): the second
+    call with the same weight and workspace may assert the flag and gets the bits of the first."""
+    from atom_amd import ops
+    L = ops.L
+    lib = L.lib()
+    M, N, K = 512, 2048, 1152
+    dev = to_device(rand_gemm_operands(M, N, K, seed=41), "plain")
+    a, b, sa, sb, a8, b8, sa8, sb8 = dev
+    need = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
+    assert need > 0 and lib.atom_gemm_w4a4_ws_recodes(M, N, K) == 1
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    outs = []
+    for flag in (0, L.WS_WEIGHT_CACHED, L.WS_WEIGHT_CACHED):
+        d = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), a8.data_ptr(), b8.data_ptr(), sa8.data_ptr(),
+                                       sb8.data_ptr(), d.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | flag, ws.data_ptr(), need,
+                                       L.current_stream(a.device))
+        L.check(st, "atom_gemm_w4a4_f16_ws")
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain"))
