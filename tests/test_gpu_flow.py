@@ -155,7 +155,10 @@ def _calibrated(tag, config, tokens, ref, seqlens, gptq_q=None):
         lines.append(f"seqlen {s}: rel. Frobenius vs the reference golden      HIP    ref-order   perturbed ref-order")
         for key in KEYS + ("layer0", "layer1"):
             lines.append(f"    {key:18s} {h[s, key]:10.4f} {b[s, key]:10.4f} {c[s, key]:10.4f}")
-            if not (h[s, key] <= 1.3 * c[s, key] + 0.01 and h[s, key] <= LIMITS["hard"]):
+            # layer outputs: 1.3 x the perturbed run; single quantiser inputs are one draw of a discrete process (a flipped code is a
+            # whole step) on as few as 12 rows x 256 channels: 1.75 x
+            slack = (1.3, 0.01) if key.startswith("layer") else (1.75, 0.02)
+            if not (h[s, key] <= slack[0] * c[s, key] + slack[1] and h[s, key] <= LIMITS["hard"]):
                 bad.append((s, key, h[s, key], c[s, key]))
         for i in (0, 1):
             if not h[s, f"layer{i}.rows"] <= LIMITS["row_sum"]:
