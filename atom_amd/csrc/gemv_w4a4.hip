@@ -112,112 +112,107 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
   }
 }
 
-// M = 1 (BASELINE config 2), second version: no LDS, no barrier.  The staged version above is a chain of three dependent round trips
-// (activation row -> LDS, barrier, then the weight row, its scales last); with one token every lane can ask for everything it will
-// ever need in its first instructions -- its weight chunks (HBM), the matching activation chunks and the group's two scales (L2:
-// every wave reads the same 2 KB row) -- so the launch is ONE memory round trip deep.  Same per-lane arithmetic and summation
-// order as gemv_w4a4_kernel<1> (bit-identical output).  UNR chunks per lane are in flight per batch (K = 4096: one batch).
-template <int UNR, int ROWS>
+// M = 1 (BASELINE config 2): no LDS, no barrier -- every lane asks for its weight chunk (HBM), the matching activation chunk and the
+// group's two scales (L2) in the same few instructions, so a K batch is ONE memory round trip deep.
+// Round 4 (tools/probes/gemv_probe.cpp, profiles/r04/gemv_probe.txt): the round-3 form of this kernel kept a whole row (up to 4 chunks
+// per lane, their activations and scales) in registers -- 65-107 VGPRs, i.e. 4-7 waves per SIMD -- and reached 0.23-0.33 of 8 TB/s cold
+// where a plain streaming read of the same bytes reaches 0.39 (8.9 MB) to 0.69 (37 MB).  What the probe showed:
+//   * the read rate is set by how many waves are resident, not by how much one wave has in flight: ONE 16-byte chunk per feature and
+//     batch (22-29 VGPRs, every wave slot of the CU filled) beats 2-4 chunks per lane on every shape;
+//   * workgroup b runs on XCD b % 8 and a 64-byte line of weight scales holds 32 adjacent features of one group: with the features
+//     dealt round-robin every XCD's L2 fetched every line (8 x the scale traffic, +23 % bytes at 4096 x 4096); each XCD now owns a
+//     contiguous eighth of the features;
+//   * two adjacent features per wave (R = 2) share the activation chunk and the token scale: better from 8192 features up;
+//   * staging the activation row and the scale tile in LDS once per workgroup measured equal to reading them per wave from L2.
+// 1 x 13824 x 5120: 16.6 -> 10.2 us cold (0.28 -> 0.47 of 8 TB/s), 1 x 4096 x 4096: 4.86 -> 4.13 (0.23 -> 0.27; the plain read of
+// these bytes takes 2.8 us, 1.6 of them the launch).  Same per-lane arithmetic and summation order as before: lane l owns chunks
+// l, l + 64, ... in ascending order, a quad sums a group exactly, the quad leader applies the two scales (bit-identical output).
+template <int R>
 __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K4h = p.K4h;
   const int nchunks = K4h >> 4;
   const bool leader = (lane & 3) == 0;
-  const int nwaves = gridDim.x * 4;
-  // ROWS output features per wave are in flight together (rows n, n + nwaves, ...): with more rows than resident waves the second
-  // row's round trip would otherwise start only when the first one's result is stored
-  for (int n0 = blockIdx.x * 4 + wave; n0 < p.N; n0 += nwaves * ROWS) {
-    v4i w8[ROWS], a8 = {0, 0, 0, 0};
-    half_t sb8h[ROWS];
-    if (lane < 8) a8 = *reinterpret_cast<const v4i *>(p.A8 + lane * 16);
+  // bijective XCD-aware map: XCD x = b % 8 takes the blocks [x * q + min(x, rem), ...) of the feature axis
+  const int q = (int)gridDim.x >> 3, rem = (int)gridDim.x & 7;
+  const int x = blockIdx.x & 7;
+  const int blk = x * q + min(x, rem) + (blockIdx.x >> 3);
+  const int n0 = (blk * 4 + wave) * R;
+  if (n0 >= p.N) return;                                  // (wave-uniform)
+  int nr[R];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int n = min(n0 + r * nwaves, p.N - 1);
-      w8[r] = v4i{0, 0, 0, 0};
-      if (lane < 8) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + lane * 16);
-      sb8h[r] = p.sB8[n];
-    }
-    const half_t sa8h = p.sA8[0];
-    float acc[ROWS];
+  for (int r = 0; r < R; ++r) nr[r] = min(n0 + r, p.N - 1);
+  float acc[R];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    for (int c0 = 0; c0 < nchunks; c0 += 64 * UNR) {
-      v4i w[ROWS][UNR], a[UNR];
-      half_t sbh[ROWS][UNR], sah[UNR];
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  const unsigned short *sBu = reinterpret_cast<const unsigned short *>(p.sB), *sAu = reinterpret_cast<const unsigned short *>(p.sA);
+  // the keeper's operands are requested with the first instructions and consumed after the K loop (behind the loop they would be one
+  // more dependent round trip at the very end of every wave)
+  const v4i a8 = *reinterpret_cast<const v4i *>(p.A8 + (lane & 7) * 16);   // lanes 8.. hold copies; lane 0's sums touch lanes 0-7 only
+  const unsigned short sa8u = reinterpret_cast<const unsigned short *>(p.sA8)[0];
+  v4i w8[R];
+  unsigned short sb8u[R];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int c = c0 + u * 64 + lane;
-        const bool ok = c < nchunks;
-        a[u] = v4i{0, 0, 0, 0};
-        sah[u] = (half_t)0;
+  for (int r = 0; r < R; ++r) {
+    w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)nr[r] * kKeeper + (lane & 7) * 16);
+    sb8u[r] = reinterpret_cast<const unsigned short *>(p.sB8)[nr[r]];
+  }
+  for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < nchunks;
+    // NO divergent control flow around the loads: a lane past the end re-reads the last chunk and every lane of a quad reads the
+    // group's scales (same address: one request).  Inside `if (ok) / if (leader)` blocks the compiler waits for each 16-bit scale
+    // load before leaving the block -- and, vmcnt being in order, for the weight chunk issued before it: two or three dependent
+    // round trips per batch instead of one (the round-4 rewrite measured 4.7 us instead of 4.1 at 4096 x 4096 until this was gone).
+    const int cc = min(c, nchunks - 1);
+    v4i w[R];
+    unsigned short sbu[R];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int n = min(n0 + r * nwaves, p.N - 1);
-          w[r][u] = v4i{0, 0, 0, 0};
-          sbh[r][u] = (half_t)0;
-          if (ok) {
-            w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)n * K4h + c * 16));   // nt: read once, by this CU only (gemm_w4a4_skinny.hip, NT)
-            if (leader) sbh[r][u] = p.sB[(int64_t)(c >> 2) * p.N + n];
-          }
-        }
-        if (ok) {
-          a[u] = *reinterpret_cast<const v4i *>(p.A4 + c * 16);
-          if (leader) sah[u] = p.sA[(int64_t)(c >> 2) * p.ldA];            // token 0: index 0 in either scale layout
-        }
-      }
+    for (int r = 0; r < R; ++r) w[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)nr[r] * K4h + cc * 16));   // nt: read once, by this CU only
+    const v4i a = *reinterpret_cast<const v4i *>(p.A4 + cc * 16);
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
+    for (int r = 0; r < R; ++r) sbu[r] = sBu[(int64_t)(cc >> 2) * p.N + nr[r]];
+    const unsigned short sau = sAu[(int64_t)(cc >> 2) * p.ldA];          // token 0: index 0 in either scale layout
+    const float saf = (float)__builtin_bit_cast(half_t, sau);
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          int d = 0;
-          d = __builtin_amdgcn_sdot8(a[u][0], w[r][u][0], d, false);
-          d = __builtin_amdgcn_sdot8(a[u][1], w[r][u][1], d, false);
-          d = __builtin_amdgcn_sdot8(a[u][2], w[r][u][2], d, false);
-          d = __builtin_amdgcn_sdot8(a[u][3], w[r][u][3], d, false);
-          d = quad_sum(d);                                  // exact: the group's 128-element integer dot
-          if (leader && c0 + u * 64 + lane < nchunks) {
-            const float t = (float)d * (float)sah[u];
-            acc[r] = __builtin_fmaf(t, (float)sbh[r][u], acc[r]);
-          }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int n = n0 + r * nwaves;
+    for (int r = 0; r < R; ++r) {
       int d = 0;
-      d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false);
-      d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
-      d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false);
-      d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
-      d = quad_sum(d);
-      d += __shfl_xor(d, 4);
-      float s = acc[r];
-      s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
-      if (lane == 0 && n < p.N) {
-        const float t = (float)d * (float)sa8h;
-        p.D[n] = f2h(__builtin_fmaf(t, (float)sb8h[r], s));
-      }
+      d = __builtin_amdgcn_sdot8(a[0], w[r][0], d, false);
+      d = __builtin_amdgcn_sdot8(a[1], w[r][1], d, false);
+      d = __builtin_amdgcn_sdot8(a[2], w[r][2], d, false);
+      d = __builtin_amdgcn_sdot8(a[3], w[r][3], d, false);
+      d = quad_sum(d);                                    // exact: the group's 128-element integer dot
+      const float t = (float)d * saf;
+      const float next = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sbu[r]), acc[r]);
+      acc[r] = (leader && ok) ? next : acc[r];
+    }
+  }
+  const float sa8f = (float)__builtin_bit_cast(half_t, sa8u);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int d = 0;
+    d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false);
+    d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
+    d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false);
+    d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
+    d = quad_sum(d);
+    d += __shfl_xor(d, 4);
+    float s = acc[r];
+    s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
+    if (lane == 0 && n0 + r < p.N) {
+      const float t = (float)d * sa8f;
+      p.D[n0 + r] = f2h(__builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s));
     }
   }
 }
 
 static int launch_gemv1(const GemmParams &p, hipStream_t s) {
-  // one wave per output feature, at most 2048 workgroups (the resident set: 8 per CU); beyond that a wave walks its features one
-  // after the other.  (Measured, profiles/r02_decode.txt: more workgroups, or two features in flight per wave (ROWS = 2, tuning
-  // only), are not faster.)
-  const int nb = (p.N + 3) / 4;
-  const int rows2 = ATOM_TUNE("ATOM_GEMV1_ROWS2", 0);
-  int blocks = rows2 ? (nb + 1) / 2 : nb;
-  if (blocks > 2048) blocks = 2048;
-  const bool k2 = p.K4h <= 2 * 64 * 16;
-  if (rows2) {
-    if (k2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemv1_w4a4_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-  } else {
-    if (k2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemv1_w4a4_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-  }
+  // one wave per R adjacent output features, every wave resident at once (no feature loop); R = 2 from 8192 features up
+  const int R = p.N >= 8192 ? 2 : 1;
+  const int blocks = (p.N + 4 * R - 1) / (4 * R);
+  if (R == 2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemv1_w4a4_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   return check_launch();
 }
 

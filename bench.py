@@ -176,6 +176,46 @@ def cold_launches(step, dev, n=30, flush_mb=512):
     return float(np.mean(times)), float(np.median(times)), len(times)
 
 
+def configs_sweep(dev):
+    """The other BASELINE configs beside the headline (N = 1 only; each row a fraction of a second): configs[1] (M = 1, N = K = 4096:
+    the bandwidth-bound decode GEMM), the corners of configs[4] (hidden 5120: M in {1, 64, 256, 2048} x the two wide shapes) and the
+    4096-wide batch sweep of the reference's own NVBench driver (bench_dense_layer_gemm_i4_o16.cu:64-69).  Packed (reference-format)
+    operands through atom_gemm_w4a4_f16_ws, timed per launch by HIP-graph replay (the Python launch loop is slower than a 3 us kernel):
+    hot = one operand set replayed, cold = the graph cycles through enough distinct weight sets (>= 600 MB) that every launch streams
+    its weights from HBM -- what a model's layers do (tools/cold_bench.py).  From 257 rows the native BF6 operand format is timed
+    beside it (`f6_us`, hot).  Fractions: of 8 TB/s on the algorithmic bytes (`frac_hbm`), of the dense INT8 MFMA peak (`frac_mfma`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cold_bench as CB
+    from atom_amd import _lib as L
+    lib = L.lib()
+    rows = []
+    shapes = [("C2", 1, 4096, 4096)]
+    shapes += [("C5", m, n, k) for (n, k) in ((13824, 5120), (5120, 13824)) for m in (1, 64, 256, 2048)]
+    shapes += [("C5", 64, 5120, 5120)]
+    shapes += [("M-sweep", m, 4096, 4096) for m in (16, 64, 128, 256, 512, 1024)]
+    for tag, M, N, K in shapes:
+        hot, cold = CB.gemm_row(M, N, K, quiet=True)
+        by, op = algorithmic_bytes(M, N, K), 2.0 * M * N * K
+        row = {"config": tag, "M": M, "N": N, "K": K, "hot_us": round(hot, 2), "cold_us": round(cold, 2),
+               "cold_gbps": round(by / cold / 1e3, 1), "cold_frac_hbm": round(by / cold / 1e6 / 8.0, 4),
+               "hot_frac_hbm": round(by / hot / 1e6 / 8.0, 4),
+               "cold_tops": round(op / cold / 1e6, 1), "cold_frac_mfma": round(op / cold / 1e6 / PEAK_I8_TOPS, 4)}
+        if M >= 257:
+            ops_ = make_operands(M, N, K, dev, seed=1)
+            a6, b6 = build_f6_operands(ops_, M, N, K, dev)
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ptrs = [a6.data_ptr(), b6.data_ptr()] + [t.data_ptr() for t in ops_[2:]]
+            f = lambda st: lib.atom_gemm_w4a4_f16(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S, st)
+            f6 = CB.graph_time([f], 64)
+            row.update({"f6_us": round(f6, 2), "f6_tops": round(op / f6 / 1e6, 1), "f6_frac_mfma": round(op / f6 / 1e6 / PEAK_I8_TOPS, 4)})
+            del ops_, a6, b6, D
+        rows.append(row)
+        torch.cuda.empty_cache()
+    return {"method": "HIP-graph replay, per launch; hot = one operand set, cold = distinct weight sets >= 600 MB cycled (every launch "
+                      "streams its weights from HBM); packed reference-format operands through atom_gemm_w4a4_f16_ws; f6_* = native BF6 operands",
+            "rows": rows}
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources: a committed PMC pass is quoted only for the sources it was taken from."""
     import hashlib
@@ -301,6 +341,9 @@ def main():
     ap.add_argument("--format", choices=["f6", "packed", "wide"], default="f6",
                     help="operand format of the headline measurement (the other two are reported beside it at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side sweep over the other BASELINE configs (N=1 only)")
+    ap.add_argument("--with-block", action="store_true", help="also run --workload block (BASELINE configs[3]) and put its numbers "
+                                                                "into the line's `configs` (adds ~1-2 minutes)")
     ap.add_argument("--workload", choices=["gemm", "block"], default="gemm",
                     help="gemm = the headline GEMM (BASELINE configs[2]); block = one Llama-7B decoder block, batch 32 x seq 2048, "
                          "KV INT4, through QLlamaDecoderLayer (BASELINE configs[3]; a step = one block forward; --steps 3 is plenty)")
@@ -370,20 +413,40 @@ def main():
                "both operands BF6 group-major (ATOM_AB_F6): v_mfma_f32_16x16x128_f8f6f4, exact integer dot products; the "
                "format the fused quantisers emit for prefill batches"),
         "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
-                      "reference packed format through atom_gemm_w4a4_f16_ws: the activation is re-coded to BF6 in the caller's workspace "
-                      "by every call, the (static) weight by the first call only (ATOM_WS_WEIGHT_CACHED afterwards), then the BF6 "
-                      "MFMA kernel; what atom_amd.ops does for packed operands"),
+                      "reference packed format through atom_gemm_w4a4_f16_ws with a caller-owned workspace, nothing cached: BOTH operands "
+                      "are re-coded to BF6 in the workspace by every call, then the BF6 MFMA kernel -- what a one-to-one binding of the "
+                      "reference's launcher with a workspace gets (INTEGRATION.md)"),
+        "packed_ws_same_weight": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+                                  "as packed_ws, REPEATED CALLS WITH ONE WEIGHT: the caller asserts ATOM_WS_WEIGHT_CACHED from the second call "
+                                  "on (only the activation is re-coded); holds only while nothing else touches that workspace"),
+        "packed_ops": (None, None,
+                       "reference packed format through atom_amd.ops.dense_layer_gemm_i4_fp16 (the punica.ops surface), TWO weights in "
+                       "alternation so that a one-slot cache cannot help: ops keeps every weight's BF6 form in a per-weight LRU cache and "
+                       "re-codes only the activation -- what a punica.ops caller walking a model's projections gets"),
     }
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     ws_state = {"flag": 0}
+    last = {"d": None}                                             # output of the ops-level variant (ops allocates its result)
 
     def make_step(name):
         vp, layout, _ = variants[name]
+        if name == "packed_ops":
+            from atom_amd import ops as aops
+            second = [t.clone() for t in (ops_[1], ops_[3], ops_[5], ops_[7])]            # another weight (same values, its own storage)
+            weights = [(ops_[1], ops_[3], ops_[5], ops_[7]), tuple(second)]
+            turn = {"i": 0}
+
+            def step():
+                b, sb, b8, sb8 = weights[turn["i"] & 1]
+                turn["i"] += 1
+                last["d"] = aops.dense_layer_gemm_i4_fp16(ops_[0], b, ops_[2], sb, ops_[4], b8, ops_[6], sb8, scale_layout="plain")
+            return step
 
         def step():
-            if name == "packed_ws":                              # (the weight is static: re-coded by the first call, then cached)
-                st = lib.atom_gemm_w4a4_f16_ws(*vp, D.data_ptr(), M, N, K, 128, 128, layout | ws_state["flag"], ws.data_ptr(), ws_bytes, stream)
+            if name.startswith("packed_ws"):
+                flag = ws_state["flag"] if name == "packed_ws_same_weight" else 0
+                st = lib.atom_gemm_w4a4_f16_ws(*vp, D.data_ptr(), M, N, K, 128, 128, layout | flag, ws.data_ptr(), ws_bytes, stream)
                 ws_state["flag"] = L.WS_WEIGHT_CACHED if lib.atom_gemm_w4a4_ws_recodes(M, N, K) else 0
             else:
                 st = lib.atom_gemm_w4a4_f16(*vp, D.data_ptr(), M, N, K, 128, 128, layout, stream)
@@ -430,7 +493,7 @@ def main():
             for _ in range(n_warm):                              # (at least one launch: the comparison below is of ITS output)
                 st2()
             torch.cuda.synchronize(dev)
-            same = bool(torch.equal(D, D_head))
+            same = bool(torch.equal(last["d"] if name == "packed_ops" else D, D_head))
             e0.record()
             for _ in range(n_steps):
                 st2()
@@ -476,9 +539,25 @@ def main():
             out["cold"] = cold
         if others:
             out["other_operand_formats"] = others
-            if "packed_ws" in others:                            # what a punica.ops caller (the reference's operand ABI) gets
-                out["abi_value"] = others["packed_ws"]["value"]
-                out["abi_value_note"] = "TOPS of the same GEMM called with the reference's packed operand format (packed_ws)"
+            if "packed_ops" in others:                           # what a punica.ops caller (the reference's operand ABI) gets
+                out["abi_value"] = others["packed_ops"]["value"]
+                out["abi_value_note"] = ("TOPS of the same GEMM called with the reference's packed operand format through atom_amd.ops, two "
+                                         "weights in alternation (packed_ops); packed_ws = nothing cached, "
+                                         "packed_ws_same_weight = the round-3 figure (one weight repeated)")
+        if world == 1 and not args.no_configs:
+            del a6, b6, wide
+            torch.cuda.empty_cache()
+            out["configs"] = configs_sweep(dev)
+            if args.with_block:                                  # BASELINE configs[3] in the same line (its own process: fresh allocator state)
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "block", "--steps", "3", "--warmup", "1",
+                                    "--no-cpu-baseline"], capture_output=True, text=True)
+                try:
+                    b = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["configs"]["block"] = {k: b[k] for k in ("metric", "value", "unit", "block_ms", "gemm_ms", "gemm_share", "module_ms")}
+                    out["configs"]["block"]["frac_mfma"] = b["roofline"]["frac"]
+                except Exception as e:                           # pragma: no cover
+                    out["configs"]["block"] = {"error": f"{type(e).__name__}: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N, K)
         print(json.dumps(out), flush=True)

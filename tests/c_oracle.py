@@ -33,6 +33,8 @@ def lib():
         L.oracle_gemm_w4a4_f32.argtypes = [vp] * 9 + [ctypes.c_long] * 3
         L.oracle_gemm_w4a4_f16_split.restype = None
         L.oracle_gemm_w4a4_f16_split.argtypes = [vp] * 9 + [ctypes.c_long] * 3 + [ctypes.c_int]
+        L.oracle_gemv_w4a4_f16_lanes.restype = None
+        L.oracle_gemv_w4a4_f16_lanes.argtypes = [vp] * 9 + [ctypes.c_long] * 3
         _lib = L
     return _lib
 
@@ -56,7 +58,8 @@ def act_quant(op, x, b, idx, sim, clip, eps=0.0):
 def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False, nsplit=1):
     """Packed operands, sA_GM plain [G, M].  Returns float16 [M, N] under the C-ABI arithmetic contract
     (fp32=True: the FP32 accumulators before the final rounding; nsplit=8: the decode-batch kernel's summation order;
-    nsplit=-2 / -4: the two- / four-K-group tile kernels' -- K steps in 2 / 4 ranges, partial sums added in order)."""
+    nsplit=-2 / -4: the two- / four-K-group tile kernels' -- K steps in 2 / 4 ranges, partial sums added in order;
+    nsplit="lanes": the one-token dot-product kernel's -- groups dealt to 16 quad leaders, 64-lane butterfly, keeper last)."""
     A4 = np.ascontiguousarray(A4, np.uint8); B4 = np.ascontiguousarray(B4, np.uint8)
     M, N = A4.shape[0], B4.shape[0]
     K = A4.shape[1] * 2 + 128
@@ -68,6 +71,9 @@ def gemm(A4, B4, sA_GM, sB, A8, B8, sA8, sB8, fp32=False, nsplit=1):
         lib().oracle_gemm_w4a4_f32(*[_p(a) for a in arrs], _p(D), M, N, K)
         return D
     D = np.empty((M, N), np.float16)
+    if nsplit == "lanes":
+        lib().oracle_gemv_w4a4_f16_lanes(*[_p(a) for a in arrs], _p(D), M, N, K)
+        return D
     if nsplit > 1 or nsplit < 0:
         lib().oracle_gemm_w4a4_f16_split(*[_p(a) for a in arrs], _p(D), M, N, K, int(nsplit))
     else:

@@ -65,7 +65,7 @@ def gemm_sets(M, N, K, R):
     return sets
 
 
-def gemm_row(M, N, K):
+def gemm_row(M, N, K, quiet=False):
     wbytes = N * (K - 128) // 2 + N * 128 + 2 * N * ((K - 128) // 128 + 1)
     R = max(2, -(-COLD_BYTES // wbytes))
     sets = gemm_sets(M, N, K, R)
@@ -82,7 +82,8 @@ def gemm_row(M, N, K):
     hot = graph_time(launchers[:1], iters)
     cold = graph_time(launchers, iters)
     by = bench.algorithmic_bytes(M, N, K)
-    print(f"{M:5d} {N:6d} {K:6d} | hot {hot:7.2f} us {by / hot / 1e6:5.2f} TB/s ({by / hot / 1e6 / 8:.3f}) | cold {cold:7.2f} us {by / cold / 1e6:5.2f} TB/s "
+    if not quiet:
+        print(f"{M:5d} {N:6d} {K:6d} | hot {hot:7.2f} us {by / hot / 1e6:5.2f} TB/s ({by / hot / 1e6 / 8:.3f}) | cold {cold:7.2f} us {by / cold / 1e6:5.2f} TB/s "
           f"({by / cold / 1e6 / 8:.3f} of 8 TB/s) | {R} weight sets x {wbytes / 1e6:.1f} MB", flush=True)
     return hot, cold
 

@@ -1,0 +1,492 @@
+// Probe (round 4): what bounds the M = 1 W4A4 GEMV (BASELINE configs[1]; 0.22-0.27 of 8 TB/s cold in round 3)?
+// Variants of the product kernel's design (csrc/gemv_w4a4.hip gemv1_w4a4_kernel) on the product's operand layout, timed per launch
+// by hipGraph replay, hot (one weight set) and cold (weight sets >= 600 MB cycled):
+//   v0<UNR>      the round-3 kernel: one wave per output feature, lanes along K, the group's two fp16 scales fetched by the quad leader
+//                (2-byte loads at stride N), the activation chunk re-read by every wave
+//   v1<UNR,R>    one wave owns R ADJACENT features: activation chunks + token scales loaded once per wave, the R weight scales of a
+//                group as ONE 2R-byte load, R x UNR 16-byte weight loads in flight per lane
+//   rd<UNR,R>    the same loads with the arithmetic removed (sum of the dwords): the read-rate ceiling of the access pattern
+// Same per-lane arithmetic and summation order in v0 and v1 (outputs compared bit for bit).
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/gemv_probe.cpp -o build/tools/gemv_probe
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct P {
+  const uint8_t *A4, *B4; const half_t *sA, *sB; const int8_t *A8, *B8; const half_t *sA8, *sB8; half_t *D;
+  int N, K4h, G;
+};
+
+__device__ __forceinline__ int quad_sum(int d) {
+  d += __builtin_amdgcn_mov_dpp(d, 0xB1, 0xF, 0xF, true);
+  d += __builtin_amdgcn_mov_dpp(d, 0x4E, 0xF, 0xF, true);
+  return d;
+}
+__device__ __forceinline__ float wave_sum_butterfly(float x) {
+  { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+  { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128, 0xF, 0xF, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124, 0xF, 0xF, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x122, 0xF, 0xF, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x121, 0xF, 0xF, true));
+  return x;
+}
+
+template <int UNR>
+__global__ __launch_bounds__(256) void v0(P p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, nchunks = K4h >> 4;
+  const bool leader = (lane & 3) == 0;
+  const int nwaves = gridDim.x * 4;
+  for (int n = blockIdx.x * 4 + wave; n < p.N; n += nwaves) {
+    v4i w8 = {0, 0, 0, 0}, a8 = {0, 0, 0, 0};
+    if (lane < 8) { a8 = *reinterpret_cast<const v4i *>(p.A8 + lane * 16); w8 = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * 128 + lane * 16); }
+    const half_t sb8h = p.sB8[n], sa8h = p.sA8[0];
+    float acc = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64 * UNR) {
+      v4i w[UNR], a[UNR]; half_t sbh[UNR], sah[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64 + lane; const bool ok = c < nchunks;
+        a[u] = v4i{0, 0, 0, 0}; w[u] = v4i{0, 0, 0, 0}; sah[u] = (half_t)0; sbh[u] = (half_t)0;
+        if (ok) {
+          w[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)n * K4h + c * 16));
+          if (leader) sbh[u] = p.sB[(int64_t)(c >> 2) * p.N + n];
+          a[u] = *reinterpret_cast<const v4i *>(p.A4 + c * 16);
+          if (leader) sah[u] = p.sA[c >> 2];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        int d = 0;
+        d = __builtin_amdgcn_sdot8(a[u][0], w[u][0], d, false); d = __builtin_amdgcn_sdot8(a[u][1], w[u][1], d, false);
+        d = __builtin_amdgcn_sdot8(a[u][2], w[u][2], d, false); d = __builtin_amdgcn_sdot8(a[u][3], w[u][3], d, false);
+        d = quad_sum(d);
+        if (leader && c0 + u * 64 + lane < nchunks) { const float t = (float)d * (float)sah[u]; acc = __builtin_fmaf(t, (float)sbh[u], acc); }
+      }
+    }
+    int d = 0;
+    d = __builtin_amdgcn_sdot4(a8[0], w8[0], d, false); d = __builtin_amdgcn_sdot4(a8[1], w8[1], d, false);
+    d = __builtin_amdgcn_sdot4(a8[2], w8[2], d, false); d = __builtin_amdgcn_sdot4(a8[3], w8[3], d, false);
+    d = quad_sum(d); d += __shfl_xor(d, 4);
+    float s = wave_sum_butterfly(acc);
+    if (lane == 0) { const float t = (float)d * (float)sa8h; p.D[n] = (half_t)__builtin_fmaf(t, (float)sb8h, s); }
+  }
+}
+
+template <int R> struct HalfVec { half_t v[R]; };
+
+// MODE 0: compute, 1: loads only
+template <int UNR, int R, int MODE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void v1(P p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, nchunks = K4h >> 4;
+  const bool leader = (lane & 3) == 0;
+  const int nwaves = gridDim.x * WPB;
+  for (int n0 = (blockIdx.x * WPB + wave) * R; n0 < p.N; n0 += nwaves * R) {
+    v4i w8[R], a8 = {0, 0, 0, 0};
+    if (lane < 8 && MODE < 4) a8 = *reinterpret_cast<const v4i *>(p.A8 + lane * 16);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { w8[r] = v4i{0, 0, 0, 0}; if (lane < 8 && MODE < 4) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)(n0 + r) * 128 + lane * 16); }
+    HalfVec<R> sb8; for (int r = 0; r < R; ++r) sb8.v[r] = (half_t)0;
+    if (MODE < 4) sb8 = *reinterpret_cast<const HalfVec<R> *>(p.sB8 + n0);
+    const half_t sa8h = p.sA8[0];
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64 * UNR) {
+      v4i w[R][UNR], a[UNR]; HalfVec<R> sb[UNR]; half_t sah[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64 + lane; const bool ok = c < nchunks;
+        a[u] = v4i{0, 0, 0, 0}; sah[u] = (half_t)0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w[r][u] = v4i{0, 0, 0, 0}; sb[u].v[r] = (half_t)0; }
+        if (ok) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)(n0 + r) * K4h + c * 16));
+          if (leader && MODE < 2) sb[u] = *reinterpret_cast<const HalfVec<R> *>(p.sB + (int64_t)(c >> 2) * p.N + n0);
+          if (MODE < 3) a[u] = *reinterpret_cast<const v4i *>(p.A4 + c * 16);
+          if (leader && MODE < 3) sah[u] = p.sA[c >> 2];
+        }
+      }
+      if (MODE >= 1) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] += __int_as_float((w[r][u][0] ^ w[r][u][1] ^ w[r][u][2] ^ w[r][u][3] ^ a[u][0]) & 0x3fffff) + (float)sb[u].v[r] + (float)sah[u];
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          int d = 0;
+          d = __builtin_amdgcn_sdot8(a[u][0], w[r][u][0], d, false); d = __builtin_amdgcn_sdot8(a[u][1], w[r][u][1], d, false);
+          d = __builtin_amdgcn_sdot8(a[u][2], w[r][u][2], d, false); d = __builtin_amdgcn_sdot8(a[u][3], w[r][u][3], d, false);
+          d = quad_sum(d);
+          if (leader && c0 + u * 64 + lane < nchunks) { const float t = (float)d * (float)sah[u]; acc[r] = __builtin_fmaf(t, (float)sb[u].v[r], acc[r]); }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int d = 0;
+      d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false); d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
+      d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false); d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
+      d = quad_sum(d); d += __shfl_xor(d, 4);
+      float s = wave_sum_butterfly(acc[r]);
+      if (lane == 0) { const float t = (float)d * (float)sa8h; p.D[n0 + r] = (half_t)__builtin_fmaf(t, (float)sb8.v[r], s); }
+    }
+  }
+}
+
+// the plainest possible read of the same weight bytes: every lane 16 B, grid-stride, U loads in flight
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void stream(P p) {
+  const size_t n16 = (size_t)p.N * p.K4h / 16;
+  const v4i *src = reinterpret_cast<const v4i *>(p.B4);
+  int x = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * U) {
+    v4i w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { w[u] = v4i{0, 0, 0, 0}; if (i + u * stride < n16) w[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x ^= w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3];
+  }
+  if (x == 0x12345678) p.D[threadIdx.x] = (half_t)1;
+}
+// each WORKGROUP reads one contiguous slab (what a row-owning wave does, at workgroup granularity)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void slab(P p) {
+  const size_t n16 = (size_t)p.N * p.K4h / 16;
+  const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+  const v4i *src = reinterpret_cast<const v4i *>(p.B4);
+  const size_t beg = blockIdx.x * per, end = beg + per < n16 ? beg + per : n16;
+  int x = 0;
+  for (size_t i = beg + threadIdx.x; i < end; i += 256 * U) {
+    v4i w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { w[u] = v4i{0, 0, 0, 0}; if (i + u * 256 < end) w[u] = NT ? __builtin_nontemporal_load(src + i + u * 256) : src[i + u * 256]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x ^= w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3];
+  }
+  if (x == 0x12345678) p.D[threadIdx.x] = (half_t)1;
+}
+template <int U, bool NT, int BLK> static void l_stream(P p, int, hipStream_t s) { hipLaunchKernelGGL((stream<U, NT>), dim3(BLK), dim3(256), 0, s, p); }
+template <int U, bool NT, int BLK> static void l_slab(P p, int, hipStream_t s) { hipLaunchKernelGGL((slab<U, NT>), dim3(BLK), dim3(256), 0, s, p); }
+__global__ void empty_kernel(P p) { if (p.N == -1) p.D[0] = (half_t)0; }
+static void l_empty(P p, int, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, p); }
+
+
+// v2: the weights first (R x UNR 16-byte NT loads per lane, straight to VGPRs), everything else ONCE PER WORKGROUP through LDS: the
+// activation row, its scales, the keeper row and the [G][WPB*R] tile of weight scales are fetched cooperatively (16-byte pieces) by
+// loads issued BEFORE the weight loads (so that their s_waitcnt does not wait for the weights), written to LDS, and read back by
+// every wave behind an LDS-only barrier -- while the weight stream is still in flight.
+template <int UNR, int R, int WPB>
+__global__ __launch_bounds__(WPB * 64) void v2(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int T = WPB * 64, ROWS = WPB * R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, nchunks = K4h >> 4, G = p.G;
+  const bool leader = (lane & 3) == 0;
+  const int nb = blockIdx.x * ROWS, n0 = nb + wave * R;
+  // LDS: a [K4h] | a8 [128] | sBt [G][ROWS] halves | sB8 [ROWS] halves | sA [G] halves
+  char *l_a = lds, *l_a8 = lds + K4h;
+  half_t *l_sb = reinterpret_cast<half_t *>(lds + K4h + 128);
+  half_t *l_sb8 = l_sb + G * ROWS, *l_sa = l_sb8 + ROWS;
+  constexpr int SBP = ROWS * 2 / 16 > 0 ? ROWS * 2 / 16 : 1;          // 16-byte pieces per group of the scale tile (ROWS >= 8)
+  const int na = nchunks + 8, nsb = G * SBP, total = na + nsb;
+  constexpr int CP = 4;                                                // cooperative pieces per thread (total <= CP * T)
+  v4i cp[CP];
+#pragma unroll
+  for (int i = 0; i < CP; ++i) {
+    const int q = tid + i * T;
+    cp[i] = v4i{0, 0, 0, 0};
+    if (q < nchunks) cp[i] = *reinterpret_cast<const v4i *>(p.A4 + q * 16);
+    else if (q < na) cp[i] = *reinterpret_cast<const v4i *>(p.A8 + (q - nchunks) * 16);
+    else if (q < total) { const int g = (q - na) / SBP, j = (q - na) % SBP; cp[i] = *reinterpret_cast<const v4i *>(p.sB + (int64_t)g * p.N + nb + j * 8); }
+  }
+  half_t sa_h = (half_t)0, sb8_h = (half_t)0;
+  if (tid < G) sa_h = p.sA[tid];
+  if (tid < ROWS) sb8_h = p.sB8[nb + tid];
+  // the weight stream
+  v4i w8[R], w[R][UNR];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { w8[r] = v4i{0, 0, 0, 0}; if (lane < 8) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)(n0 + r) * 128 + lane * 16); }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int c = u * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { w[r][u] = v4i{0, 0, 0, 0}; if (c < nchunks) w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)(n0 + r) * K4h + c * 16)); }
+  }
+  // cooperative pieces -> LDS (the compiler waits for exactly these: they are the oldest loads)
+#pragma unroll
+  for (int i = 0; i < CP; ++i) {
+    const int q = tid + i * T;
+    if (q < na) *reinterpret_cast<v4i *>(lds + q * 16) = cp[i];
+    else if (q < total) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(l_sb) + (q - na) * 16) = cp[i];
+  }
+  if (tid < G) l_sa[tid] = sa_h;
+  if (tid < ROWS) l_sb8[tid] = sb8_h;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  v4i a[UNR]; HalfVec<R> sb[UNR]; half_t sah[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int c = u * 64 + lane;
+    a[u] = v4i{0, 0, 0, 0}; sah[u] = (half_t)0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) sb[u].v[r] = (half_t)0;
+    if (c < nchunks) {
+      a[u] = *reinterpret_cast<const v4i *>(l_a + c * 16);
+      if (leader) { sb[u] = *reinterpret_cast<const HalfVec<R> *>(l_sb + (c >> 2) * ROWS + wave * R); sah[u] = l_sa[c >> 2]; }
+    }
+  }
+  v4i a8 = {0, 0, 0, 0};
+  if (lane < 8) a8 = *reinterpret_cast<const v4i *>(l_a8 + lane * 16);
+  const HalfVec<R> sb8 = *reinterpret_cast<const HalfVec<R> *>(l_sb8 + wave * R);
+  const half_t sa8h = p.sA8[0];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int d = 0;
+      d = __builtin_amdgcn_sdot8(a[u][0], w[r][u][0], d, false); d = __builtin_amdgcn_sdot8(a[u][1], w[r][u][1], d, false);
+      d = __builtin_amdgcn_sdot8(a[u][2], w[r][u][2], d, false); d = __builtin_amdgcn_sdot8(a[u][3], w[r][u][3], d, false);
+      d = quad_sum(d);
+      if (leader && u * 64 + lane < nchunks) { const float t = (float)d * (float)sah[u]; acc[r] = __builtin_fmaf(t, (float)sb[u].v[r], acc[r]); }
+    }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int d = 0;
+    d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false); d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
+    d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false); d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
+    d = quad_sum(d); d += __shfl_xor(d, 4);
+    float s = wave_sum_butterfly(acc[r]);
+    if (lane == 0) { const float t = (float)d * (float)sa8h; p.D[n0 + r] = (half_t)__builtin_fmaf(t, (float)sb8.v[r], s); }
+  }
+}
+template <int UNR, int R, int WPB> static void l_v2(P p, int, hipStream_t s) {
+  const size_t lds = (size_t)p.K4h + 128 + ((size_t)p.G * WPB * R + WPB * R + p.G) * 2 + 16;
+  hipLaunchKernelGGL((v2<UNR, R, WPB>), dim3(p.N / (WPB * R)), dim3(WPB * 64), lds, s, p);
+}
+
+
+// gv: the general form.  A wave owns R adjacent features; K is walked in batches of UNR x 64 chunks (all R x UNR weight loads of a batch
+// in flight together); STAGED: activation row / its scales / keeper row / the weight-scale tile go through LDS once per workgroup
+// (fetched by loads issued before the first weight batch), else every wave loads its own copies.  Rows beyond N are clamped.
+template <int UNR, int R, int WPB, bool STAGED, bool XCD = false>
+__global__ __launch_bounds__(WPB * 64) void gv(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int T = WPB * 64, ROWS = WPB * R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, nchunks = K4h >> 4, G = p.G;
+  const bool leader = (lane & 3) == 0;
+  // XCD: workgroup b runs on XCD b % 8 -- give every XCD a contiguous eighth of the features, so that a 64-byte line of weight scales
+  // (32 adjacent features of one group) is fetched into ONE L2 instead of eight
+  const int blk = XCD ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int nb = blk * ROWS, n0 = nb + wave * R;
+  char *l_a = lds, *l_a8 = lds + K4h;
+  half_t *l_sb = reinterpret_cast<half_t *>(lds + K4h + 128);
+  half_t *l_sb8 = l_sb + G * ROWS, *l_sa = l_sb8 + ROWS;
+  v4i w8[R], w[R][UNR];
+  if (STAGED) {
+    constexpr int SBP = ROWS * 2 / 16;                                 // 16-byte pieces per group of the scale tile (ROWS >= 8)
+    const int na = nchunks + 8, total = na + G * SBP;
+    for (int q0 = 0; q0 < total; q0 += 2 * T) {
+      v4i cp[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = q0 + tid + i * T;
+        cp[i] = v4i{0, 0, 0, 0};
+        if (q < nchunks) cp[i] = *reinterpret_cast<const v4i *>(p.A4 + q * 16);
+        else if (q < na) cp[i] = *reinterpret_cast<const v4i *>(p.A8 + (q - nchunks) * 16);
+        else if (q < total) { const int g = (q - na) / SBP, j = (q - na) % SBP; cp[i] = *reinterpret_cast<const v4i *>(p.sB + (int64_t)g * p.N + nb + j * 8); }
+      }
+      if (q0 == 0) {                                                   // the first weight batch goes out right behind the first pieces
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w8[r] = v4i{0, 0, 0, 0}; if (lane < 8) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)(n0 + r) * 128 + lane * 16); }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int c = u * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < R; ++r) { w[r][u] = v4i{0, 0, 0, 0}; if (c < nchunks) w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)(n0 + r) * K4h + c * 16)); }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = q0 + tid + i * T;
+        if (q < na) *reinterpret_cast<v4i *>(lds + q * 16) = cp[i];
+        else if (q < total) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(l_sb) + (q - na) * 16) = cp[i];
+      }
+    }
+    for (int g = tid; g < G; g += T) l_sa[g] = p.sA[g];
+    if (tid < ROWS) l_sb8[tid] = p.sB8[nb + tid];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int c0 = 0; c0 < nchunks; c0 += 64 * UNR) {
+    if (!STAGED || c0 > 0) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w[r][u] = v4i{0, 0, 0, 0}; if (c < nchunks) w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)(n0 + r) * K4h + c * 16)); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int c = c0 + u * 64 + lane;
+      v4i a = {0, 0, 0, 0};
+      unsigned sbp[(R + 1) / 2] = {};
+      half_t sah = (half_t)0;
+      if (c < nchunks) {
+        if (STAGED) {
+          a = *reinterpret_cast<const v4i *>(l_a + c * 16);
+          if (leader) { __builtin_memcpy(sbp, l_sb + (c >> 2) * ROWS + wave * R, R * 2); sah = l_sa[c >> 2]; }
+        } else {
+          a = *reinterpret_cast<const v4i *>(p.A4 + c * 16);
+          if (leader) { __builtin_memcpy(sbp, p.sB + (int64_t)(c >> 2) * p.N + n0, R * 2); sah = p.sA[c >> 2]; }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int d = 0;
+        d = __builtin_amdgcn_sdot8(a[0], w[r][u][0], d, false); d = __builtin_amdgcn_sdot8(a[1], w[r][u][1], d, false);
+        d = __builtin_amdgcn_sdot8(a[2], w[r][u][2], d, false); d = __builtin_amdgcn_sdot8(a[3], w[r][u][3], d, false);
+        d = quad_sum(d);
+        half_t sbh; { const unsigned short bits = (unsigned short)(sbp[r / 2] >> (16 * (r & 1))); __builtin_memcpy(&sbh, &bits, 2); }
+        if (leader && c < nchunks) { const float t = (float)d * (float)sah; acc[r] = __builtin_fmaf(t, (float)sbh, acc[r]); }
+      }
+    }
+  }
+  if (!STAGED) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { w8[r] = v4i{0, 0, 0, 0}; if (lane < 8) w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)(n0 + r) * 128 + lane * 16); }
+  }
+  v4i a8 = {0, 0, 0, 0};
+  if (lane < 8) a8 = STAGED ? *reinterpret_cast<const v4i *>(l_a8 + lane * 16) : *reinterpret_cast<const v4i *>(p.A8 + lane * 16);
+  const half_t sa8h = p.sA8[0];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int d = 0;
+    d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false); d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
+    d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false); d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
+    d = quad_sum(d); d += __shfl_xor(d, 4);
+    float s = wave_sum_butterfly(acc[r]);
+    const half_t sb8h = STAGED ? l_sb8[wave * R + r] : p.sB8[n0 + r];
+    if (lane == 0) { const float t = (float)d * (float)sa8h; p.D[n0 + r] = (half_t)__builtin_fmaf(t, (float)sb8h, s); }
+  }
+}
+template <int UNR, int R, int WPB, bool STAGED, bool XCD = false> static void l_gv(P p, int, hipStream_t s) {
+  const size_t lds = STAGED ? (size_t)p.K4h + 128 + ((size_t)p.G * WPB * R + WPB * R + p.G) * 2 + 16 : 0;
+  hipLaunchKernelGGL((gv<UNR, R, WPB, STAGED, XCD>), dim3(p.N / (WPB * R)), dim3(WPB * 64), lds, s, p);
+}
+
+static uint32_t rng_state = 12345;
+static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+
+struct Set { uint8_t *B4; half_t *sB; int8_t *B8; half_t *sB8; };
+
+typedef void (*Launch)(P, int, hipStream_t);
+template <int UNR> static void l_v0(P p, int blocks, hipStream_t s) { int nb = (p.N + 3) / 4; if (nb > 2048) nb = 2048; hipLaunchKernelGGL((v0<UNR>), dim3(nb), dim3(256), 0, s, p); }
+template <int UNR, int R, int MODE, int WPB> static void l_v1(P p, int blocks, hipStream_t s) {
+  int nb = (p.N / R + WPB - 1) / WPB; if (blocks > 0 && nb > blocks) nb = blocks;
+  hipLaunchKernelGGL((v1<UNR, R, MODE, WPB>), dim3(nb), dim3(WPB * 64), 0, s, p);
+}
+
+static float graph_us(Launch f, std::vector<P> &ps, int nsets, int iters, int blocks, hipStream_t st) {
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < iters; ++i) f(ps[i % nsets], blocks, st);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+  float best = 1e9;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0, st); CK(hipGraphLaunch(ge, st)); hipEventRecord(e1, st); CK(hipStreamSynchronize(st));
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms / iters * 1e3f < best) best = ms / iters * 1e3f;
+  }
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return best;
+}
+
+int main(int argc, char **argv) {
+  hipStream_t st; CK(hipStreamCreate(&st));
+  const int shapes[][2] = {{4096, 4096}, {11008, 4096}, {4096, 11008}, {13824, 5120}, {5120, 13824}, {5120, 5120}};
+  for (auto &sh : shapes) {
+    const int N = sh[0], K = sh[1], K4 = K - 128, K4h = K4 / 2, G = K4 / 128;
+    const size_t wbytes = (size_t)N * K4h + (size_t)N * 128 + 2 * (size_t)N * (G + 1);
+    const int nsets = (int)((600u << 20) / wbytes) + 1;
+    std::vector<uint8_t> hb4((size_t)N * K4h); for (auto &x : hb4) x = rnd();
+    std::vector<int8_t> hb8((size_t)N * 128); for (auto &x : hb8) x = (int8_t)rnd();
+    std::vector<half_t> hsb((size_t)G * N), hsb8(N), hsa(G), hsa8(1);
+    for (auto &x : hsb) x = (half_t)(0.005f + (rnd() % 1000) * 4.5e-5f);
+    for (auto &x : hsb8) x = (half_t)(0.005f + (rnd() % 1000) * 4.5e-5f);
+    for (auto &x : hsa) x = (half_t)(0.005f + (rnd() % 1000) * 4.5e-5f);
+    hsa8[0] = (half_t)0.01f;
+    std::vector<uint8_t> ha4(K4h); for (auto &x : ha4) x = rnd();
+    std::vector<int8_t> ha8(128); for (auto &x : ha8) x = (int8_t)rnd();
+    uint8_t *A4; int8_t *A8; half_t *sA, *sA8, *D, *D2;
+    CK(hipMalloc(&A4, K4h)); CK(hipMalloc(&A8, 128)); CK(hipMalloc(&sA, G * 2)); CK(hipMalloc(&sA8, 2)); CK(hipMalloc(&D, N * 2)); CK(hipMalloc(&D2, N * 2));
+    CK(hipMemcpy(A4, ha4.data(), K4h, hipMemcpyHostToDevice)); CK(hipMemcpy(A8, ha8.data(), 128, hipMemcpyHostToDevice));
+    CK(hipMemcpy(sA, hsa.data(), G * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(sA8, hsa8.data(), 2, hipMemcpyHostToDevice));
+    std::vector<Set> sets(nsets);
+    std::vector<P> ps(nsets);
+    for (int i = 0; i < nsets; ++i) {
+      CK(hipMalloc(&sets[i].B4, (size_t)N * K4h)); CK(hipMalloc(&sets[i].sB, (size_t)G * N * 2)); CK(hipMalloc(&sets[i].B8, (size_t)N * 128)); CK(hipMalloc(&sets[i].sB8, N * 2));
+      CK(hipMemcpy(sets[i].B4, hb4.data(), (size_t)N * K4h, hipMemcpyHostToDevice)); CK(hipMemcpy(sets[i].sB, hsb.data(), (size_t)G * N * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(sets[i].B8, hb8.data(), (size_t)N * 128, hipMemcpyHostToDevice)); CK(hipMemcpy(sets[i].sB8, hsb8.data(), N * 2, hipMemcpyHostToDevice));
+      ps[i] = P{A4, sets[i].B4, sA, sets[i].sB, A8, sets[i].B8, sA8, sets[i].sB8, D, N, K4h, G};
+    }
+    const bool k2 = K4h <= 2 * 64 * 16;
+    struct V { const char *name; Launch f; int blocks; };
+    std::vector<V> vs;
+    vs.push_back(k2 ? V{"v0<2>            ", l_v0<2>, 0} : V{"v0<4>            ", l_v0<4>, 0});
+#define GV(U, R, W, S) vs.push_back({"gv<" #U "," #R "> wpb" #W " " #S, l_gv<U, R, W, S>, 0})
+#define GX(U, R, W, S) vs.push_back({"gx<" #U "," #R "> wpb" #W " " #S, l_gv<U, R, W, S, true>, 0})
+    GV(1, 1, 4, false); GX(1, 1, 4, false); GV(2, 1, 4, false); GX(2, 1, 4, false); GV(1, 2, 4, false); GX(1, 2, 4, false);
+    GV(2, 2, 4, false); GX(2, 2, 4, false); GX(3, 2, 4, false); GX(1, 4, 4, false); GX(2, 4, 4, false);
+    GX(1, 1, 8, false); GX(2, 1, 8, false); GX(1, 2, 8, false); GX(1, 1, 2, false); GX(2, 1, 2, false); GX(1, 2, 2, false);
+    GV(1, 2, 8, true); GX(1, 2, 8, true); GX(2, 2, 8, true); GX(1, 2, 4, true); GX(2, 2, 4, true); GX(1, 4, 4, true);
+    vs.push_back({"slab<8,nt>   2048", l_slab<8, true, 2048>, 0});
+    vs.push_back({"empty kernel     ", l_empty, 0});
+    const size_t alg = wbytes + K4h + 128 + 2 * G + 2 + 2 * (size_t)N;
+    printf("== 1 x %d x %d   %.2f MB per launch, %d weight sets\n", N, K, alg / 1e6, nsets);
+    std::vector<half_t> ref(N), got(N);
+    for (size_t vi = 0; vi < vs.size(); ++vi) {
+      int iters = nsets * 2 > 64 ? nsets * 2 : 64; iters -= iters % nsets;
+      CK(hipMemset(D, 0, N * 2));
+      vs[vi].f(ps[0], vs[vi].blocks, st); CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(got.data(), D, N * 2, hipMemcpyDeviceToHost));
+      const char *same = "";
+      if (vi == 0) ref = got;
+      else if (vs[vi].name[0] == 'v' || vs[vi].name[0] == 'g') same = memcmp(ref.data(), got.data(), N * 2) == 0 ? " bits==v0" : " BITS DIFFER";
+      const float hot = graph_us(vs[vi].f, ps, 1, iters, vs[vi].blocks, st);
+      const float cold = graph_us(vs[vi].f, ps, nsets, iters, vs[vi].blocks, st);
+      printf("  %s hot %6.2f us %5.2f TB/s | cold %6.2f us %5.2f TB/s (%.3f of 8)%s\n", vs[vi].name, hot, alg / hot / 1e6, cold, alg / cold / 1e6, alg / cold / 8e6, same);
+    }
+    for (auto &s : sets) { hipFree(s.B4); hipFree(s.sB); hipFree(s.B8); hipFree(s.sB8); }
+    hipFree(A4); hipFree(A8); hipFree(sA); hipFree(sA8); hipFree(D); hipFree(D2);
+  }
+  return 0;
+}
