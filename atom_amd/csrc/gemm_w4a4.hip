@@ -303,6 +303,7 @@ int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const voi
   if (!aligned16(D_f32)) return ATOM_ERR_ALIGN;
   if (!skinny_fits(M, N, K_total)) return ATOM_ERR_SHAPE;
   p.ws = (float *)D_f32;
+  if (M == 1) return launch_gemv1_f32(p, reinterpret_cast<hipStream_t>(stream));   // one token: the dot-product kernel (and ITS summation order) behind every entry point
   return launch_gemm_skinny_f32(p, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -330,6 +331,7 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
   p.seg_add = (const half_t *)add0_f16;
   p.seg_n = (int)N_seg;
   p.seg_f32 = f32_mask;
+  if (M == 1) return launch_gemv1_multi(p, reinterpret_cast<hipStream_t>(stream));  // (see atom_gemm_w4a4_f32)
   return launch_gemm_skinny_multi(p, reinterpret_cast<hipStream_t>(stream));
 }
 

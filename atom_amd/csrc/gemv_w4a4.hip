@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
 // 1 x 13824 x 5120: 16.6 -> 10.2 us cold (0.28 -> 0.47 of 8 TB/s), 1 x 4096 x 4096: 4.86 -> 4.13 (0.23 -> 0.27; the plain read of
 // these bytes takes 2.8 us, 1.6 of them the launch).  Same per-lane arithmetic and summation order as before: lane l owns chunks
 // l, l + 64, ... in ascending order, a quad sums a group exactly, the quad leader applies the two scales (bit-identical output).
-template <int R>
+// OUT 0: fp16 D [N]; 1: the FP32 sums into p.ws [N] (atom_gemm_w4a4_f32); 2: segmented outputs (atom_gemm_w4a4_multi: p.seg_*)
+template <int R, int OUT>
 __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,18 +203,42 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
     s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
     if (lane == 0 && n0 + r < p.N) {
       const float t = (float)d * sa8f;
-      p.D[n0 + r] = f2h(__builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s));
+      const float c = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s);
+      const int n = n0 + r;
+      if constexpr (OUT == 0) {
+        p.D[n] = f2h(c);
+      } else if constexpr (OUT == 1) {
+        p.ws[n] = c;
+      } else {
+        const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
+        void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+        if ((p.seg_f32 >> seg) & 1u) {
+          reinterpret_cast<float *>(out)[nl] = c;
+        } else {
+          half_t h = f2h(c);
+          if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[nl]);   // fp16 + fp16 as torch adds halves (the skinny kernel's rule)
+          reinterpret_cast<half_t *>(out)[nl] = h;
+        }
+      }
     }
   }
 }
 
-static int launch_gemv1(const GemmParams &p, hipStream_t s) {
+template <int OUT>
+static int launch_gemv1_out(const GemmParams &p, hipStream_t s) {
   // one wave per R adjacent output features, every wave resident at once (no feature loop); R = 2 from 8192 features up
   const int R = p.N >= 8192 ? 2 : 1;
   const int blocks = (p.N + 4 * R - 1) / (4 * R);
-  if (R == 2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemv1_w4a4_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  if (R == 2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemv1_w4a4_kernel<1, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   return check_launch();
+}
+static int launch_gemv1(const GemmParams &p, hipStream_t s) { return launch_gemv1_out<0>(p, s); }
+// one token, the FP32 sums into p.ws / the segmented outputs of atom_gemm_w4a4_multi: the same kernel, the same summation order
+int launch_gemv1_f32(const GemmParams &p, hipStream_t s) { return p.M == 1 && p.ws ? launch_gemv1_out<1>(p, s) : ATOM_ERR_SHAPE; }
+int launch_gemv1_multi(const GemmParams &p, hipStream_t s) {
+  if (p.M != 1 || p.seg_n < 1 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3 || !p.seg_out[0]) return ATOM_ERR_SHAPE;
+  return launch_gemv1_out<2>(p, s);
 }
 
 template <int MB>

@@ -234,23 +234,29 @@ def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, n
     res = (torch.randn((M, K), device="cuda", generator=g) * 2).half()
     add = (torch.randn((M, N), device="cuda", generator=g) * 3).half()
     eps = 1e-5
+    # the fused launch runs the decode-batch kernel (its summation order: the K items dealt to 8 waves).  One token through the SEPARATE
+    # entry points takes the dot-product kernel since round 4 (another order, csrc/gemv_w4a4.hip), so the separate ops are run on the
+    # token twice -- two rows take the decode-batch kernel, rows are independent -- and row 0 is compared
+    rep = 2 if M == 1 else 1
+    dup = lambda t: t if rep == 1 else t.repeat(rep, 1)
     res_want = None
     if op == "reorder":
-        qt = ops.reorder_fp16_i4(x, idx)
+        qt = ops.reorder_fp16_i4(dup(x), idx)
         kw = dict(reorder_index=idx)
     elif op == "rmsnorm":
-        qt = ops.rmsnorm_fp16_i4(x, w, idx, eps)
+        qt = ops.rmsnorm_fp16_i4(dup(x), w, idx, eps)
         kw = dict(x2=w, reorder_index=idx, eps=eps)
     elif op == "add_rmsnorm":
-        out = ops.add_rmsnorm_fp16_i4(x, res, w, idx, eps)
-        res_want, qt = out[0], out[1:]
+        out = ops.add_rmsnorm_fp16_i4(dup(x), dup(res), w, idx, eps)
+        res_want, qt = out[0][:M], out[1:]
         kw = dict(x2=w, residual=res, reorder_index=idx, eps=eps)
     else:
-        qt = ops.activate_fp16_i4(x, x2)
+        qt = ops.activate_fp16_i4(dup(x), dup(x2))
         kw = dict(x2=x2)
     outlier, norms, outlier_scales, norm_scales = qt
     for mask, ad in ((0, None), (0b110 & ((1 << nseg) - 1), add)):
-        want = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, fused, f32_mask=mask, add=ad)
+        want = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, fused, f32_mask=mask, add=None if ad is None else dup(ad))
+        want = [t[:M] for t in want]
         got, res_out = ops.dense_layer_gemm_i4_multi_q(op, x, fused, f32_mask=mask, add=ad, **kw)
         for i in range(nseg):
             assert got[i].dtype == want[i].dtype and torch.equal(got[i], want[i]), (op, M, i, mask)
@@ -263,7 +269,7 @@ def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, n
 @pytest.mark.parametrize("bsz", [1, 2])
 def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
     """A decode step of one or two tokens with the four quantisers inside their consumers' launches (7 launches) against the same
-    step with separate quantiser launches (11): same cache contents, same output, bit for bit."""
+    step with separate quantiser launches (11): same cache contents, same output, bit for bit at two tokens (one token: see below)."""
     import atom_amd.e2e.llama as E
     from atom_amd.e2e import LlamaDecoderLayer
     from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
@@ -292,8 +298,15 @@ def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
     finally:
         E._FUSED_Q_DECODE = True
         E._FUSED_Q_MASK = mask0
-    assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
-    assert torch.equal(outs[0], outs[1])
+    if bsz >= 2:
+        assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
+        assert torch.equal(outs[0], outs[1])
+    else:
+        # one token: the separate launches take the dot-product kernel (csrc/gemv_w4a4.hip), the launches with the quantiser inside
+        # the decode-batch kernel -- two summation orders, one fp16 ulp per projection, a W4A4 code flip downstream at worst.  The
+        # bit-for-bit statement for one token is test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm (M = 1).
+        assert (caches[0][0] != caches[1][0]).float().mean().item() <= 0.02
+        assert (outs[0].float() - outs[1].float()).abs().max().item() <= 0.05 * outs[0].float().abs().max().item()
 
 
 @pytest.mark.parametrize("bsz", [1, 3, 16])
@@ -301,7 +314,8 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     """A decode step of atom_amd.e2e.LlamaDecoderLayer with the round-3 launch fusions (q / k / v in one launch, gate / up in one
     launch, the second residual add inside down_proj's launch: 14 -> 10 launches) against the same step with one launch per
     projection (ATOM_FUSED_DECODE = 0, the reference's call order llama.py:259-292): same cache contents and same output, bit for
-    bit (batch 1: q comes from the decode-batch kernel instead of the dot-product kernel -- another summation order, one fp16 ulp)."""
+    bit (batch 1: o_proj with its quantiser inside the launch runs the decode-batch kernel, o_proj alone the dot-product kernel --
+    two summation orders, one fp16 ulp; every other projection of a one-token step takes the dot-product kernel on both sides)."""
     import atom_amd.e2e.llama as E
     from atom_amd.e2e import LlamaDecoderLayer
     from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
