@@ -2481,6 +2481,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
 #undef ATOM_ABL
   }
 #endif
+#ifdef ATOM_TOOLS   // geometries no shape is dispatched to (f6_pick_cfg): tuning builds only
   if (cfg == 2) {
     if (p.splits > 1 && p.ws) return f6::launch<f6::Cfg<64, 128, 2, 3>, true>(p, s);
     return f6::launch<f6::Cfg<64, 128, 2, 3>, false>(p, s);
@@ -2488,6 +2489,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 10) return f6::launch<f6::Cfg<256, 256, 4, 3>, false>(p, s);   // tuning: 256x256 on the 32x32x64 MFMA
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
+#endif
   if (cfg == 8) {                                                              // 256x128, qk_step, K steps in order
     if (p.sB32 && p.G >= 2) return f6::launch_q2<f6::Cfg<256, 128, 2, 3, 2, 1>>(p, s);
     cfg = 3;                                                                   // fp16 weight scales: the 128x128 geometry (same order)
@@ -2498,19 +2500,28 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     // workgroup saves a round of tiles (profiles/r02_mid_m.txt: 1536x4096x4096 37.7 vs 40.9 us, 1024x11008x4096 64.7 vs 55.4).
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (p.sB32 && (t128 + 511) / 512 <= (t128 + 767) / 768) {
+#ifdef ATOM_TOOLS
       if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, true>(p, s);
+#endif
       return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);
     }
+#ifdef ATOM_TOOLS
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, true>(p, s);
+#endif
     return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);
   }
   // two K groups of 4 waves per workgroup: for shapes that put at most one tile on a CU (f6_pick_cfg)
-  if (cfg == 5 || cfg == 6) {                                                  // 128x128; 2 (tuning) / 3 stages per group
+#ifdef ATOM_TOOLS
+  if (cfg == 5) {                                                              // tuning: 128x128, two K groups, 2 stages per group
+    if (p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s);
+    return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s);
+  }
+#endif
+  if (cfg == 6) {                                                              // 128x128, two K groups, 3 stages per group
     // float32 weight scales (ATOM_B_F6S) and a K long enough for its unrolled loop: the q kernel's K step per group (same sums)
-    if (cfg == 6 && p.sB32 && p.G >= 7 && ATOM_TUNE("ATOM_QK", 1)) return f6::launch_qk<f6::Cfg<128, 128, 2, 3, 3, 1>>(p, s);
-    if (p.sB32) return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>, false, 2>(p, s)
-                                : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
-    return cfg == 5 ? f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>, false, 2>(p, s) : f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
+    if (p.sB32 && p.G >= 7 && ATOM_TUNE("ATOM_QK", 1)) return f6::launch_qk<f6::Cfg<128, 128, 2, 3, 3, 1>>(p, s);
+    if (p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
+    return f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
   }
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
@@ -2520,6 +2531,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 1>, false, 4>(p, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 2>, false, 4>(p, s);
   }
+#ifdef ATOM_TOOLS   // tuning builds only
   if (cfg == 51 && p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);   // tuning: the two scale forms of cfg 3
   if (cfg == 52) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);
   if (cfg == 53) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3>>(p, s);            // tuning: cfg 3 with fp16 weight scales
@@ -2528,7 +2540,8 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.splits > 1 && p.ws) return f6::launch_x16<f6::Cfg<128, 128, 1, 2, 3>, true>(p, s);
     return f6::launch_x16<f6::Cfg<128, 128, 1, 2, 3>>(p, s);
   }
-  if (cfg == 30 || !p.sB32) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);   // 256x256, pipelined across K steps (fp16 weight scales)
+#endif
+  if (!p.sB32 || cfg == 30) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);   // 256x256, pipelined across K steps (fp16 weight scales; cfg 30: tuning)
   return f6::launch_q<f6::Cfg<256, 256, 4, 3>>(p, s);                          // ... third generation (ATOM_B_F6S; the headline)
 }
 
