@@ -104,8 +104,14 @@ int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v
 int launch_gemm_v2_o4(const GemmParams &p, hipStream_t s);         // gemm_w4a4_v2.hip, u4 epilogue
 int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_v3.hip (templated geometry)
 int launch_gemv(const GemmParams &p, hipStream_t s);               // gemv_w4a4.hip (M <= 16)
-int launch_gemv1_f32(const GemmParams &p, hipStream_t s);          // ... one token: FP32 sums into p.ws
-int launch_gemv1_multi(const GemmParams &p, hipStream_t s);        // ... one token: segmented outputs (p.seg_*)
+#ifdef ATOM_TOOLS
+constexpr int kGemvMaxTokens = 8;                                  // (tuning builds carry the 4- and 8-token instances too)
+#else
+constexpr int kGemvMaxTokens = 2;                                  // the few-token dot-product kernel (gemv_w4a4.hip gemv1_w4a4_kernel)
+#endif
+int launch_gemv1(const GemmParams &p, hipStream_t s);              // ... M <= kGemvMaxTokens: fp16 output
+int launch_gemv1_f32(const GemmParams &p, hipStream_t s);          // ... FP32 sums into p.ws
+int launch_gemv1_multi(const GemmParams &p, hipStream_t s);        // ... segmented outputs (p.seg_*)
 int launch_gemm_skinny(const GemmParams &p, hipStream_t s);        // gemm_w4a4_skinny.hip (decode batches, M <= 256)
 int launch_gemm_skinny_f32(const GemmParams &p, hipStream_t s);    // ... FP32 sums into p.ws, no final rounding
 int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the u4 epilogue launch

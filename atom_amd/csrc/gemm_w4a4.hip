@@ -27,6 +27,16 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 
 // largest M served by the weight-streaming decode kernel (ATOM_GEMV_MAXM overrides it for tuning)
 static int gemv_max_m() { return ATOM_TUNE("ATOM_GEMV_MAXM", 7); }
+// Up to this many tokens EVERY GEMM entry point (fp16, FP32 sums, segmented) runs the few-token dot-product kernel (gemv_w4a4.hip
+// gemv1_w4a4_kernel: the weights streamed once at full occupancy, each token's sum in the one-token kernel's order); above it the
+// MFMA decode-batch kernel.  One token always; two tokens where K is long (measured cold, us, dot-product | decode-batch kernel:
+// 2 x 5120 x 13824 12.5 | 17.5, 2 x 4096 x 11008 8.0 | 8.6, 2 x 5120 x 5120 6.6 | 7.0, 2 x 4096 x 4096 4.6 | 4.4; from three tokens
+// the per-token VALU work loses everywhere: 3 x 13824 x 5120 13.9 | 11.7; profiles/r04/decode_small_m.txt).  The rule depends on
+// (M, K) only, so the projections that share an activation take the same kernel through every entry point.
+static int gemv_tokens(int64_t K_total) {
+  const int t = ATOM_TUNE("ATOM_GEMV_TOKENS", K_total > 4096 ? 2 : 1);
+  return t > kGemvMaxTokens ? kGemvMaxTokens : t;
+}
 
 // Decode batches go to the register-resident weight-streaming MFMA kernel (gemm_w4a4_skinny.hip) where it measures
 // faster than the tile kernels + split-K (profiles/r01_skinny.txt): always up to 16 tokens, up to 32 unless K is very
@@ -128,6 +138,10 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
         const int64_t cm256 = (M + 255) / 256, cn256 = (N + 255) / 256, t5 = ((M + 63) / 64) * ((N + 127) / 128);
         const int cfg = cm256 * cn256 >= 128 ? 20 : ((t5 > 256 && t5 < 1024) ? 24 : 25);
         return launch_gemm_v3(p, cfg, hs);
+      }
+      if (M <= gemv_tokens(K_total)) {                                     // a few tokens: the dot-product weight stream
+        const int st = launch_gemv1(p, hs);
+        if (st != ATOM_ERR_SHAPE) return st;
       }
       if (M > 1 && skinny_fits(M, N, K_total)) {                    // decode batches: weight streaming on the MFMA
         const int st = launch_gemm_skinny(p, hs);
@@ -303,7 +317,7 @@ int atom_gemm_w4a4_f32(const void *A4, const void *B4, const void *sA, const voi
   if (!aligned16(D_f32)) return ATOM_ERR_ALIGN;
   if (!skinny_fits(M, N, K_total)) return ATOM_ERR_SHAPE;
   p.ws = (float *)D_f32;
-  if (M == 1) return launch_gemv1_f32(p, reinterpret_cast<hipStream_t>(stream));   // one token: the dot-product kernel (and ITS summation order) behind every entry point
+  if (M <= gemv_tokens(K_total)) return launch_gemv1_f32(p, reinterpret_cast<hipStream_t>(stream));   // a few tokens: the dot-product kernel (and ITS summation order) behind every entry point
   return launch_gemm_skinny_f32(p, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -331,7 +345,7 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
   p.seg_add = (const half_t *)add0_f16;
   p.seg_n = (int)N_seg;
   p.seg_f32 = f32_mask;
-  if (M == 1) return launch_gemv1_multi(p, reinterpret_cast<hipStream_t>(stream));  // (see atom_gemm_w4a4_f32)
+  if (M <= gemv_tokens(K_total)) return launch_gemv1_multi(p, reinterpret_cast<hipStream_t>(stream));  // (see atom_gemm_w4a4_f32)
   return launch_gemm_skinny_multi(p, reinterpret_cast<hipStream_t>(stream));
 }
 

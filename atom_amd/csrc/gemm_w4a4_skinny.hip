@@ -92,7 +92,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row = lane & 15, kb = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  // XCD-aware feature map (round 4, as in gemv_w4a4.hip): workgroup b runs on XCD b % 8; a 64-byte line of weight scales holds 32
+  // adjacent features of one group = two workgroups' worth -- dealt round-robin they sit in two L2s.  Bijective for any grid size.
+  const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
+  const int n0 = (xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3)) * 16;
   const int K4h = p.K4h, G = p.G;
 
   // this wave's items: int4 groups [i0, min(i1, G)), and the keeper if i1 == G + 1
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
           h8 v = q_xr[i];
           if constexpr (QOP == 3) {
             v = v + q_rr[i];
-            if (blockIdx.x == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
+            if (n0 == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
           }
           *reinterpret_cast<h8 *>(rowbuf + m * H * 2 + cc * 16) = v;
         }

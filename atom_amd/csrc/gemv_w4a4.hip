@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
 // 1 x 13824 x 5120: 16.6 -> 10.2 us cold (0.28 -> 0.47 of 8 TB/s), 1 x 4096 x 4096: 4.86 -> 4.13 (0.23 -> 0.27; the plain read of
 // these bytes takes 2.8 us, 1.6 of them the launch).  Same per-lane arithmetic and summation order as before: lane l owns chunks
 // l, l + 64, ... in ascending order, a quad sums a group exactly, the quad leader applies the two scales (bit-identical output).
-// OUT 0: fp16 D [N]; 1: the FP32 sums into p.ws [N] (atom_gemm_w4a4_f32); 2: segmented outputs (atom_gemm_w4a4_multi: p.seg_*)
-template <int R, int OUT>
+// One or two tokens (MT rows of activations; round 4): the weight chunk of a feature is loaded once and meets every token's
+// activation chunk (L2) -- per token 4 v_dot8 + the quad sum + 3 VALU per chunk.  Two tokens: 2 x 5120 x 13824 cold 12.5 us where the
+// MFMA decode-batch kernel takes 17.5; from three tokens the VALU work loses to it (MT = 4, 8: tuning builds; profiles/r04/decode_small_m.txt).
+// Every token's sum is formed exactly as the one-token kernel forms it (same lanes, same order): M rows = M independent one-token results.
+// OUT 0: fp16 D [M, N]; 1: the FP32 sums into p.ws [M, N] (atom_gemm_w4a4_f32); 2: segmented outputs (atom_gemm_w4a4_multi: p.seg_*)
+template <int R, int MT, int OUT>
 __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,19 +145,29 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
   const int blk = x * q + min(x, rem) + (blockIdx.x >> 3);
   const int n0 = (blk * 4 + wave) * R;
   if (n0 >= p.N) return;                                  // (wave-uniform)
-  int nr[R];
+  int nr[R], mr[MT], so[MT];                              // clamped feature / token indices, token offsets inside a scale row
 #pragma unroll
   for (int r = 0; r < R; ++r) nr[r] = min(n0 + r, p.N - 1);
-  float acc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int m = 0; m < MT; ++m) {
+    mr[m] = min(m, p.M - 1);
+    so[m] = p.ref_layout ? ref_scale_index(mr[m]) : mr[m];
+  }
+  float acc[R][MT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
   const unsigned short *sBu = reinterpret_cast<const unsigned short *>(p.sB), *sAu = reinterpret_cast<const unsigned short *>(p.sA);
   // the keeper's operands are requested with the first instructions and consumed after the K loop (behind the loop they would be one
   // more dependent round trip at the very end of every wave)
-  const v4i a8 = *reinterpret_cast<const v4i *>(p.A8 + (lane & 7) * 16);   // lanes 8.. hold copies; lane 0's sums touch lanes 0-7 only
-  const unsigned short sa8u = reinterpret_cast<const unsigned short *>(p.sA8)[0];
-  v4i w8[R];
-  unsigned short sb8u[R];
+  v4i a8[MT], w8[R];
+  unsigned short sa8u[MT], sb8u[R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    a8[m] = *reinterpret_cast<const v4i *>(p.A8 + (int64_t)mr[m] * kKeeper + (lane & 7) * 16);   // lanes 8.. hold copies; lane 0's sums touch lanes 0-7 only
+    sa8u[m] = reinterpret_cast<const unsigned short *>(p.sA8)[so[m]];
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)nr[r] * kKeeper + (lane & 7) * 16);
@@ -167,77 +181,97 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
     // load before leaving the block -- and, vmcnt being in order, for the weight chunk issued before it: two or three dependent
     // round trips per batch instead of one (the round-4 rewrite measured 4.7 us instead of 4.1 at 4096 x 4096 until this was gone).
     const int cc = min(c, nchunks - 1);
-    v4i w[R];
-    unsigned short sbu[R];
+    v4i w[R], a[MT];
+    unsigned short sbu[R], sau[MT];
 #pragma unroll
     for (int r = 0; r < R; ++r) w[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)nr[r] * K4h + cc * 16));   // nt: read once, by this CU only
-    const v4i a = *reinterpret_cast<const v4i *>(p.A4 + cc * 16);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const v4i *>(p.A4 + (int64_t)mr[m] * K4h + cc * 16);
 #pragma unroll
     for (int r = 0; r < R; ++r) sbu[r] = sBu[(int64_t)(cc >> 2) * p.N + nr[r]];
-    const unsigned short sau = sAu[(int64_t)(cc >> 2) * p.ldA];          // token 0: index 0 in either scale layout
-    const float saf = (float)__builtin_bit_cast(half_t, sau);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) sau[m] = sAu[(int64_t)(cc >> 2) * p.ldA + so[m]];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float saf = (float)__builtin_bit_cast(half_t, sau[m]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int d = 0;
+        d = __builtin_amdgcn_sdot8(a[m][0], w[r][0], d, false);
+        d = __builtin_amdgcn_sdot8(a[m][1], w[r][1], d, false);
+        d = __builtin_amdgcn_sdot8(a[m][2], w[r][2], d, false);
+        d = __builtin_amdgcn_sdot8(a[m][3], w[r][3], d, false);
+        d = quad_sum(d);                                    // exact: the group's 128-element integer dot
+        const float t = (float)d * saf;
+        const float next = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sbu[r]), acc[r][m]);
+        acc[r][m] = (leader && ok) ? next : acc[r][m];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float sa8f = (float)__builtin_bit_cast(half_t, sa8u[m]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int d = 0;
-      d = __builtin_amdgcn_sdot8(a[0], w[r][0], d, false);
-      d = __builtin_amdgcn_sdot8(a[1], w[r][1], d, false);
-      d = __builtin_amdgcn_sdot8(a[2], w[r][2], d, false);
-      d = __builtin_amdgcn_sdot8(a[3], w[r][3], d, false);
-      d = quad_sum(d);                                    // exact: the group's 128-element integer dot
-      const float t = (float)d * saf;
-      const float next = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sbu[r]), acc[r]);
-      acc[r] = (leader && ok) ? next : acc[r];
-    }
-  }
-  const float sa8f = (float)__builtin_bit_cast(half_t, sa8u);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int d = 0;
-    d = __builtin_amdgcn_sdot4(a8[0], w8[r][0], d, false);
-    d = __builtin_amdgcn_sdot4(a8[1], w8[r][1], d, false);
-    d = __builtin_amdgcn_sdot4(a8[2], w8[r][2], d, false);
-    d = __builtin_amdgcn_sdot4(a8[3], w8[r][3], d, false);
-    d = quad_sum(d);
-    d += __shfl_xor(d, 4);
-    float s = acc[r];
-    s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
-    if (lane == 0 && n0 + r < p.N) {
-      const float t = (float)d * sa8f;
-      const float c = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s);
-      const int n = n0 + r;
-      if constexpr (OUT == 0) {
-        p.D[n] = f2h(c);
-      } else if constexpr (OUT == 1) {
-        p.ws[n] = c;
-      } else {
-        const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
-        void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
-        if ((p.seg_f32 >> seg) & 1u) {
-          reinterpret_cast<float *>(out)[nl] = c;
+      d = __builtin_amdgcn_sdot4(a8[m][0], w8[r][0], d, false);
+      d = __builtin_amdgcn_sdot4(a8[m][1], w8[r][1], d, false);
+      d = __builtin_amdgcn_sdot4(a8[m][2], w8[r][2], d, false);
+      d = __builtin_amdgcn_sdot4(a8[m][3], w8[r][3], d, false);
+      d = quad_sum(d);
+      d += __builtin_amdgcn_update_dpp(0, d, 0x104, 0xF, 0xF, true);   // row_shl:4 -- lane 0 += lane 4 (the other lanes' values are not used)
+      float s = acc[r][m];
+      s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
+      if (lane == 0 && n0 + r < p.N && m < p.M) {
+        const float t = (float)d * sa8f;
+        const float c = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s);
+        const int n = n0 + r;
+        if constexpr (OUT == 0) {
+          p.D[(int64_t)m * p.N + n] = f2h(c);
+        } else if constexpr (OUT == 1) {
+          p.ws[(int64_t)m * p.N + n] = c;
         } else {
-          half_t h = f2h(c);
-          if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[nl]);   // fp16 + fp16 as torch adds halves (the skinny kernel's rule)
-          reinterpret_cast<half_t *>(out)[nl] = h;
+          const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
+          void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+          const int64_t at = (int64_t)m * p.seg_n + nl;
+          if ((p.seg_f32 >> seg) & 1u) {
+            reinterpret_cast<float *>(out)[at] = c;
+          } else {
+            half_t h = f2h(c);
+            if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[at]);   // fp16 + fp16 as torch adds halves (the skinny kernel's rule)
+            reinterpret_cast<half_t *>(out)[at] = h;
+          }
         }
       }
     }
   }
 }
 
-template <int OUT>
-static int launch_gemv1_out(const GemmParams &p, hipStream_t s) {
+// the few-token dot-product kernel takes M <= kGemvMaxTokens (every entry point: atom_gemm_w4a4_f16 / _f32 / _multi route here)
+template <int OUT, int MT>
+static int launch_gemv1_mt(const GemmParams &p, hipStream_t s) {
   // one wave per R adjacent output features, every wave resident at once (no feature loop); R = 2 from 8192 features up
   const int R = p.N >= 8192 ? 2 : 1;
   const int blocks = (p.N + 4 * R - 1) / (4 * R);
-  if (R == 2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemv1_w4a4_kernel<1, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  if (R == 2) hipLaunchKernelGGL((gemv1_w4a4_kernel<2, MT, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemv1_w4a4_kernel<1, MT, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   return check_launch();
 }
-static int launch_gemv1(const GemmParams &p, hipStream_t s) { return launch_gemv1_out<0>(p, s); }
-// one token, the FP32 sums into p.ws / the segmented outputs of atom_gemm_w4a4_multi: the same kernel, the same summation order
-int launch_gemv1_f32(const GemmParams &p, hipStream_t s) { return p.M == 1 && p.ws ? launch_gemv1_out<1>(p, s) : ATOM_ERR_SHAPE; }
+template <int OUT>
+static int launch_gemv1_out(const GemmParams &p, hipStream_t s) {
+  if (p.M <= 1) return launch_gemv1_mt<OUT, 1>(p, s);
+  if (p.M <= 2) return launch_gemv1_mt<OUT, 2>(p, s);
+#ifdef ATOM_TOOLS   // (measured slower than the MFMA decode-batch kernel from three tokens up: tuning builds only)
+  if (p.M <= 4) return launch_gemv1_mt<OUT, 4>(p, s);
+  if (p.M <= 8) return launch_gemv1_mt<OUT, 8>(p, s);
+#endif
+  return ATOM_ERR_SHAPE;
+}
+int launch_gemv1(const GemmParams &p, hipStream_t s) { return launch_gemv1_out<0>(p, s); }
+// ... the FP32 sums into p.ws / the segmented outputs of atom_gemm_w4a4_multi: the same kernel, the same summation order
+int launch_gemv1_f32(const GemmParams &p, hipStream_t s) { return p.ws ? launch_gemv1_out<1>(p, s) : ATOM_ERR_SHAPE; }
 int launch_gemv1_multi(const GemmParams &p, hipStream_t s) {
-  if (p.M != 1 || p.seg_n < 1 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3 || !p.seg_out[0]) return ATOM_ERR_SHAPE;
+  if (p.seg_n < 1 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3 || !p.seg_out[0]) return ATOM_ERR_SHAPE;
   return launch_gemv1_out<2>(p, s);
 }
 
@@ -255,7 +289,7 @@ static int launch_gemv_mb(const GemmParams &p, hipStream_t s) {
 
 // M <= 16.  Returns ATOM_ERR_SHAPE when the activations do not fit LDS (caller falls back to the tile kernel).
 int launch_gemv(const GemmParams &p, hipStream_t s) {
-  if (p.M <= 1) return ATOM_TUNE("ATOM_GEMV1_STAGED", 0) ? launch_gemv_mb<1>(p, s) : launch_gemv1(p, s);
+  if (p.M <= 1) return launch_gemv1(p, s);
   if (p.M <= 2) return launch_gemv_mb<2>(p, s);
   if (p.M <= 4) return launch_gemv_mb<4>(p, s);
   if (p.M <= 8) return launch_gemv_mb<8>(p, s);

@@ -236,9 +236,10 @@ def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, n
     eps = 1e-5
     # the fused launch runs the decode-batch kernel (its summation order: the K items dealt to 8 waves).  One token through the SEPARATE
     # entry points takes the dot-product kernel since round 4 (another order, csrc/gemv_w4a4.hip), so the separate ops are run on the
-    # token twice -- two rows take the decode-batch kernel, rows are independent -- and row 0 is compared
-    rep = 2 if M == 1 else 1
-    dup = lambda t: t if rep == 1 else t.repeat(rep, 1)
+    # tokens two or three times over -- three or more rows take the decode-batch kernel, rows are independent -- and the first M rows
+    # are compared
+    rep = 3 if M == 1 else 2                                      # (two tokens with K > 4096 take the dot-product kernel too)
+    dup = lambda t: t.repeat(rep, 1)
     res_want = None
     if op == "reorder":
         qt = ops.reorder_fp16_i4(dup(x), idx)

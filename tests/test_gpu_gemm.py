@@ -690,17 +690,32 @@ def test_c_abi_ws_weight_cached_flag():
     assert torch.equal(outs[0], ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain"))
 
 
-@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (11008, 4096), (1024, 11008), (13824, 5120), (640, 13824), (8256, 640), (8320, 384)])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (1, 4096, 4096), (1, 11008, 4096), (1, 1024, 11008), (1, 13824, 5120), (1, 640, 13824),
+                                   (1, 8256, 640), (1, 8320, 384), (2, 1024, 11008), (2, 13824, 5120), (2, 640, 13824), (2, 8320, 4224)])
 @pytest.mark.parametrize("layout", ["plain", "ref"])
-def test_gemv_m1_bit_exact_vs_c_contract(N, K, layout):
-    """The one-token kernel (BASELINE config 2; round 4: one 16-byte chunk per feature and K batch, one or two adjacent features per
-    wave from 8192 features up, XCD-aware feature map -- csrc/gemv_w4a4.hip) is bit-identical to the C restatement of its summation
-    order (oracle/atom_oracle.c oracle_gemv_w4a4_f16_lanes: groups dealt to the 16 quad leaders in ascending order, 64-lane butterfly,
-    keeper last) -- the order the round-3 kernel had, so the rewrite changed no bit; short rows (8 chunks: most lanes re-read the
-    last chunk) and both feature-per-wave variants included."""
+def test_gemv_bit_exact_vs_c_contract(M, N, K, layout):
+    """The dot-product kernel (BASELINE config 2: one token; two tokens where K > 4096; round 4: one 16-byte chunk per feature and K
+    batch, one or two adjacent features per wave from 8192 features up, XCD-aware feature map -- csrc/gemv_w4a4.hip) is bit-identical
+    to the C restatement of its summation order (oracle/atom_oracle.c oracle_gemv_w4a4_f16_lanes: groups dealt to the 16 quad leaders
+    in ascending order, 64-lane butterfly, keeper last; every token independently) -- the order the round-3 one-token kernel had, so
+    the rewrite changed no bit; short rows (8 chunks: most lanes re-read the last chunk) and both feature-per-wave variants included."""
     from tests import c_oracle as C
     ops = _ops()
-    d = rand_gemm_operands(1, N, K, seed=N + K)
-    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, layout), scale_layout=layout)
+    d = rand_gemm_operands(M, N, K, seed=N + K + M)
+    dev = to_device(d, layout)
     want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit="lanes")
+    out = ops.dense_layer_gemm_i4_fp16(*dev, scale_layout=layout)
+    assert np.array_equal(bits16(t2n(out)), bits16(want))
+    # the FP32 sums and the segmented entry point take the same kernel: same sums, rounded once
+    f32 = ops.dense_layer_gemm_i4_f32(*dev, scale_layout=layout)
+    assert torch.equal(f32.half(), out)
+
+
+def test_two_tokens_take_the_decode_batch_kernel_up_to_k_4096():
+    """The routing rule is (M, K) only: two tokens with K <= 4096 keep the MFMA decode-batch kernel (its order: nsplit = 8)."""
+    from tests import c_oracle as C
+    ops = _ops()
+    d = rand_gemm_operands(2, 1024, 4096, seed=77)
+    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
+    want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=8)
     assert np.array_equal(bits16(t2n(out)), bits16(want))

@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from atom_amd import _lib as L  # noqa: E402
 
+if os.environ.get("ATOM_LIB"):                 # tools only: time another build of the library (tools/ab_build.sh) on the same box
+    L.LIB_PATH = os.path.abspath(os.environ["ATOM_LIB"])
 dev = torch.device("cuda", 0)
 lib = L.lib()
 COLD_BYTES = 600 << 20
@@ -88,11 +90,11 @@ def gemm_row(M, N, K, quiet=False):
     return hot, cold
 
 
-def gemm_main():
+def gemm_main(ms=None):
     print("# decode-size W4A4 GEMMs, HIP-graph replay, per launch; (fraction of 8 TB/s on the algorithmic bytes)")
     print("#   M      N      K")
     for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (13824, 5120), (5120, 13824)):
-        for M in ((1, 2, 8, 16, 32, 64, 128, 256) if (N, K) == (4096, 4096) else (1, 16, 64, 256)):
+        for M in (ms or ((1, 2, 8, 16, 32, 64, 128, 256) if (N, K) == (4096, 4096) else (1, 16, 64, 256))):
             gemm_row(M, N, K)
 
 
@@ -152,5 +154,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
         gemm_main()
+    if what == "gemm_m":                                      # python tools/cold_bench.py gemm_m 2,16,32
+        gemm_main(tuple(int(b) for b in sys.argv[2].split(",")))
     if what in ("layer", "all"):
         layer_main(batches=tuple(int(b) for b in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 16, 64))
