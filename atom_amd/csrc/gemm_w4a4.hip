@@ -34,7 +34,8 @@ static int gemv_max_m() { return ATOM_TUNE("ATOM_GEMV_MAXM", 7); }
 // the per-token VALU work loses everywhere: 3 x 13824 x 5120 13.9 | 11.7; profiles/r04/decode_small_m.txt).  The rule depends on
 // (M, K) only, so the projections that share an activation take the same kernel through every entry point.
 static int gemv_tokens(int64_t K_total) {
-  const int t = ATOM_TUNE("ATOM_GEMV_TOKENS", K_total > 4096 ? 2 : 1);
+  const int forced = ATOM_TUNE("ATOM_GEMV_TOKENS", 0);       // (tuning builds)
+  const int t = forced > 0 ? forced : (K_total > 4096 ? 2 : 1);
   return t > kGemvMaxTokens ? kGemvMaxTokens : t;
 }
 

@@ -59,7 +59,9 @@ typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
 // Quantise + store the 16 values of slot (row r, group g, octet lane j).  e0 = first (reordered) channel of the slot.
-template <bool SIM, bool DQ>
+// FMT: the code format as a compile-time constant (0 packed nibbles, 1 wide int8, 2 BF6 records) -- as run-time branches on
+// p.wide / p.f6_rows the three store paths cost the packed path 4-7 % (register copies at the merges; round 4, same-box A/B)
+template <bool SIM, bool DQ, int FMT>
 __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantParams &p, int64_t r, int g, int j,
                                            int e0, bool keeper, int K4h) {
   float amax = 0.f;
@@ -76,7 +78,7 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
   if (keeper) {
     *reinterpret_cast<v4u *>(p.o8 + r * kKeeper + j * 16) = w;
   } else {
-    if (p.f6_rows) {
+    if constexpr (FMT == 2) {
       // BF6 (E3M2) holds every INT4 code exactly; v_cvt_scalef32_2xpk16_bf6_f32 converts AND packs 32 floats into 6-bit
       // fields, interleaving its two sources (field 2i = a[i], 2i+1 = b[i]; tools/probes): my 16 codes are fields 0..15
       typedef float v16f __attribute__((ext_vector_type(16)));
@@ -98,7 +100,7 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
         const unsigned sh = (unsigned)__builtin_bit_cast(unsigned short, shh);
         *reinterpret_cast<v2u *>(dst + 96) = v2u{sh, __builtin_bit_cast(unsigned, (float)shh)};
       }
-    } else if (p.wide) {
+    } else if constexpr (FMT == 1) {
       // my 16 channels are half `j & 1` of 32-channel block g*4 + j/2: even channels -> chunk 0, odd -> chunk 1
       uint8_t *dst = p.o4 + r * (int64_t)(2 * K4h) + g * 128 + (j >> 1) * 32 + (j & 1) * 8;
       *reinterpret_cast<v2u *>(dst) = v2u{(w[0] << 4) & 0xF0F0F0F0u, (w[1] << 4) & 0xF0F0F0F0u};
@@ -132,7 +134,7 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
 }
 
 // reorder / rmsnorm: persistent workgroups, LDS-DMA double buffer.  NP = slots (16 channels) per thread per row.
-template <int OP, bool SIM, bool DQ, int NP>
+template <int OP, bool SIM, bool DQ, int NP, int FMT>
 __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -327,14 +329,14 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       const int slot = ps * 256 + tid;
       if (slot < nslots) {
         const int g = slot >> 3;
-        quant_slot<SIM, DQ>(x[ps], p, r, g, j, slot * 16, g == Gt - 1, K4h);
+        quant_slot<SIM, DQ, FMT>(x[ps], p, r, g, j, slot * 16, g == Gt - 1, K4h);
       }
     }
   }
 }
 
 // silu(a)*b: no gather, no LDS; one row per workgroup.
-template <bool SIM, bool DQ>
+template <bool SIM, bool DQ, int FMT>
 __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
   const int tid = threadIdx.x;
   // rows by XCD (see act_quant2_kernel): the grid is 8 * ceil(M / 8); XCD x takes rows [x * cm, (x + 1) * cm)
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
       v[k] = silu_mul<SIM>((float)av[k], (float)bv[k]);
     }
     const int g = slot >> 3;
-    quant_slot<SIM, DQ>(v, p, r, g, tid & 7, e0, g == Gt - 1, K4h);
+    quant_slot<SIM, DQ, FMT>(v, p, r, g, tid & 7, e0, g == Gt - 1, K4h);
   }
 }
 
@@ -378,7 +380,7 @@ static int resident_blocks(K kernel, size_t lds) {           // persistent grid:
   return per_cu * cus;
 }
 
-template <int OP, bool SIM, bool DQ, int NP>
+template <int OP, bool SIM, bool DQ, int NP, int FMT>
 static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   ActQuantParams p = p0;
   const size_t rowb = (size_t)((p.H * 2 + 1023) & ~1023);
@@ -390,7 +392,7 @@ static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   // on H: one cached (lds, resident) word per device slot and kernel (a race re-computes the same value)
   static std::atomic<uint64_t> lds_set{0};
   static std::atomic<uint64_t> cache[64];
-  const auto kernel = act_quant2_kernel<OP, SIM, DQ, NP>;
+  const auto kernel = act_quant2_kernel<OP, SIM, DQ, NP, FMT>;
   if (const int st = ensure_max_lds(reinterpret_cast<const void *>(kernel), 160 * 1024, lds_set); st != ATOM_OK) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return ATOM_ERR_LAUNCH;
@@ -406,19 +408,25 @@ static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   return ATOM_OK;
 }
 
-template <int OP, bool SIM, bool DQ>
-static int launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
+template <int OP, bool SIM, bool DQ, int FMT>
+static int launch_act_quant2_fmt(const ActQuantParams &p, hipStream_t s) {
   if constexpr (OP == OP_SILU_MUL) {
     const unsigned parts = p.M <= 1024 ? (unsigned)(((p.H >> 4) + 255) >> 8) : 1u;
-    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ>), dim3((unsigned)(((p.M + 7) >> 3) << 3), parts), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((silu_quant2_kernel<SIM, DQ, FMT>), dim3((unsigned)(((p.M + 7) >> 3) << 3), parts), dim3(256), 0, s, p);
     return ATOM_OK;
   } else {
     const int np = ((p.H >> 4) + 255) >> 8;
-    if (np == 1) return launch_act_quant2_np<OP, SIM, DQ, 1>(p, s);
-    if (np == 2) return launch_act_quant2_np<OP, SIM, DQ, 2>(p, s);
-    if (np == 3) return launch_act_quant2_np<OP, SIM, DQ, 3>(p, s);
-    return launch_act_quant2_np<OP, SIM, DQ, 4>(p, s);
+    if (np == 1) return launch_act_quant2_np<OP, SIM, DQ, 1, FMT>(p, s);
+    if (np == 2) return launch_act_quant2_np<OP, SIM, DQ, 2, FMT>(p, s);
+    if (np == 3) return launch_act_quant2_np<OP, SIM, DQ, 3, FMT>(p, s);
+    return launch_act_quant2_np<OP, SIM, DQ, 4, FMT>(p, s);
   }
+}
+template <int OP, bool SIM, bool DQ>
+static int launch_act_quant2(const ActQuantParams &p, hipStream_t s) {
+  if (p.f6_rows) return launch_act_quant2_fmt<OP, SIM, DQ, 2>(p, s);
+  if (p.wide) return launch_act_quant2_fmt<OP, SIM, DQ, 1>(p, s);
+  return launch_act_quant2_fmt<OP, SIM, DQ, 0>(p, s);
 }
 
 static int launch_act_quant(int op, ActQuantParams p, int quant_mode, int scale_layout, void *stream) {
