@@ -5,7 +5,8 @@ record what the flow tests compare.  One file, three users:
     quant, qLinearLayer, qLlamaLayer), CPU, build container only -> tests/golden/flow_*.npz
   * tests/test_flow_reference_cpu.py -- ``impl="ref_flow_on_dropin"``: the UNMODIFIED reference modelutils_llama / eval / gptq driving
     OUR classes (atom_amd/dropin first on sys.path), CPU, configurations that need no kernel (16-bit activations)
-  * tests/test_gpu_flow.py           -- ``impl="atom"``: atom_amd.model.modelutils_llama / eval on cuda:0 (nothing of /root/reference)
+  * tests/test_gpu_flow.py           -- ``impl="atom"``: atom_amd.model.modelutils_llama / eval on cuda:0 (nothing of /root/reference);
+    ``impl="atom_cpu"`` (tests/test_flow_reference_cpu.py): the same mirrors on CPU for the 16-bit-activation configurations
 
 Run as a script it executes one (impl, config) in a fresh interpreter (the reference's modules are top-level names -- ``quant``,
 ``qLinearLayer`` ... -- so two implementations cannot share a process) and writes an .npz.
@@ -64,6 +65,17 @@ def load_impl(impl):
     if impl == "atom":
         from atom_amd.model import eval as E, modelutils_llama as F
         return types.SimpleNamespace(flow=F, eval=E, device="cuda:0")
+    if impl == "atom_cpu":
+        # OUR flow mirrors driving OUR classes on CPU (16-bit-activation configurations only: no kernel needed); the GPTQ solver is
+        # the reference's module, found behind the drop-in directory on sys.path (build container only)
+        if not torch.cuda.is_available():
+            torch.cuda.synchronize = lambda *a, **k: None      # gptq.py:308 synchronises unconditionally; there is no GPU here
+        sys.path[:0] = [os.path.join(ROOT, "atom_amd", "dropin"), _stub_dir()]
+        if os.path.isdir(REF):
+            sys.path.append(REF)
+        F, E = importlib.import_module("modelutils_llama"), importlib.import_module("eval")
+        assert F.__file__.startswith(ROOT) and E.__file__.startswith(ROOT)
+        return types.SimpleNamespace(flow=F, eval=E, device="cpu")
     assert os.path.isdir(REF), "the reference tree is needed for impl=" + impl
     if not torch.cuda.is_available():
         torch.cuda.synchronize = lambda *a, **k: None          # gptq.py:308 synchronises unconditionally; there is no GPU here

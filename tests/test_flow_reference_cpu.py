@@ -5,8 +5,8 @@ main.py:224-270 wires them -- is executed over a two-layer model twice: with the
 (atom_amd/dropin first on sys.path), each in a fresh interpreter (tests/flow_run.py).
 
 On CPU only the configurations that need no kernel can run through our classes (W4, 16-bit activations: the W4A4 hot path has no
-CPU fallback by design -- tests/test_gpu_flow.py covers it on the GPU against goldens written by the reference flow).  For those
-the two runs must agree BIT FOR BIT on everything the flow produces: every projection's weight after reorder + RTN / GPTQ
+CPU fallback by design -- tests/test_gpu_flow.py covers it on the GPU against goldens written by the reference flow).  (A third run puts this repository's flow mirrors -- the code the GPU tests execute -- in place of the reference's flow code.)  For those
+the runs must agree BIT FOR BIT on everything the flow produces: every projection's weight after reorder + RTN / GPTQ
 (``layer.weight.data = Q``, hooks, per-layer .cpu()/.to(dev) round trips, layer replacement inside model.model.layers), the
 fake-quantised K/V path, every layer's output on every sample, and the perplexity."""
 import os
@@ -41,9 +41,12 @@ def test_unmodified_reference_flow_drives_our_classes_bit_for_bit(tmp_path, gold
     tok = _tokens(tmp_path, golden_dir, stream)
     ref = _run("reference", config, tok, str(tmp_path / "ref.npz"))
     ours = _run("ref_flow_on_dropin", config, tok, str(tmp_path / "ours.npz"))
-    assert set(ref.files) == set(ours.files) and len(ref.files) >= 49
+    # ... and the flow code the GPU tests run: this repository's mirrors (atom_amd.model.modelutils_llama / eval) over our classes
+    mirror = _run("atom_cpu", config, tok, str(tmp_path / "mirror.npz"))
+    assert set(ref.files) == set(ours.files) == set(mirror.files) and len(ref.files) >= 49
     for k in ref.files:
         assert np.array_equal(ref[k], ours[k]), k
+        assert np.array_equal(ref[k], mirror[k]), ("mirror", k)
     if config.startswith("gptq"):
         assert any(k.startswith("Q1.") for k in ref.files)          # the solver's weights of the SECOND layer: its Hessians came from
         #                                                             layer 0's outputs computed by our classes
