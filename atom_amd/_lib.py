@@ -97,6 +97,10 @@ def lib() -> ctypes.CDLL:
             raise AtomHipError(
                 f"{LIB_PATH} not found: build it with `make -C atom_amd/csrc` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the Atom W4A4 path.")
+        # torch first: PyTorch-ROCm ships its own libamdhip64, and the process must have ONE HIP runtime -- dlopen'ed before torch, this
+        # library binds the system's copy, torch then loads its own, and every launch on one of torch's streams fails (HIP launch
+        # failed) because the kernels are registered with the other runtime (seen with build() + smoke() in one process, round 4)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)           # AttributeError if a declared symbol is not exported
