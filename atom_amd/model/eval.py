@@ -40,22 +40,22 @@ def llama_eval(model, testenc, dev, offload: bool = False, rows_per_call: int = 
             outs[j:j + n] = layer(inps[j:j + n], **(kw if n == 1 else _for_batch(kw, n)))[0]
         layers[i] = layer.cpu() if offload else layer
         inps, outs = outs, inps
-    if model.model.norm is not None:
-        model.model.norm = model.model.norm.to(dev)
-    model.lm_head = model.lm_head.to(dev)
-    testenc = testenc.to(dev)
-    loss_fct = nn.CrossEntropyLoss()
-    nlls = []
-    for i in range(nsamples):
-        h = inps[i].unsqueeze(0)
-        if model.model.norm is not None:
-            h = model.model.norm(h)
-        logits = model.lm_head(h)
-        shift_logits = logits[:, :-1, :].contiguous()
-        shift_labels = testenc[:, i * seqlen:(i + 1) * seqlen][:, 1:]
-        loss = loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.reshape(-1))
-        nlls.append(loss.float() * seqlen)
-    ppl = torch.exp(torch.stack(nlls).sum() / (nsamples * seqlen)).item()
+    head = model.lm_head.to(dev)
+    final_norm = model.model.norm.to(dev) if model.model.norm is not None else None
+    model.lm_head = head
+    if final_norm is not None:
+        model.model.norm = final_norm
+    targets = testenc.to(dev)[0, :nsamples * seqlen].view(nsamples, seqlen)
+
+    def sample_nll(i):
+        """seqlen x the mean token loss of sample i, the loss taken on the model's own (fp16) logits as the reference takes it
+        (eval.py:68-79: the mean over seqlen - 1 predictions, scaled by seqlen)."""
+        h = inps[i:i + 1]
+        logits = head(h if final_norm is None else final_norm(h))[0, :-1]
+        return nn.functional.cross_entropy(logits, targets[i, 1:]).float() * seqlen
+
+    nlls = torch.stack([sample_nll(i) for i in range(nsamples)])
+    ppl = torch.exp(nlls.sum() / (nsamples * seqlen)).item()
     if return_details:
-        return ppl, torch.stack(nlls).cpu(), inps
+        return ppl, nlls.cpu(), inps
     return ppl
