@@ -42,13 +42,13 @@ def _lin(i, o, s, g):
 class TinyAttention(nn.Module):
     def __init__(self, cfg, g):
         super().__init__()
-        h, nh = cfg.hidden_size, cfg.num_attention_heads
+        h, nh, kvh = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads
         self.config = cfg
         self.hidden_size, self.num_heads, self.head_dim = h, nh, h // nh
-        self.num_key_value_heads, self.num_key_value_groups = nh, 1
+        self.num_key_value_heads, self.num_key_value_groups = kvh, nh // kvh      # grouped-query attention when kvh < nh (qLlamaLayer.py:268-269)
         self.max_position_embeddings, self.rope_theta = cfg.max_position_embeddings, 10000.0
-        self.q_proj, self.k_proj = _lin(h, h, 0.04, g), _lin(h, h, 0.04, g)
-        self.v_proj, self.o_proj = _lin(h, h, 0.04, g), _lin(h, h, 0.04, g)
+        self.q_proj, self.k_proj = _lin(h, h, 0.04, g), _lin(h, kvh * (h // nh), 0.04, g)
+        self.v_proj, self.o_proj = _lin(h, kvh * (h // nh), 0.04, g), _lin(h, h, 0.04, g)
         self.rotary_emb = Rotary(h // nh)
 
 
@@ -95,10 +95,11 @@ class TinyLlamaForCausalLM(nn.Module):
     """model(input_ids [1, T]) -> logits; the layer call passes attention_mask / position_ids as keywords (the Catcher of
     eval.py:26-36 and modelutils_llama.py:172-184 reads exactly these two)."""
 
-    def __init__(self, hidden=512, heads=4, inter=1408, layers=2, vocab=1000, seqlen=96, seed=11):
+    def __init__(self, hidden=512, heads=4, inter=1408, layers=2, vocab=1000, seqlen=96, seed=11, kv_heads=None):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
-        self.config = types.SimpleNamespace(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
+        self.config = types.SimpleNamespace(hidden_size=hidden, num_attention_heads=heads, num_key_value_heads=kv_heads or heads,
+                                            intermediate_size=inter,
                                             num_hidden_layers=layers, vocab_size=vocab, max_position_embeddings=2048,
                                             rms_norm_eps=1e-5, use_cache=False)
         self.seqlen = seqlen

@@ -32,6 +32,9 @@ CONFIGS = {
     # name: (model kwargs, args overrides, seqlens to evaluate, gptq)
     "rtn_w4a4": (dict(hidden=512, heads=4, inter=1408, layers=2, vocab=1000), dict(), (96, 320), False),
     "gptq_w4a4": (dict(hidden=256, heads=2, inter=384, layers=2, vocab=1000), dict(), (96,), True),
+    # grouped-query attention (4 query heads on 2 K/V heads: k_proj / v_proj are 512 -> 256, repeat_kv before the V quantiser)
+    "rtn_w4a4_gqa": (dict(hidden=512, heads=4, kv_heads=2, inter=1408, layers=2, vocab=1000), dict(), (96,), False),
+    "rtn_w4a16_gqa": (dict(hidden=512, heads=4, kv_heads=2, inter=1408, layers=2, vocab=1000), dict(abits=16), (96,), False),
     "rtn_w4a16": (dict(hidden=512, heads=4, inter=1408, layers=2, vocab=1000), dict(abits=16), (96,), False),
     "gptq_w4a16": (dict(hidden=256, heads=2, inter=384, layers=2, vocab=1000), dict(abits=16), (96,), True),
 }

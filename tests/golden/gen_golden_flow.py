@@ -7,7 +7,7 @@
 wired as main.py:224-270 wires them, run on CPU with the reference's own classes over the tiny seeded model of tests/flow_model.py.
 Build container only (needs /root/reference):
 
-    python tests/golden/gen_golden_flow.py     ->  flow_tokens.npz, flow_rtn_w4a4.npz, flow_gptq_w4a4.npz
+    python tests/golden/gen_golden_flow.py     ->  flow_tokens.npz, flow_rtn_w4a4.npz, flow_gptq_w4a4.npz, flow_rtn_w4a4_gqa.npz
 
 flow_tokens.npz holds the token streams: drawn once, autoregressively, from the UN-quantised tiny model's own distribution (plain
 fp32 torch forward below), so that the model is predictive on them and the perplexity of a quantised copy is a sensitive number
@@ -43,8 +43,9 @@ def fp32_logits(model, ids):
     norm = lambda x, w: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps) * w.float()
     for L in model.model.layers:
         x = norm(h, L.input_layernorm.weight)
-        q, k, v = (torch.nn.functional.linear(x, getattr(L.self_attn, p).weight.float()).view(b, s, nh, hd).transpose(1, 2)
+        q, k, v = (torch.nn.functional.linear(x, getattr(L.self_attn, p).weight.float()).view(b, s, -1, hd).transpose(1, 2)
                    for p in ("q_proj", "k_proj", "v_proj"))
+        k, v = (t.repeat_interleave(nh // t.shape[1], dim=1) for t in (k, v))          # grouped-query attention: K/V heads shared
         q, k = q * cos + rot(q) * sin, k * cos + rot(k) * sin
         a = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(hd) + mask, -1) @ v
         h = h + torch.nn.functional.linear(a.transpose(1, 2).reshape(b, s, d), L.self_attn.o_proj.weight.float())
@@ -71,7 +72,7 @@ def main():
     from tests.flow_run import CONFIGS
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     tokens = {}
-    for name in ("rtn_w4a4", "gptq_w4a4"):
+    for name in ("rtn_w4a4", "gptq_w4a4", "rtn_w4a4_gqa"):
         mk, _, seqlens, gptq = CONFIGS[name]
         model = TinyLlamaForCausalLM(**mk).eval()
         for s in seqlens:
@@ -82,7 +83,7 @@ def main():
             ids, _ = sample_stream(model, 4, seqlens[0], seed=7)
             tokens[f"{name}.calib"] = ids.numpy().astype(np.int16)
     np.savez_compressed(os.path.join(HERE, "flow_tokens.npz"), **tokens)
-    for name in ("rtn_w4a4", "gptq_w4a4"):
+    for name in ("rtn_w4a4", "gptq_w4a4", "rtn_w4a4_gqa"):
         tok = os.path.join("/tmp", f"flow_tokens_{name}.npz")
         np.savez(tok, **{k.split(".", 1)[1]: v for k, v in tokens.items() if k.startswith(name + ".")})
         out = os.path.join(HERE, f"flow_{name}.npz")

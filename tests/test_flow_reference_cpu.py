@@ -36,7 +36,7 @@ def _run(impl, config, tokens, out):
     return np.load(out)
 
 
-@pytest.mark.parametrize("config,stream", [("rtn_w4a16", "rtn_w4a4"), ("gptq_w4a16", "gptq_w4a4")])
+@pytest.mark.parametrize("config,stream", [("rtn_w4a16", "rtn_w4a4"), ("gptq_w4a16", "gptq_w4a4"), ("rtn_w4a16_gqa", "rtn_w4a4_gqa")])
 def test_unmodified_reference_flow_drives_our_classes_bit_for_bit(tmp_path, golden_dir, config, stream):
     tok = _tokens(tmp_path, golden_dir, stream)
     ref = _run("reference", config, tok, str(tmp_path / "ref.npz"))

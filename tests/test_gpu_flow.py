@@ -183,6 +183,14 @@ def test_rtn_flow_w4a4_matches_the_reference_flow(golden_dir):
     _calibrated("RTN W4A4 flow, hidden 512 / inter 1408 / 2 layers, 4 samples", "rtn_w4a4", _tokens(golden_dir, "rtn_w4a4"), ref, (96, 320))
 
 
+def test_rtn_flow_w4a4_grouped_query_attention(golden_dir):
+    """The same flow over a grouped-query model (4 query heads on 2 K/V heads: k_proj / v_proj are 512 -> 256, K quantised before RoPE
+    per K/V head, repeat_kv before the V quantiser -- qLlamaLayer.py:240-275)."""
+    ref = np.load(os.path.join(golden_dir, "flow_rtn_w4a4_gqa.npz"))
+    _calibrated("RTN W4A4 flow, grouped-query attention (4 heads on 2 K/V heads), hidden 512 / inter 1408 / 2 layers", "rtn_w4a4_gqa",
+                _tokens(golden_dir, "rtn_w4a4_gqa"), ref, (96,))
+
+
 def test_gptq_flow_w4a4_matches_the_reference_flow(golden_dir):
     """quantize_model_gptq_llama on the HIP path: forward hooks on our QLinearLayers feed the solver, the solver assigns
     ``layer.weight.data = Q`` (here: the weights the reference's own GPTQ produced in the golden run, replayed by a stand-in with the
