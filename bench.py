@@ -6,6 +6,7 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
+                    [--no-configs] [--with-block] [--workload gemm|block]
                     [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle;
                                      reported as "ramp" in the JSON line)
 
@@ -15,8 +16,12 @@ torch.distributed.run WORLD_SIZE must equal --gpus.  "n_gpus" in the JSON line i
 
 The headline runs the operand format the drop-in modules use for prefill batches (F6: both operands BF6-coded, block-scaled
 MFMA); at N=1 the reference's packed-nibble format and the wide-activation format are timed beside it (same codes, same
-scales, outputs compared bit for bit) and reported under "other_operand_formats", as is the packed format through the
-workspace entry point (operands re-coded to BF6 on the fly).
+scales, outputs compared bit for bit) and reported under "other_operand_formats", as is the packed format on the re-coding
+route three ways: "packed_ws" (C ABI + caller-owned workspace, nothing cached), "packed_ws_same_weight" (the caller asserts
+ATOM_WS_WEIGHT_CACHED: one weight repeated) and "packed_ops" (atom_amd.ops with two weights in alternation: its per-weight
+cache; = "abi_value").  Also at N=1: "cold" (the headline with 512 MB flushed between launches) and "configs" -- the other
+BASELINE configs (config 2 M=1, the corners of config 5, the 4096-wide batch sweep), HIP-graph replay per launch, hot and with
+the weights streamed from HBM (--no-configs skips it; --with-block adds config 4 through --workload block).
 
 N > 1: one process per GPU (torch.distributed.run), every rank runs an independent replica (the path is a
 single-device per-layer GEMM: "replicas only", no collective on the data path); value = all ranks' ops / max time.
