@@ -8,6 +8,10 @@ gen_golden_block.py, prepared the way modelutils_llama.py prepares a layer (reor
 is 2048 x 4096 halves (16 MB); the fixture keeps a FIXED SAMPLE of token rows (every 32nd row + the first and last 8 = 80 rows,
 0.6 MB compressed) of y and of the residual-stream input of the MLP half, 16 rows of the intermediate tensors either side of every
 quantiser (for stage-wise, teacher-forced checks), checksums of the full tensors, and checksums of the weights and of x, which the test re-generates from the same seeds (torch CPU generators are platform-independent).
+A second file, llama_block_7b_wide.npz, is the WIDE teacher-forcing sample: for 256 token rows (every 8th) the reference's input of
+every projection -- the four fake-quantised activation tensors, which deflate to a third of their size -- and 256 sampled output
+features of all seven projections, so that each GEMM is checked against the reference's own output on 256 x 256 elements per
+projection with the reference's own input (a 5 % systematic error in one projection is 100 sigma there).
 Container only (needs /root/reference; ~2 min on 8 cores):
 
     python tests/golden/gen_golden_block7b.py
@@ -37,6 +41,45 @@ def sample_rows(seq=SEQ):
 def mid_rows(seq=SEQ):
     """The 16 token rows for which the fixture also stores intermediate tensors (stage-wise, teacher-forced checks)."""
     return np.array(sorted(set(range(5, seq, 136)) | {0})[:16], dtype=np.int64)
+
+
+def wide_rows(seq=SEQ):
+    """The 256 token rows of the wide teacher-forcing sample."""
+    return np.arange(0, seq, seq // 256, dtype=np.int64)[:256]
+
+
+def wide_cols(nfeat):
+    """256 output features of a projection: a fixed pseudo-random subset (every 128-feature tile of the GEMM kernels is hit)."""
+    g = np.random.default_rng(1234 + nfeat)
+    return np.sort(g.choice(nfeat, 256, replace=False)).astype(np.int64)
+
+
+def recover_scales(v, qmax, group):
+    """The per-(row, group) fp16 scale s of a fake-quantised tensor v = half(code * s) (model/quant.py:141-181 returns only v):
+    the largest-code candidate s = half(max|v| / k), k = qmax .. 1 (and its fp16 neighbours), for which every element is
+    reproduced EXACTLY by an integer code in [-qmax - 1, qmax].  Where several (code, s) pairs describe the same numbers (all codes
+    even) they differ by a power of two and the W4A4 GEMM contract gives identical sums.  Returns s [rows, groups] fp16; raises if
+    a group cannot be reproduced."""
+    r, h = v.shape
+    x = v.astype(np.float32).reshape(r, h // group, group)
+    vmax = np.abs(x).max(-1)
+    best = np.zeros(vmax.shape, dtype=np.float16)
+    done = vmax == 0
+    best[done] = 1.0
+    for k in range(qmax + 1, 0, -1):
+        base = (vmax / k).astype(np.float16)
+        for d in (0, 1, -1):
+            cand = (base.view(np.int16) + d).view(np.float16)
+            cf = cand.astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                c = np.rint(x / cf[..., None])
+            ok = (np.abs(c).max(-1) <= qmax + 1) & (c.max(-1) <= qmax) & np.isfinite(cf) & (cf > 0)
+            ok &= ((c * cf[..., None]).astype(np.float16) == x.astype(np.float16)).all(-1)
+            take = ok & ~done
+            best[take] = cand[take]
+            done |= take
+    assert done.all(), "fake-quantised group not reproducible by integer codes: %d of %d" % ((~done).sum(), done.size)
+    return best
 
 
 def build_original():
@@ -95,6 +138,10 @@ def main():
              m.mlp.up_proj.register_forward_hook(keep("up", "out")),
              m.mlp.down_proj.register_forward_hook(keep("act_q", "in")),
              m.mlp.down_proj.register_forward_hook(keep("down", "out"))]
+    wide = {}
+    keepw = lambda name, io: (lambda mod, inp, out: wide.__setitem__(name, (inp[0] if io == "in" else out).detach().clone()))
+    hooks += [m.self_attn.k_proj.register_forward_hook(keepw("k", "out")), m.self_attn.v_proj.register_forward_hook(keepw("v", "out")),
+              m.self_attn.o_proj.register_forward_hook(keepw("o", "out"))]
     t0 = time.time()
     with torch.no_grad():
         y = m(x.clone(), attention_mask=mask, position_ids=pos)[0]
@@ -112,6 +159,19 @@ def main():
     path = os.path.join(HERE, "llama_block_7b_1x2048.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; |y| rms", float(yf.pow(2).mean().sqrt()))
+    wr = wide_rows()
+    outs = dict(q=mid["q"], k=wide["k"], v=wide["v"], o=wide["o"], gate=mid["gate"], up=mid["up"], down=mid["down"])
+    w = dict(rows=wr, xq1=n(mid["xq1"][0][wr]), attn_q=n(mid["attn_q"][0][wr]), xq2=n(mid["xq2"][0][wr]), act_q=n(mid["act_q"][0][wr]))
+    for k in ("xq1", "attn_q", "xq2", "act_q"):                  # the integer view of the reference's tensors: scales per (row, group)
+        w["s4_" + k] = recover_scales(w[k][:, :-128], 7, 128)
+        w["s8_" + k] = recover_scales(w[k][:, -128:], 127, 128)[:, 0]
+    for k, v in outs.items():
+        cols = wide_cols(v.shape[-1])
+        w["cols_" + k] = cols
+        w["out_" + k] = n(v[0][wr][:, cols])
+    path = os.path.join(HERE, "llama_block_7b_wide.npz")
+    np.savez_compressed(path, **w)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -188,6 +188,83 @@ def test_llama7b_projection_teacher_forced(name, N, K, feeder):
     assert flips <= 5e-3, (name, flips)                         # measured 1-3e-3 (profiles/r02_block_llama7b.txt)
 
 
+WIDE_PROJ = {   # projection -> (fixture key of its input, module path)
+    "q": ("xq1", "self_attn.q_proj"), "k": ("xq1", "self_attn.k_proj"), "v": ("xq1", "self_attn.v_proj"), "o": ("attn_q", "self_attn.o_proj"),
+    "gate": ("xq2", "mlp.gate_proj"), "up": ("xq2", "mlp.up_proj"), "down": ("act_q", "mlp.down_proj"),
+}
+
+
+def test_llama7b_projections_teacher_forced_on_256_reference_rows(golden_dir):
+    """The WIDE teacher-forcing sample (tests/golden/llama_block_7b_wide.npz, gen_golden_block7b.py): for 256 token rows of the
+    unmodified reference's QLlamaDecoderLayer.forward at hidden 4096 / intermediate 11008, every one of the seven W4A4 GEMMs is fed
+    the REFERENCE's own input -- its fake-quantised activation tensor in the integer view the fixture's recovered per-group scales
+    give (codes = value / scale, exact) -- through atom_gemm_w4a4 with the HIP-quantised weights, and compared with the REFERENCE's
+    own output on 256 sampled features: 256 x 256 elements per projection, where a 5 % systematic error in one projection would be
+    two orders of magnitude above the bound (the 16-row sample of the test below could not see it).  The deviation that remains is
+    the reference's own: its F.linear runs on fp16-ROUNDED fake-quant operands and rounds the sum once more (3.4e-4 relative; the
+    CPU oracle pinned on the same fixture shows the same number, tests/test_oracle_block7b.py), so the HIP output is ALSO compared
+    with the C restatement of the contract on the same integer operands, in the summation order of the kernel the shape is dispatched
+    to (atom_gemm_w4a4_ws_recodes / atom_gemm_w4a4_f6_order): bit for bit.
+    The first quantiser (input_layernorm -> reorder -> quantise) is compared on all 256 rows as well."""
+    import gen_golden_block7b as G7
+    import gen_golden_block as G
+    import c_oracle as C
+    from atom_amd import ops, _lib
+    from atom_amd.model import quant, qLlamaLayer
+    from atom_amd.model.qLinearLayer import find_qlinear_layers
+    lib = _lib.lib()
+    z = np.load(os.path.join(golden_dir, "llama_block_7b_wide.npz"))
+    args = _args()
+    orig = G7.build_original()
+    idx, x, _, _ = G7.make_inputs()
+    m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
+    G.prepare(m, args, {k: v.cuda() for k, v in idx.items()}, quant)
+    layers = find_qlinear_layers(m)
+    wr = torch.from_numpy(z["rows"]).cuda()
+    xq1 = m.input_layernorm(x.cuda()[:, wr])[0]
+    differ = (xq1 != torch.from_numpy(z["xq1"]).cuda()).float().mean().item()
+    print("input_layernorm -> quant on 256 reference rows: fraction of differing elements", differ)
+    assert differ <= 5e-3
+    report = {}
+    for name, (key, path) in WIDE_PROJ.items():
+        v = torch.from_numpy(z[key]).cuda().float()
+        s4 = torch.from_numpy(z["s4_" + key]).cuda()
+        s8 = torch.from_numpy(z["s8_" + key]).cuda()
+        M, H = v.shape
+        c4 = torch.round(v[:, :-128].reshape(M, -1, 128) / s4.float()[..., None]).reshape(M, H - 128).to(torch.int32)
+        c8 = torch.round(v[:, -128:] / s8.float()[:, None]).to(torch.int8)
+        assert int(c4.min()) >= -8 and int(c4.max()) <= 7
+        o4 = ((c4[:, 0::2] & 0xF) | ((c4[:, 1::2] & 0xF) << 4)).to(torch.uint8).view(torch.int8).contiguous()
+        sA = s4.t().contiguous()
+        b4, b8, sb, sb8 = layers[path].packed_weight()
+        D = ops.dense_layer_gemm_i4_fp16(o4, b4, sA, sb, c8.contiguous(), b8, s8, sb8, scale_layout="plain")
+        cols = torch.from_numpy(z["cols_" + name]).cuda()
+        got = D[:, cols].double()
+        ref = torch.from_numpy(z["out_" + name]).cuda().double()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        worst = ((got - ref).abs() / ref.abs().clamp_min(ref.pow(2).mean().sqrt())).max().item()
+        # ... and against the C restatement of the contract on the same integer operands (the sampled features of the HIP weights)
+        # (in the summation order of the kernel this shape is dispatched to: the library's own queries)
+        N, K = b4.shape[0], H
+        if lib.atom_gemm_w4a4_ws_recodes(M, N, K):
+            order = lib.atom_gemm_w4a4_f6_order(M, N, K)
+            nsplit = 1 if order == 1 else -order
+        else:
+            nsplit = 8                                                    # the decode-batch kernel
+        Dc = C.gemm(o4.cpu().numpy().view(np.uint8), b4[cols].cpu().numpy().view(np.uint8), sA.cpu().numpy(),
+                    sb.reshape(sA.shape[0], -1)[:, cols].cpu().numpy(), c8.cpu().numpy(), b8[cols].cpu().numpy(), s8.cpu().numpy(),
+                    sb8.reshape(-1)[cols].cpu().numpy(), nsplit=nsplit)
+        dc = torch.from_numpy(Dc.astype(np.float64)).cuda()
+        ndiff = (got != dc).float().mean().item()
+        report[name] = (rel, worst, nsplit, ndiff)
+        assert rel <= 1e-3 and worst <= 1e-2, (name, rel, worst)
+        assert ndiff == 0.0, (name, nsplit, ndiff)
+    print("HIP GEMM on the reference's input vs the reference's output, 256 rows x 256 features per projection "
+          "(relative Frobenius, worst element / max(|ref|, rms)) and vs the C contract (summation order, fraction of elements that differ):")
+    for k, r in report.items():
+        print(f"  {k:5s} {r[0]:.2e} {r[1]:.2e} | {r[2]} {r[3]:.4f}")
+
+
 def test_qlinear_weight_memory_policy():
     """keep_packed_with_f6 = False: after the first prefill batch the layer holds the F6 form (6.75 bit per weight incl. its fp32
     scales) and no packed INT4 codes; a decode-size batch afterwards re-packs them from the fp16 weight; results are those of a layer

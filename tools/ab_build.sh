@@ -15,7 +15,7 @@ fi
 objs=""
 for f in $src/atom_amd/csrc/*.hip; do
   o=$out/$(basename $f .hip).o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -DATOM_TOOLS -c $f -o $o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -DATOM_TOOLS $ABFLAGS -c $f -o $o &
   objs="$objs $o"
 done
 wait
