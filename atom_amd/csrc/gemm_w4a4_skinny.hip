@@ -95,11 +95,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
   // XCD-aware feature map (round 4, as in gemv_w4a4.hip): workgroup b runs on XCD b % 8; a 64-byte line of weight scales holds 32
   // adjacent features of one group = two workgroups' worth -- dealt round-robin they sit in two L2s.  Bijective for any grid size.
   const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
-#ifdef ATOM_NOXCD
-  const int n0 = (int)blockIdx.x * 16;
-#else
   const int n0 = (xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3)) * 16;
-#endif
   const int K4h = p.K4h, G = p.G;
 
   // this wave's items: int4 groups [i0, min(i1, G)), and the keeper if i1 == G + 1
