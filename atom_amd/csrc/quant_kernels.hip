@@ -58,60 +58,43 @@ struct ActQuantParams {
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
-// Quantise + store the 16 values of slot (row r, group g, octet lane j).  e0 = first (reordered) channel of the slot.
+// What one slot (row r, group g, octet lane j: 16 reordered channels) writes: computed by slot_codes / slot_codes_h, written by
+// slot_store -- apart, so that the persistent kernels can issue a row's stores AFTER the next iteration's wait (below).
+template <bool DQ>
+struct SlotOut {
+  v4u w;                  // keeper: the 16 code bytes; packed / wide: the two nibble words in w[0], w[1]; BF6: the 12 stream bytes in w[0..2]
+  unsigned sh;            // the group's scale as a half (low 16 bits)
+  v4u o[DQ ? 2 : 1];      // DQ: the 16 de-quantised halves
+};
+
 // FMT: the code format as a compile-time constant (0 packed nibbles, 1 wide int8, 2 BF6 records) -- as run-time branches on
 // p.wide / p.f6_rows the three store paths cost the packed path 4-7 % (register copies at the merges; round 4, same-box A/B)
-template <bool SIM, bool DQ, int FMT>
-__device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantParams &p, int64_t r, int g, int j,
-                                           int e0, bool keeper, int K4h) {
-  float amax = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-  amax = max8(amax);
-  const GroupScale gs = group_scale<SIM>(amax, keeper, p.clip);
-  float tr[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) tr[i] = group_code<SIM>(v[i], gs);
-  const float s_store = gs.s_store, s_dq = gs.s_dq;
-
-  const v4u w = pack_codes16(tr, keeper);
+template <bool DQ, int FMT>
+__device__ __forceinline__ void slot_store(const SlotOut<DQ> &q, const ActQuantParams &p, int64_t r, int g, int j, int e0,
+                                           bool keeper, int K4h) {
+  typedef unsigned v3u __attribute__((ext_vector_type(3)));
   if (keeper) {
-    *reinterpret_cast<v4u *>(p.o8 + r * kKeeper + j * 16) = w;
+    *reinterpret_cast<v4u *>(p.o8 + r * kKeeper + j * 16) = q.w;
   } else {
     if constexpr (FMT == 2) {
-      // BF6 (E3M2) holds every INT4 code exactly; v_cvt_scalef32_2xpk16_bf6_f32 converts AND packs 32 floats into 6-bit
-      // fields, interleaving its two sources (field 2i = a[i], 2i+1 = b[i]; tools/probes): my 16 codes are fields 0..15
-      typedef float v16f __attribute__((ext_vector_type(16)));
-      typedef unsigned v6u __attribute__((ext_vector_type(6)));
-      typedef unsigned v3u __attribute__((ext_vector_type(3)));
-      v16f ea, eb;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ea[i] = tr[2 * i];
-        eb[i] = tr[2 * i + 1];
-        ea[8 + i] = 0.f;
-        eb[8 + i] = 0.f;
-      }
-      const v6u f = cvt_2xpk16_bf6(ea, eb);
       uint8_t *dst = p.o4 + ((int64_t)g * p.f6_rows + r) * 104;
-      *reinterpret_cast<v3u *>(dst + 12 * j) = v3u{f[0], f[1], f[2]};
-      if (j == 0) {                                       // the GEMM reads the token scale from the row itself
-        const half_t shh = f2h(s_store);                  // fp16 at byte 96, the same value as fp32 at byte 100
-        const unsigned sh = (unsigned)__builtin_bit_cast(unsigned short, shh);
-        *reinterpret_cast<v2u *>(dst + 96) = v2u{sh, __builtin_bit_cast(unsigned, (float)shh)};
+      *reinterpret_cast<v3u *>(dst + 12 * j) = v3u{q.w[0], q.w[1], q.w[2]};
+      if (j == 0) {                                       // the GEMM reads the token scale from the row itself: fp16 at byte 96,
+        const float sf = (float)__builtin_bit_cast(half_t, (unsigned short)q.sh);   // the same value as fp32 at byte 100
+        *reinterpret_cast<v2u *>(dst + 96) = v2u{q.sh, __builtin_bit_cast(unsigned, sf)};
       }
     } else if constexpr (FMT == 1) {
       // my 16 channels are half `j & 1` of 32-channel block g*4 + j/2: even channels -> chunk 0, odd -> chunk 1
       uint8_t *dst = p.o4 + r * (int64_t)(2 * K4h) + g * 128 + (j >> 1) * 32 + (j & 1) * 8;
-      *reinterpret_cast<v2u *>(dst) = v2u{(w[0] << 4) & 0xF0F0F0F0u, (w[1] << 4) & 0xF0F0F0F0u};
-      *reinterpret_cast<v2u *>(dst + 16) = v2u{w[0] & 0xF0F0F0F0u, w[1] & 0xF0F0F0F0u};
+      *reinterpret_cast<v2u *>(dst) = v2u{(q.w[0] << 4) & 0xF0F0F0F0u, (q.w[1] << 4) & 0xF0F0F0F0u};
+      *reinterpret_cast<v2u *>(dst + 16) = v2u{q.w[0] & 0xF0F0F0F0u, q.w[1] & 0xF0F0F0F0u};
     } else {
-      *reinterpret_cast<v2u *>(p.o4 + r * (int64_t)K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
+      *reinterpret_cast<v2u *>(p.o4 + r * (int64_t)K4h + g * 64 + j * 8) = v2u{q.w[0], q.w[1]};
     }
   }
   if (j == 0) {
     half_t *dst = keeper ? p.s8 : (p.s4 + (int64_t)g * p.ld);
-    const half_t sh = f2h(s_store);
+    const half_t sh = __builtin_bit_cast(half_t, (unsigned short)q.sh);
     if (p.ref_layout) {
       const int base = ref_scale_index((int)r);
 #pragma unroll
@@ -121,16 +104,130 @@ __device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantP
     }
   }
   if constexpr (DQ) {
+    v4u *dst = reinterpret_cast<v4u *>(p.xq + r * (int64_t)p.H + e0);
+    dst[0] = q.o[0];
+    dst[1] = q.o[1];
+  }
+}
+
+// Quantise the 16 values of a slot (FP32 form: the kernel-flavoured mode, and the simulated mode's fallback)
+template <bool SIM, bool DQ, int FMT>
+__device__ __forceinline__ SlotOut<DQ> slot_codes(const float (&v)[16], const ActQuantParams &p, bool keeper) {
+  SlotOut<DQ> q;
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  amax = max8(amax);
+  const GroupScale gs = group_scale<SIM>(amax, keeper, p.clip);
+  float tr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tr[i] = group_code<SIM>(v[i], gs);
+  q.sh = (unsigned)__builtin_bit_cast(unsigned short, f2h(gs.s_store));
+  q.w = pack_codes16(tr, keeper);
+  if constexpr (FMT == 2) {
+    if (!keeper) {
+      // BF6 (E3M2) holds every INT4 code exactly; v_cvt_scalef32_2xpk16_bf6_f32 converts AND packs 32 floats into 6-bit
+      // fields, interleaving its two sources (field 2i = a[i], 2i+1 = b[i]; tools/probes): my 16 codes are fields 0..15
+      typedef float v16f __attribute__((ext_vector_type(16)));
+      typedef unsigned v6u __attribute__((ext_vector_type(6)));
+      v16f ea, eb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ea[i] = tr[2 * i];
+        eb[i] = tr[2 * i + 1];
+        ea[8 + i] = 0.f;
+        eb[8 + i] = 0.f;
+      }
+      const v6u f = cvt_2xpk16_bf6(ea, eb);
+      q.w = v4u{f[0], f[1], f[2], 0u};
+    }
+  }
+  if constexpr (DQ) {
     // code * scale is exact in FP32 (8 x 11 significant bits), so one rounding to half == the reference's half
     // multiply; "+ 0" turns the -0 of a negative value that rounded to code 0 into the reference's +0
-    v4u o[2];
-    half_t *ov = reinterpret_cast<half_t *>(o);
+    half_t *ov = reinterpret_cast<half_t *>(q.o);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ov[i] = (half_t)__builtin_fmaf(tr[i], s_dq, 0.0f);
-    v4u *dst = reinterpret_cast<v4u *>(p.xq + r * (int64_t)p.H + e0);
-    dst[0] = o[0];
-    dst[1] = o[1];
+    for (int i = 0; i < 16; ++i) ov[i] = (half_t)__builtin_fmaf(tr[i], gs.s_dq, 0.0f);
   }
+  return q;
+}
+
+template <bool SIM, bool DQ, int FMT>
+__device__ __forceinline__ void quant_slot(const float (&v)[16], const ActQuantParams &p, int64_t r, int g, int j,
+                                           int e0, bool keeper, int K4h) {
+  slot_store<DQ, FMT>(slot_codes<SIM, DQ, FMT>(v, p, keeper), p, r, g, j, e0, keeper, K4h);
+}
+
+// The same for the simulated path with the slot as 8 half pairs (quant_math.h, "SIM mode in the FP16 domain"): z[i] = channels
+// (pair_lo(i), pair_lo(i) + 4) of the slot.  Same codes, scales and de-quantised values as slot_codes<true, ...> bit for bit.
+template <bool DQ, int FMT>
+__device__ __forceinline__ SlotOut<DQ> slot_codes_h(const unsigned (&z)[8], const ActQuantParams &p, bool keeper) {
+  SlotOut<DQ> q;
+  const float amax = max8_dpp(amax16_h(z));
+  const GroupScale gs = group_scale<true>(amax, keeper, p.clip);
+  const unsigned s2 = (unsigned)__builtin_bit_cast(unsigned short, (half_t)gs.s_store);      // exact: s_store is a half value
+  const unsigned lo2 = keeper ? 0xD800D800u : 0xC800C800u, hi2 = keeper ? 0x57F057F0u : 0x47004700u;   // (-128 | -8), (127 | 7)
+  unsigned t[8];
+  sim_codes4(z[0], z[1], z[2], z[3], gs.rs, s2, lo2, hi2, t[0], t[1], t[2], t[3]);
+  sim_codes4(z[4], z[5], z[6], z[7], gs.rs, s2, lo2, hi2, t[4], t[5], t[6], t[7]);
+  q.sh = s2;
+  // t[i] = (0x6600 + c_lo, 0x6600 + c_hi): the codes are the low bits
+  if (keeper) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned c01 = (t[4 * k] & 0x00FF00FFu) | ((t[4 * k + 1] & 0x00FF00FFu) << 8);      // low half: channels 8k + 0, 1; high: + 4, 5
+      const unsigned c23 = (t[4 * k + 2] & 0x00FF00FFu) | ((t[4 * k + 3] & 0x00FF00FFu) << 8);
+      w[2 * k] = __builtin_amdgcn_perm(c23, c01, 0x05040100u);                                  // channels 8k + 0..3
+      w[2 * k + 1] = __builtin_amdgcn_perm(c23, c01, 0x07060302u);                              // channels 8k + 4..7
+    }
+    q.w = v4u{w[0], w[1], w[2], w[3]};
+  } else if constexpr (FMT == 2) {
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef unsigned v6u __attribute__((ext_vector_type(6)));
+    v16f ea, eb;                                          // field 2i = ea[i], 2i + 1 = eb[i]: channel 2i -> ea[i], 2i + 1 -> eb[i]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const h2v c = __builtin_bit_cast(h2v, t[i]) - h2v{(_Float16)1536.0f, (_Float16)1536.0f};
+      const int L = pair_lo(i);                           // channels L and L + 4 (same parity)
+      if (L & 1) { eb[L >> 1] = (float)c.x; eb[(L + 4) >> 1] = (float)c.y; }
+      else { ea[L >> 1] = (float)c.x; ea[(L + 4) >> 1] = (float)c.y; }
+    }
+#pragma unroll
+    for (int i = 8; i < 16; ++i) { ea[i] = 0.f; eb[i] = 0.f; }
+    const v6u f = cvt_2xpk16_bf6(ea, eb);
+    q.w = v4u{f[0], f[1], f[2], 0u};
+  } else {
+    unsigned w[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      w[k] = (t[4 * k] & 0x000F000Fu) | ((t[4 * k + 1] & 0x000F000Fu) << 4) | ((t[4 * k + 2] & 0x000F000Fu) << 8) |
+             ((t[4 * k + 3] & 0x000F000Fu) << 12);
+    q.w = v4u{w[0], w[1], 0u, 0u};
+  }
+  if constexpr (DQ) {
+    // code * scale rounded once to half (the reference's half multiply); codes come out of the subtraction as +0 for a negative
+    // value that rounded to 0, as the FP32 form's "+ 0" arranges
+    const h2v sv = {__builtin_bit_cast(_Float16, (unsigned short)s2), __builtin_bit_cast(_Float16, (unsigned short)s2)};
+    unsigned d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      d[i] = __builtin_bit_cast(unsigned, (__builtin_bit_cast(h2v, t[i]) - h2v{(_Float16)1536.0f, (_Float16)1536.0f}) * sv);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                         // dword m of the 16 halves = channels (2m, 2m + 1)
+      q.o[k][0] = __builtin_amdgcn_perm(d[4 * k + 1], d[4 * k], 0x05040100u);       // channels 8k + 0, 1: low halves of pairs 0, 1
+      q.o[k][1] = __builtin_amdgcn_perm(d[4 * k + 3], d[4 * k + 2], 0x05040100u);   // 8k + 2, 3
+      q.o[k][2] = __builtin_amdgcn_perm(d[4 * k + 1], d[4 * k], 0x07060302u);       // 8k + 4, 5: high halves
+      q.o[k][3] = __builtin_amdgcn_perm(d[4 * k + 3], d[4 * k + 2], 0x07060302u);   // 8k + 6, 7
+    }
+  }
+  return q;
+}
+
+template <bool DQ, int FMT>
+__device__ __forceinline__ void quant_slot_h(const unsigned (&z)[8], const ActQuantParams &p, int64_t r, int g, int j, int e0,
+                                             bool keeper, int K4h) {
+  slot_store<DQ, FMT>(slot_codes_h<DQ, FMT>(z, p, keeper), p, r, g, j, e0, keeper, K4h);
 }
 
 // reorder / rmsnorm: persistent workgroups, LDS-DMA double buffer.  NP = slots (16 channels) per thread per row.
@@ -235,6 +332,30 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
     }
   }
 
+  unsigned wp[NP][8];                                       // SIM, FP16-domain form: the weights as pairs (pair_lo(i), + 4)
+  if constexpr (NORM && SIM) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        wp[ps][i] = (unsigned)__builtin_bit_cast(unsigned short, wg[ps][pair_lo(i)]) |
+                    ((unsigned)__builtin_bit_cast(unsigned short, wg[ps][pair_lo(i) + 4]) << 16);
+  }
+
+  // (Round 4 tried issuing a row's stores one iteration late, behind the next row's vmcnt(0) -- vmcnt counts stores too, so that wait
+  // also covers the previous row's writes: slower, 14.6 vs 13.6 us at 4,096 x 4096; the rows of the six resident workgroups of a CU
+  // already overlap each other's write latency, and the 10-25 registers of the parked results cost a workgroup per CU.)
+  SlotOut<DQ> pend[NP];
+  auto flush = [&](int64_t rr) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int slot = ps * 256 + tid;
+      if (slot < nslots) {
+        const int g = slot >> 3;
+        slot_store<DQ, FMT>(pend[ps], p, rr, g, j, slot * 16, g == Gt - 1, K4h);
+      }
+    }
+  };
   for (; r < rend; r += rstep, b ^= 1) {
     __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0): my DMA writes have landed
     __syncthreads();
@@ -283,6 +404,66 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       __syncthreads();
     }
 
+    float rinv = 0.f;
+    if constexpr (NORM) {
+      const float tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
+      // correctly rounded divide, sqrt and divide (hipcc default); a power-of-two H divides exactly by multiplying
+      const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
+      rinv = 1.0f / sqrtf(var + p.eps);
+    }
+    if constexpr (SIM) {
+      // the simulated path in the FP16 domain (quant_math.h): a slot as 8 half pairs, pair i = channels (pair_lo(i), pair_lo(i) + 4)
+      if (p.clip >= kSimHalfMinClip) {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          unsigned z[8];
+          if (p.idx) {
+            unsigned xs[16];                              // one gathered half per register (ds_read_u16 zero-extends)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xs[k] = *reinterpret_cast<const unsigned short *>(row + off[ps][k]);
+            if constexpr (NORM) {
+              // HF LlamaRMSNorm, half opmath: half(x * rinv) from the FP32 product, then a half multiply by the weight
+              sim_scale4<0, 0, 0, 0>(xs[0], xs[1], xs[2], xs[3], xs[4], xs[5], xs[6], xs[7], rinv, z[0], z[1], z[2], z[3]);
+              sim_scale4<0, 0, 0, 0>(xs[8], xs[9], xs[10], xs[11], xs[12], xs[13], xs[14], xs[15], rinv, z[4], z[5], z[6], z[7]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) z[i] = xs[pair_lo(i)] | (xs[pair_lo(i) + 4] << 16);
+            }
+          } else {
+            v4u raw[2];                                   // dword m = channels (2m, 2m + 1)
+            raw[0] = *reinterpret_cast<const v4u *>(row + off[ps][0]);
+            raw[1] = *reinterpret_cast<const v4u *>(row + off[ps][0] + 16);
+            if constexpr (NORM) {
+              sim_scale4<0, 1, 0, 1>(raw[0][0], raw[0][0], raw[0][1], raw[0][1], raw[0][2], raw[0][2], raw[0][3], raw[0][3], rinv, z[0],
+                                     z[1], z[2], z[3]);
+              sim_scale4<0, 1, 0, 1>(raw[1][0], raw[1][0], raw[1][1], raw[1][1], raw[1][2], raw[1][2], raw[1][3], raw[1][3], rinv, z[4],
+                                     z[5], z[6], z[7]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                z[4 * k + 0] = __builtin_amdgcn_perm(raw[k][2], raw[k][0], 0x05040100u);   // channels 8k + (0, 4)
+                z[4 * k + 1] = __builtin_amdgcn_perm(raw[k][2], raw[k][0], 0x07060302u);   // (1, 5)
+                z[4 * k + 2] = __builtin_amdgcn_perm(raw[k][3], raw[k][1], 0x05040100u);   // (2, 6)
+                z[4 * k + 3] = __builtin_amdgcn_perm(raw[k][3], raw[k][1], 0x07060302u);   // (3, 7)
+              }
+            }
+          }
+          if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              z[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2v, z[i]) * __builtin_bit_cast(h2v, wp[ps][i]));
+          }
+          const int slot = ps * 256 + tid;
+          if (slot < nslots) {
+            const int g = slot >> 3;
+            pend[ps] = slot_codes_h<DQ, FMT>(z, p, g == Gt - 1);
+          }
+        }
+        flush(r);
+        continue;
+      }
+    }
+
     float x[NP][16];
     half_t xh[NP][16];
 #pragma unroll
@@ -300,10 +481,6 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       }
     }
     if constexpr (NORM) {
-      const float tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
-      // correctly rounded divide, sqrt and divide (hipcc default); a power-of-two H divides exactly by multiplying
-      const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
-      const float rinv = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
 #pragma unroll
@@ -329,9 +506,10 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       const int slot = ps * 256 + tid;
       if (slot < nslots) {
         const int g = slot >> 3;
-        quant_slot<SIM, DQ, FMT>(x[ps], p, r, g, j, slot * 16, g == Gt - 1, K4h);
+        pend[ps] = slot_codes<SIM, DQ, FMT>(x[ps], p, g == Gt - 1);
       }
     }
+    flush(r);
   }
 }
 
@@ -359,12 +537,27 @@ __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
     rb[1] = *reinterpret_cast<const v4u *>(brow + e0 + 8);
     const half_t *av = reinterpret_cast<const half_t *>(ra);
     const half_t *bv = reinterpret_cast<const half_t *>(rb);
+    const int g = slot >> 3;
+    if constexpr (SIM) {
+      if (p.clip >= kSimHalfMinClip) {
+        // act_fn(gate) * up in half opmath: half(silu) from the FP32 value, then a half multiply -- pairwise (quant_math.h)
+        unsigned z[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int L = pair_lo(i);
+          const h2v sh = {(_Float16)silu_f32((float)av[L]), (_Float16)silu_f32((float)av[L + 4])};
+          const h2v bb = {bv[L], bv[L + 4]};
+          z[i] = __builtin_bit_cast(unsigned, sh * bb);
+        }
+        quant_slot_h<DQ, FMT>(z, p, r, g, tid & 7, e0, g == Gt - 1, K4h);
+        continue;
+      }
+    }
     float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       v[k] = silu_mul<SIM>((float)av[k], (float)bv[k]);
     }
-    const int g = slot >> 3;
     quant_slot<SIM, DQ, FMT>(v, p, r, g, tid & 7, e0, g == Gt - 1, K4h);
   }
 }

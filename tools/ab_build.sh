@@ -8,9 +8,9 @@ name=$1; rev=$2
 out=build/ab/$name; src=$out/src
 rm -rf $out; mkdir -p $src/atom_amd/csrc $src/include $src/tools
 if [ -n "$rev" ]; then
-  git archive $rev atom_amd/csrc include tools/gemm_bench.cpp | tar -x -C $src
+  git archive $rev atom_amd/csrc include tools/gemm_bench.cpp tools/quant_bench.cpp | tar -x -C $src
 else
-  cp atom_amd/csrc/*.hip atom_amd/csrc/*.h $src/atom_amd/csrc/; cp include/*.h $src/include/; cp tools/gemm_bench.cpp $src/tools/
+  cp atom_amd/csrc/*.hip atom_amd/csrc/*.h $src/atom_amd/csrc/; cp include/*.h $src/include/; cp tools/gemm_bench.cpp tools/quant_bench.cpp $src/tools/
 fi
 objs=""
 for f in $src/atom_amd/csrc/*.hip; do
@@ -21,5 +21,6 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/libatom_hip.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $src/tools/gemm_bench.cpp -o $out/gemm_bench -L$out -latom_hip -Wl,-rpath,'$ORIGIN' 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $src/tools/quant_bench.cpp -o $out/quant_bench -L$out -latom_hip -Wl,-rpath,'$ORIGIN' 2>/dev/null || true
 rm -f $objs; rm -rf $src
 ls -la $out
