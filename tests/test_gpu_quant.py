@@ -82,6 +82,49 @@ def test_reorder_quant_golden(golden_dir):
     assert np.array_equal(bits16(t2n(outs[4])), bits16(z["xq"]))
 
 
+@pytest.mark.parametrize("clip", [1.0 / 64.0, 0.5, 0.0155])
+def test_simulated_path_small_clips_and_edge_values(clip):
+    """The simulated path runs in the FP16 domain (quant_math.h sim_codes4) for clip >= 1/64 and in the FP32 form below (a smaller
+    clip could overflow the half estimate of the quotient): both against the oracle, bit for bit, on rows that hold every edge the
+    arithmetic has -- all-zero groups (the 1e-5 clamp makes the scale a subnormal half), values far below the scale, subnormal
+    halves, fp16 max, exact ties of the half quotient, -0 -- through all three quantisers and the de-quantised output."""
+    ops = _ops()
+    M, H = 12, 1024
+    x = rand_act(M, H, seed=11)
+    x[1] = 0
+    x[2, :] = 1e-6
+    x[3, 7] = 65504.0
+    x[4] = (np.arange(H) % 15 - 7) * 0.5
+    x[5] = np.float16(6e-8) * (np.arange(H) % 5)            # subnormal halves
+    x[6, ::2] = -0.0
+    x[7] = (np.arange(H) % 17 - 8) * np.float16(0.000123)
+    x[8, :128] = 0                                          # one all-zero group in an ordinary row
+    x[9] *= np.float16(1e-3)
+    x[10] = np.where(np.arange(H) % 128 == 0, np.float16(30000.0), x[10] * np.float16(1e-4))   # huge group maximum, tiny values
+    if clip < 0.1:                                          # clamp(1e-5) * clip / 7 rounds to a ZERO half: the reference divides by 0
+        x[[1, 2, 5]] = rand_act(3, H, seed=13) * np.float16(1e-2)       # there (NaN codes); keep these rows' scales representable
+        x[8, :128] = x[9, :128]
+        x[10] = rand_act(1, H, seed=14)[0] * np.float16(4.0)              # (the normalised row 10 has groups of ~1e-8)
+    idx = np.random.default_rng(3).permutation(H).astype(np.int16)
+    ref = O.reorder_quant(x, idx, "sim", clip)
+    outs = ops.reorder_fp16_i4(torch.from_numpy(x).cuda(), torch.from_numpy(idx).cuda(), quant_mode="sim", clip=clip,
+                               scale_layout="plain", return_dequant=True)
+    _check_tail(outs, ref, M, "plain", exact=True, xq_ref=O.act_dequant_sim(ref))
+    ref = O._quant_row_tail(x, "sim", clip)
+    outs = ops.reorder_fp16_i4(torch.from_numpy(x).cuda(), None, quant_mode="sim", clip=clip, scale_layout="plain", return_dequant=True)
+    _check_tail(outs, ref, M, "plain", exact=True, xq_ref=O.act_dequant_sim(ref))
+    w = (1 + 0.1 * np.random.default_rng(4).standard_normal(H)).astype(np.float16)
+    ref = O.rmsnorm_reorder_quant(x, w, 1e-5, idx, "sim", clip)
+    outs = ops.rmsnorm_fp16_i4(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda(), 1e-5,
+                               quant_mode="sim", clip=clip, scale_layout="plain", return_dequant=True)
+    _check_tail(outs, ref, M, "plain", exact=True, xq_ref=O.act_dequant_sim(ref))
+    b = rand_act(M, H, seed=12)
+    ref = O.silu_mul_quant(x, b, "sim", clip)
+    outs = ops.activate_fp16_i4(torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda(), quant_mode="sim", clip=clip,
+                                scale_layout="plain", return_dequant=True)
+    _check_tail(outs, ref, M, "plain", exact=False)
+
+
 @pytest.mark.parametrize("M,H", [(1, 256), (7, 1024), (33, 4096), (4, 5120), (2, 13824)])
 @pytest.mark.parametrize("mode,clip", [("sim", 0.9), ("kernel", 1.0)])
 def test_rmsnorm_quant_bit_exact(M, H, mode, clip):
