@@ -400,6 +400,110 @@ template <int UNR, int R, int WPB, bool STAGED, bool XCD = false> static void l_
   hipLaunchKernelGGL((gv<UNR, R, WPB, STAGED, XCD>), dim3(p.N / (WPB * R)), dim3(WPB * 64), lds, s, p);
 }
 
+// gr<PPW, NST>: the same arithmetic and summation order with the weights streamed by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
+// into a ring of NST slots; a slot = one ROUND = the 4 consecutive feature rows the 4 waves consume next (4 x K4h contiguous bytes),
+// fetched as 1 KiB pieces, PPW pieces per wave (PPW = ceil(ceil(4 K4h / 1024) / 4): the padding pieces re-read the round's tail).
+// NST - 1 rounds are in flight per workgroup.  Per round: counted vmcnt -> barrier -> issue round i + NST - 1 -> consume round i.
+// Small operands (activation row, scales of the workgroup's features, keeper rows) are staged in LDS once; outputs leave at the end, so
+// that nothing but the DMA pieces is counted by vmcnt inside the loop.
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p; }
+__device__ __forceinline__ void dma16(const void *sbase, unsigned voff, unsigned lds_byte_addr) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int PPW, int NST>
+__global__ __launch_bounds__(256) void gr(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, nchunks = K4h >> 4, G = p.G;
+  const bool leader = (lane & 3) == 0;
+  const int F = p.N / gridDim.x;                                       // features of this workgroup (multiple of 4)
+  const int xq = (int)gridDim.x >> 3, xx = blockIdx.x & 7;
+  const int blk = xx * xq + ((int)blockIdx.x >> 3);                    // XCD-aware (gridDim.x multiple of 8)
+  const int f0 = blk * F, nrounds = F >> 2;
+  const int rbytes = 4 * K4h;                                          // bytes of a round
+  const int slot = (rbytes + 1023) & ~1023;
+  char *ring = lds;
+  char *l_a = ring + NST * slot;                                       // K4h + 128
+  half_t *l_sa = reinterpret_cast<half_t *>(l_a + K4h + 128);          // G + 1 (+ pad)
+  half_t *l_sb = l_sa + ((G + 2 + 7) & ~7);                            // [G][F]
+  half_t *l_sb8 = l_sb + G * F;                                        // [F]
+  char *l_b8 = reinterpret_cast<char *>(l_sb8 + ((F + 7) & ~7));       // [F][128]
+  half_t *l_out = reinterpret_cast<half_t *>(l_b8 + F * 128);          // [F]
+  const unsigned ring0 = lds_addr_of(ring);
+  const uint8_t *wsrc = p.B4 + (int64_t)f0 * K4h;
+  auto issue = [&](int r) {                                            // my PPW pieces of round r
+    const unsigned base = (unsigned)r * (unsigned)rbytes;
+    const unsigned sl = ring0 + (unsigned)(r % NST) * (unsigned)slot;
+    const int npieces = (rbytes + 1023) >> 10;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = min(j * 4 + wave, npieces - 1);                // padding pieces rewrite the last piece with the same bytes
+      unsigned off = (unsigned)piece * 1024u + (unsigned)lane * 16u;
+      off = off < (unsigned)rbytes ? off : (unsigned)rbytes - 16u;    // padding lanes / pieces re-read the round's last chunk
+      dma16(wsrc, base + off, sl + (unsigned)piece * 1024u);
+    }
+  };
+  // small operands -> registers (issued BEFORE the DMA: vmcnt is in order, so "only the DMA pieces outstanding" means these landed)
+  v4i ra[2] = {}, rb8[2] = {};
+  for (int i = 0; i < 2; ++i) { const int q = tid + i * 256; if (q < nchunks + 8) ra[i] = q < nchunks ? *reinterpret_cast<const v4i *>(p.A4 + q * 16) : *reinterpret_cast<const v4i *>(p.A8 + (q - nchunks) * 16); }
+  for (int i = 0; i < 2; ++i) { const int q = tid + i * 256; if (q < F * 8) rb8[i] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)f0 * 128 + q * 16); }
+  half_t rsa = (half_t)0; if (tid <= G) rsa = tid < G ? p.sA[tid] : p.sA8[0];
+  half_t rsb8 = (half_t)0; if (tid < F) rsb8 = p.sB8[f0 + tid];
+  constexpr int SBV = 9;                                               // scales of the workgroup's features: G x F halves, up to 6 per thread
+  half_t rsb[SBV];
+  for (int i = 0; i < SBV; ++i) { const int q = tid + i * 256; rsb[i] = (half_t)0; if (q < G * F) rsb[i] = p.sB[(int64_t)(q / F) * p.N + f0 + q % F]; }
+#pragma unroll
+  for (int r = 0; r < NST - 1; ++r) if (r < nrounds) issue(r);
+  if (nrounds >= NST - 1) wait_vm<(NST - 1) * PPW>(); else wait_vm<0>();
+  for (int i = 0; i < 2; ++i) { const int q = tid + i * 256; if (q < nchunks + 8) *reinterpret_cast<v4i *>(l_a + q * 16) = ra[i]; if (q < F * 8) *reinterpret_cast<v4i *>(l_b8 + q * 16) = rb8[i]; }
+  if (tid <= G) l_sa[tid] = rsa;
+  if (tid < F) l_sb8[tid] = rsb8;
+  for (int i = 0; i < SBV; ++i) { const int q = tid + i * 256; if (q < G * F) l_sb[q] = rsb[i]; }
+  for (int i = 0; i < nrounds; ++i) {
+    if (i + NST - 1 <= nrounds) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();     // round i's pieces of this wave have landed
+    __syncthreads();
+    if (i + NST - 1 < nrounds) issue(i + NST - 1);
+    const char *rowp = ring + (i % NST) * slot + wave * K4h;
+    const int fl = 4 * i + wave;                                       // local feature
+    float acc = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+      const int c = c0 + lane, cc = c < nchunks ? c : nchunks - 1;
+      const v4i w = *reinterpret_cast<const v4i *>(rowp + cc * 16);
+      const v4i a = *reinterpret_cast<const v4i *>(l_a + cc * 16);
+      const half_t sbh = l_sb[(cc >> 2) * F + fl], sah = l_sa[cc >> 2];
+      int d = 0;
+      d = __builtin_amdgcn_sdot8(a[0], w[0], d, false); d = __builtin_amdgcn_sdot8(a[1], w[1], d, false);
+      d = __builtin_amdgcn_sdot8(a[2], w[2], d, false); d = __builtin_amdgcn_sdot8(a[3], w[3], d, false);
+      d = quad_sum(d);
+      const float t = (float)d * (float)sah;
+      const float nx = __builtin_fmaf(t, (float)sbh, acc);
+      acc = (leader && c < nchunks) ? nx : acc;
+    }
+    v4i a8 = {0, 0, 0, 0}, w8 = {0, 0, 0, 0};
+    if (lane < 8) { a8 = *reinterpret_cast<const v4i *>(l_a + K4h + lane * 16); w8 = *reinterpret_cast<const v4i *>(l_b8 + fl * 128 + lane * 16); }
+    int d = 0;
+    d = __builtin_amdgcn_sdot4(a8[0], w8[0], d, false); d = __builtin_amdgcn_sdot4(a8[1], w8[1], d, false);
+    d = __builtin_amdgcn_sdot4(a8[2], w8[2], d, false); d = __builtin_amdgcn_sdot4(a8[3], w8[3], d, false);
+    d = quad_sum(d); d += __shfl_xor(d, 4);
+    const float s = wave_sum_butterfly(acc);
+    if (lane == 0) { const float t = (float)d * (float)l_sa[G]; l_out[fl] = (half_t)__builtin_fmaf(t, (float)l_sb8[fl], s); }
+  }
+  __syncthreads();
+  if (tid < F) p.D[f0 + tid] = l_out[tid];
+}
+template <int PPW, int NST, int WGS> static void l_gr(P p, int, hipStream_t s) {
+  const int F = p.N / WGS;
+  const size_t slot = ((size_t)4 * p.K4h + 1023) & ~(size_t)1023;
+  const size_t lds = NST * slot + p.K4h + 128 + (size_t)(((p.G + 2 + 7) & ~7) + p.G * F + ((F + 7) & ~7)) * 2 + (size_t)F * 128 + (size_t)F * 2 + 64;
+  static bool attr = false;
+  if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gr<PPW, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  if (lds > 160 * 1024 || (p.N % WGS) != 0 || (F & 3) != 0 || PPW * 4 * 1024 < 4 * p.K4h || p.G * F > 9 * 256) { return; }
+  hipLaunchKernelGGL((gr<PPW, NST>), dim3(WGS), dim3(256), lds, s, p);
+}
+
 static uint32_t rng_state = 12345;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 
@@ -464,10 +568,13 @@ int main(int argc, char **argv) {
     vs.push_back(k2 ? V{"v0<2>            ", l_v0<2>, 0} : V{"v0<4>            ", l_v0<4>, 0});
 #define GV(U, R, W, S) vs.push_back({"gv<" #U "," #R "> wpb" #W " " #S, l_gv<U, R, W, S>, 0})
 #define GX(U, R, W, S) vs.push_back({"gx<" #U "," #R "> wpb" #W " " #S, l_gv<U, R, W, S, true>, 0})
-    GV(1, 1, 4, false); GX(1, 1, 4, false); GV(2, 1, 4, false); GX(2, 1, 4, false); GV(1, 2, 4, false); GX(1, 2, 4, false);
-    GV(2, 2, 4, false); GX(2, 2, 4, false); GX(3, 2, 4, false); GX(1, 4, 4, false); GX(2, 4, 4, false);
-    GX(1, 1, 8, false); GX(2, 1, 8, false); GX(1, 2, 8, false); GX(1, 1, 2, false); GX(2, 1, 2, false); GX(1, 2, 2, false);
-    GV(1, 2, 8, true); GX(1, 2, 8, true); GX(2, 2, 8, true); GX(1, 2, 4, true); GX(2, 2, 4, true); GX(1, 4, 4, true);
+    GX(1, 1, 4, false); GX(1, 2, 4, false);
+    if (K == 4096 && N == 4096) { vs.push_back({"gr<2,8> 256 wgs  ", l_gr<2, 8, 256>, 0}); vs.push_back({"gr<2,12> 256 wgs ", l_gr<2, 12, 256>, 0}); vs.push_back({"gr<2,4> 512 wgs  ", l_gr<2, 4, 512>, 0}); vs.push_back({"gr<2,8> 512 wgs  ", l_gr<2, 8, 512>, 0}); }
+    if (K == 4096 && N == 11008) { vs.push_back({"gr<2,8> 344 wgs  ", l_gr<2, 8, 344>, 0}); vs.push_back({"gr<2,12> 344 wgs ", l_gr<2, 12, 344>, 0}); vs.push_back({"gr<2,6> 688 wgs  ", l_gr<2, 6, 688>, 0}); }
+    if (K == 11008) { vs.push_back({"gr<6,4> 256 wgs  ", l_gr<6, 4, 256>, 0}); vs.push_back({"gr<6,5> 256 wgs  ", l_gr<6, 5, 256>, 0}); vs.push_back({"gr<6,3> 512 wgs  ", l_gr<6, 3, 512>, 0}); }
+    if (K == 5120 && N == 13824) { vs.push_back({"gr<3,8> 432 wgs  ", l_gr<3, 8, 432>, 0}); vs.push_back({"gr<3,12> 432 wgs ", l_gr<3, 12, 432>, 0}); vs.push_back({"gr<3,6> 864 wgs  ", l_gr<3, 6, 864>, 0}); }
+    if (K == 5120 && N == 5120) { vs.push_back({"gr<3,8> 256 wgs  ", l_gr<3, 8, 256>, 0}); vs.push_back({"gr<3,5> 640 wgs  ", l_gr<3, 5, 640>, 0}); }
+    if (K == 13824) { vs.push_back({"gr<7,4> 256 wgs  ", l_gr<7, 4, 256>, 0}); vs.push_back({"gr<7,5> 256 wgs  ", l_gr<7, 5, 256>, 0}); vs.push_back({"gr<7,3> 640 wgs  ", l_gr<7, 3, 640>, 0}); }
     vs.push_back({"slab<8,nt>   2048", l_slab<8, true, 2048>, 0});
     vs.push_back({"empty kernel     ", l_empty, 0});
     const size_t alg = wbytes + K4h + 128 + 2 * G + 2 + 2 * (size_t)N;
