@@ -57,9 +57,23 @@ def graph_time(launchers, iters):
     return best
 
 
+WIDE = bool(int(os.environ.get("ATOM_BENCH_WIDE", "0")))      # tools only: pre-widened activations (ATOM_A_WIDE) instead of packed nibbles
+
+
+def widen(a4):
+    """packed nibbles [M, K4/2] -> the wide activation format int8 [M, K4]: per 32 channels 16 even then 16 odd codes, x 16."""
+    b = a4.view(torch.uint8).to(torch.int16)
+    even = ((b & 0xF) << 4).to(torch.uint8).view(torch.int8)       # channel 2i  -> byte i (two's complement nibble x 16)
+    odd = (b & 0xF0).to(torch.uint8).view(torch.int8)              # channel 2i+1
+    M = a4.shape[0]
+    return torch.stack([even.reshape(M, -1, 16), odd.reshape(M, -1, 16)], 2).reshape(M, -1).contiguous()
+
+
 def gemm_sets(M, N, K, R):
     """R operand sets sharing the activation side (a4, sA, a8, sA8) and the output; distinct weights."""
-    base = bench.make_operands(M, N, K, dev, seed=1)
+    base = list(bench.make_operands(M, N, K, dev, seed=1))
+    if WIDE:
+        base[0] = widen(base[0])
     sets = [base]
     for r in range(1, R):
         w = [torch.empty_like(base[i]).copy_(base[i]) for i in (1, 3, 5, 7)]     # b4, sB, b8, sB8: distinct memory, same values
@@ -77,7 +91,7 @@ def gemm_row(M, N, K, quiet=False):
 
     def mk(ops_):
         ptrs = [t.data_ptr() for t in ops_]
-        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN, ws.data_ptr(), wsb, st)
+        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | (L.A_WIDE if WIDE else 0), ws.data_ptr(), wsb, st)
     launchers = [mk(s) for s in sets]
     iters = max(64, 2 * R)
     iters -= iters % R
