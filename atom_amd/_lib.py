@@ -25,6 +25,7 @@ AB_F6 = 0x200              # ATOM_AB_F6
 O4_REF_EXTREMA = 0x800     # ATOM_O4_REF_EXTREMA
 B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
 WS_WEIGHT_CACHED = 0x1000  # ATOM_WS_WEIGHT_CACHED: the workspace already holds this weight's F6 form
+B_SCALE_PAIRS = 0x2000     # ATOM_B_SCALE_PAIRS: output channels 2j, 2j+1 share their weight scales (weight_channel_group = 2)
 Q_REORDER, Q_RMSNORM, Q_ADD_RMSNORM, Q_SILU_MUL = 1, 2, 3, 4     # atom_gemm_w4a4_multi_q: q_op
 F6_PITCH = 104
 

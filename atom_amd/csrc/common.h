@@ -83,6 +83,7 @@ struct GemmParams {
   int64_t ldA;      // halves between groups of sA
   int64_t f6_rows_a, f6_rows_b;   // F6 operand format: padded rows per group of A4 / B4 (gemm_w4a4_f6.hip)
   int o4_ref;                     // ATOM_O4_REF_EXTREMA: the u4 epilogue with the reference code's |x| extrema and 4-bit wrap
+  int b_pairs;                    // ATOM_B_SCALE_PAIRS: the caller asserts sB[g][2 j] == sB[g][2 j + 1] (weight_channel_group = 2)
   GateUpOut gu;                   // fused gate/up epilogue (launch_gemm_f6_gateup only)
   const float *sB32;              // ATOM_SB_F32: weight scales float32 [G][f6_rows_b] (then sB is not read by the 256x256 kernel)
   // atom_gemm_w4a4_multi (decode batches): the N output features are nseg segments of seg_n, each with its own [M, seg_n] output

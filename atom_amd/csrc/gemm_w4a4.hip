@@ -12,10 +12,12 @@
 //   gemm_w4a4_v2.hip   the 256x256 kernel with the asymmetric-u4 output epilogue (atom_gemm_w4a4_o4) and the
 //                      ablation switches behind profiles/r01_ablation_v1_v2.txt
 // Common design points: weights are the MFMA "A" operand and activations "B" (the accumulator tile is transposed, so a
-// lane owns ONE token m and 16 features n: the token scale is a lane scalar); per-group de-quantisation is 2 VALU per
-// accumulator element -- t = round_f32(idot * sA), c = fma(t, sB, c) -- with the INT8 kernels starting each group's
-// integer accumulator at the bit pattern of 1.5 * 2^23 so that the register READ AS A FLOAT is 12582912 + idot
-// (no int->float conversion); the 128 INT8 keeper columns run as two extra 64-wide steps through the same pipeline.
+// lane owns ONE token m and 16 features n: the token scale is a lane scalar); per-group de-quantisation is the reference's shape
+// (Dense_layer_gemm_i4_o16.cuh:413-431) -- s = sA * sB, exact in FP32; c = fma(idot, s, c), ONE rounding per group -- which is 1.5 VALU
+// per accumulator element in the BF6 headline kernel when the two channels of a weight_channel_group = 2 pair share the product
+// (ATOM_B_SCALE_PAIRS), 2 otherwise; the INT8 kernels start each group's integer accumulator at the bit pattern of 1.5 * 2^23 so that
+// the register READ AS A FLOAT is 12582912 + idot (one exact v_sub instead of an int->float conversion); the 128 INT8 keeper columns
+// run as two extra 64-wide steps through the same pipeline.
 #include "common.h"
 #include <cstdlib>
 
@@ -174,7 +176,8 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   const int a_wide = (scale_layout & ATOM_A_WIDE) != 0;
   const int f6 = (scale_layout & ATOM_AB_F6) != 0, f6s = (scale_layout & ATOM_B_F6S) != 0;
   p.o4_ref = (scale_layout & ATOM_O4_REF_EXTREMA) != 0;    // (only the _o4 entry points look at it)
-  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA | ATOM_WS_WEIGHT_CACHED);
+  p.b_pairs = (scale_layout & ATOM_B_SCALE_PAIRS) != 0;
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA | ATOM_WS_WEIGHT_CACHED | ATOM_B_SCALE_PAIRS);
   if ((a_wide && f6) || (f6s && !f6)) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
@@ -422,6 +425,8 @@ int atom_gemm_w4a4_silu_mul_quant_f6(const void *A_f6, const void *Bgu_f6s, cons
                                      void *outlier_scales, void *norm_scales, void *xq, void *stream) {
   if (!A_f6 || !Bgu_f6s || !A8 || !Bgu8 || !sA8 || !sBgu8 || !o_outliers || !o_norms_f6 || !outlier_scales || !norm_scales)
     return ATOM_ERR_INVALID_ARG;
+  const int b_pairs = (scale_layout & ATOM_B_SCALE_PAIRS) != 0;
+  scale_layout &= ~ATOM_B_SCALE_PAIRS;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (quant_mode != ATOM_QUANT_KERNEL && quant_mode != ATOM_QUANT_SIM) return ATOM_ERR_INVALID_ARG;
   if (!(clip > 0.f) || clip > 1.f) return ATOM_ERR_INVALID_ARG;
@@ -442,6 +447,7 @@ int atom_gemm_w4a4_silu_mul_quant_f6(const void *A_f6, const void *Bgu_f6s, cons
   p.K4h = (int)((K_total - kKeeper) / 2);
   p.G = (int)((K_total - kKeeper) / kGroup);
   p.ref_layout = scale_layout == ATOM_SCALE_LAYOUT_REF;
+  p.b_pairs = b_pairs;
   p.f6_rows_a = (M + 255) / 256 * 256;
   p.f6_rows_b = (N + 255) / 256 * 256;                       // == N: N_inter is a multiple of 128
   p.sB32 = reinterpret_cast<const float *>((const uint8_t *)Bgu_f6s + (size_t)p.G * (size_t)p.f6_rows_b * 104);

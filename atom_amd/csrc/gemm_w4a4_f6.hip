@@ -17,7 +17,7 @@
 // 2 x odd) makes the 32 rows of an MFMA fragment read (3 x ds_read_b64 of 24 bytes) hit 32 distinct bank pairs with no
 // swizzle.  The token scale is read from the row itself (no scale DMA, no scale region); weight scales keep their dense
 // fp16 array.  The INT8 keeper runs as the two 64-column half-steps of the INT8 kernel in the same stage buffer.
-// Arithmetic is the same contract: t = round_f32(idot * sA), c = fma(t, sB, c) per group in order, keeper last --
+// Arithmetic is the same contract: s = sA * sB (exact), c = fma(idot, s, c) per group in order, keeper last --
 // results are bit-identical to the INT8 kernels, except where two or four groups of waves share a tile (KG = 2 / 4, shapes of
 // at most 256 tiles): those sum consecutive ranges of the K steps and add the partial sums in order.
 //
@@ -157,21 +157,18 @@ __device__ __forceinline__ void dequant16(float (&acc)[16], float sa, const char
   v2u sbp[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + 16 * q);
-  // t = round_f32(idot * sA) for all 16 elements FIRST (in place, one block): a multiply followed directly by the FMA that
-  // reads it costs 3.2 cycles per instruction instead of 2 (dependent issue), which was 9 us of the 4096^3 launch
-#define M1(i) "v_mul_f32 %" #i ", %" #i ", %16\n"
-  // element 0 through the compiler: its hazard recogniser then places the MFMA->VALU wait states the asm block relies on
-  acc[0] *= sa;
-  asm volatile("" : "+v"(acc[0]));
-  asm volatile(M1(1) M1(2) M1(3) M1(4) M1(5) M1(6) M1(7) M1(8) M1(9) M1(10) M1(11) M1(12) M1(13) M1(14) M1(15)
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-                 "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
-               : "v"(sa));
-#undef M1
+  // the contract (round 5): s = sA * sB -- exact in FP32 --, c = fma(idot, s, c).  All 16 products FIRST, then the FMAs: a multiply
+  // followed directly by the FMA that reads it costs 3.2 cycles per instruction instead of 2 (dependent issue)
+  float sc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-    c[r] = __builtin_fmaf(acc[r], (float)hv[r & 3], c[r]);
+    sc[r] = (float)hv[r & 3] * sa;
+    asm volatile("" : "+v"(sc[r]));
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    c[r] = __builtin_fmaf(acc[r], sc[r], c[r]);
     asm volatile("" : "+v"(c[r]));
   }
 }
@@ -295,7 +292,6 @@ __device__ __forceinline__ void compute_keeper(const char *slot, const char *slo
     const v4i b2 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa0 + tm * 2048));
     const v4i b3 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(slot1 + oa1 + tm * 2048));
     const float sa = (float)*reinterpret_cast<const half_t *>(psa + tm * 128);
-    const float nms = -kMagic * sa;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       __builtin_amdgcn_sched_barrier(0);
@@ -312,8 +308,8 @@ __device__ __forceinline__ void compute_keeper(const char *slot, const char *slo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
-        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        const float idot = __int_as_float(a[r]) - kMagic;               // exact: the register read as a float is 12582912 + idot
+        c[tn][tm][r] = __builtin_fmaf(idot, (float)hv[r & 3] * sa, c[tn][tm][r]);
         asm volatile("" : "+v"(c[tn][tm][r]));
       }
     }
@@ -471,14 +467,58 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6_kernel(GemmParams 
 // (32 codes = 24 bytes at byte 24 * (l / 16) of the row); result: token l % 16, features 4 * (l / 16) + r.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
+// De-quantisation of a PAIR of micro-tiles (accumulators acc[0], acc[1]: exact integer dot products as floats) for one token scale.
+// The contract (include/atom_hip.h, round 5): s = sA * sB -- exact in FP32, both are fp16 values --, c = fma(idot, s, c): the
+// reference's dequant shape (Dense_layer_gemm_i4_o16.cuh:413-431: scale product first, then accu += c_frag * rs_scale).
+//   INTER = true  (fragment rows interleaved: row i of micro-tile k = feature 2 i + k): sb[2 r + k] is the scale of (k, r);
+//   INTER = false (plain rows: micro-tile k holds 16 consecutive features): sb[4 k + r];
+//   PAIR  = the caller asserts that output channels 2 j, 2 j + 1 share their weight scale (weight_channel_group = 2, ATOM_B_SCALE_PAIRS:
+//           what the reference kernel requires -- it applies ONE product to both columns of a pair, :419-431): with interleaved rows
+//           the two micro-tiles then share all four products -- 4 multiplies + 8 FMAs instead of 8 + 8 -- and sb holds the four
+//           distinct scales only (sb[r] = channels 2 r, 2 r + 1 of the lane's eight).
+// All products first, then the FMAs: a multiply followed directly by the FMA that reads it issues at 3.2 cycles instead of 2.
+template <bool PAIR, bool INTER = true>
+__device__ __forceinline__ void deq_pair(const v4f_t &a0, const v4f_t &a1, float sa, const float *sb, float (&c0)[4], float (&c1)[4]) {
+  if constexpr (PAIR) {
+    static_assert(INTER, "shared products need the interleaved rows");
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = sa * sb[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = __builtin_fmaf(a0[r], s[r], c0[r]); asm volatile("" : "+v"(c0[r])); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c1[r] = __builtin_fmaf(a1[r], s[r], c1[r]); asm volatile("" : "+v"(c1[r])); }
+  } else if constexpr (INTER) {
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[4 * k + r] = sa * sb[2 * r + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = __builtin_fmaf(a0[r], s[r], c0[r]); asm volatile("" : "+v"(c0[r])); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c1[r] = __builtin_fmaf(a1[r], s[4 + r], c1[r]); asm volatile("" : "+v"(c1[r])); }
+  } else {                                                 // (128-register geometries: one micro-tile's four products at a time)
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = sa * sb[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = __builtin_fmaf(a0[r], s[r], c0[r]); asm volatile("" : "+v"(c0[r])); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = sa * sb[4 + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c1[r] = __builtin_fmaf(a1[r], s[r], c1[r]); asm volatile("" : "+v"(c1[r])); }
+  }
+}
+
 __device__ __forceinline__ void dequant4x(const v4f_t &acc, float sa, const v2u &sb, float (&c)[4]) {
   const half_t *hv = reinterpret_cast<const half_t *>(&sb);
   float t[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) t[r] = acc[r] * sa;
+  for (int r = 0; r < 4; ++r) t[r] = (float)hv[r] * sa;                    // the exact scale products
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    c[r] = __builtin_fmaf(t[r], (float)hv[r], c[r]);
+    c[r] = __builtin_fmaf(acc[r], t[r], c[r]);
     asm volatile("" : "+v"(c[r]));
   }
 }
@@ -566,22 +606,15 @@ __device__ __forceinline__ void compute_int4_x16(const char *slot, int wm, int w
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-      float t[4 * GS];
+      float w[4 * GS];                                       // plain rows: micro-tile k = features 16 (f0 + k) + 4 kb + r
 #pragma unroll
       for (int k = 0; k < GS; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[4 * k + r] = acc[g % (DEPTH + 1)][k][r] * sa;
-#pragma unroll
-      for (int k = 0; k < GS; ++k) {
-#pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float w;
-          if constexpr (C::FS) w = sb[f0 + k][r];
-          else w = (float)reinterpret_cast<const half_t *>(&sb[f0 + k])[r];
-          c[f0 + k][tb][r] = __builtin_fmaf(t[4 * k + r], w, c[f0 + k][tb][r]);
-          asm volatile("" : "+v"(c[f0 + k][tb][r]));
+          if constexpr (C::FS) w[4 * k + r] = sb[f0 + k][r];
+          else w[4 * k + r] = (float)reinterpret_cast<const half_t *>(&sb[f0 + k])[r];
         }
-      }
+      deq_pair<false, false>(acc[g % (DEPTH + 1)][0], acc[g % (DEPTH + 1)][1], sa, w, c[f0][tb], c[f0 + 1][tb]);
     }
   }
 }
@@ -1057,19 +1090,7 @@ __device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char
       asm volatile("" : "+v"(c[2 * dh][dtb][0]) : "v"(R.acc[j & 1][0]), "v"(R.acc[j & 1][1]));
     } else {
       const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
-      const float sa = R.sa[dtb];
-      float t[8];
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[2 * dh + k][r], c[2 * dh + k][dtb][r]);
-          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
-        }
+      deq_pair<false, false>(R.acc[j & 1][0], R.acc[j & 1][1], R.sa[dtb], &R.sb[2 * dh][0], c[2 * dh][dtb], c[2 * dh + 1][dtb]);   // sb[2 dh + k][r]
     }
     // the next stage's weight scales replace a pair's FP32 copies once its last de-quantisation of this step is done:
     // pair 0 (slot 13 = block 7) after slot 14's de-quantisation, pair 1 after the carried one in the next step's slot 0
@@ -1084,11 +1105,7 @@ __device__ __forceinline__ void p_step(PRegs<C> &R, const char *slot, const char
 // the carried pair (slot 15) of the last int4 step
 template <class C>
 __device__ __forceinline__ void p_drain(PRegs<C> &R, float (&c)[4][8][4]) {
-  const float sa = R.sa[7];
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[2 + k][r], c[2 + k][7][r]);
+  deq_pair<false, false>(R.acc[1][0], R.acc[1][1], R.sa[7], &R.sb[2][0], c[2][7], c[3][7]);
 }
 
 // the keeper on v_mfma_i32_16x16x64_i8 with the interleaved row mapping: both 64-column halves (two stage slots) in one step, two
@@ -1124,8 +1141,7 @@ __device__ __forceinline__ void p_keeper(const char *slot, const char *slot1, in
       const half_t *hv = reinterpret_cast<const half_t *>(&sbp[fb >> 1]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = (float)a[r] * sa;
-        c[fb][tb][r] = __builtin_fmaf(t, (float)hv[2 * r + (fb & 1)], c[fb][tb][r]);
+        c[fb][tb][r] = __builtin_fmaf((float)a[r], (float)hv[2 * r + (fb & 1)] * sa, c[fb][tb][r]);
         asm volatile("" : "+v"(c[fb][tb][r]));
       }
     }
@@ -1314,11 +1330,11 @@ struct QC {
   static_assert(LDS_BYTES <= 160 * 1024 && STAGE + (32 * 3 + 1) * PITCH + 100 < 65536, "q kernel: stage layout / ds offsets");
 };
 
-template <class C>
+template <class C, bool PAIR = false>
 struct QRegs {
   v8i af[4];            // feature fragments of the current stage
   v8i bf[3];            // token fragments: [2] block 0, [0] blocks 2,4,6, [1] odd blocks
-  float sb[2][8];       // weight scales of feature-block pair h: [h][2 r + (fb & 1)]
+  float sb[2][PAIR ? 4 : 8];   // weight scales of feature-block pair h: [h][2 r + (fb & 1)]; PAIR (channels 2 j, 2 j + 1 share theirs): [h][r]
   float sa[4];          // token scales, ring by token block % 4
   v4f_t acc[2][2];
   // lane byte addresses in LDS, [set][piece]: set 0 serves stage slots 0 and 1 (+ instruction offset), set 1 = + 2 stages for
@@ -1348,9 +1364,15 @@ __device__ __forceinline__ float q_scale(const char *lds, const RG &R, int off, 
 template <class C, int SL, class RG>
 __device__ __forceinline__ void q_load_sb(const char *lds, RG &R, int h, int ro) {   // 8 consecutive features of pair h
   const char *b = lds + (SL < 0 ? ro : q_imm<C, SL>()) + QC<C>::SB_OFF + 128 * h + R.aB[q_set<SL>()];
-  const v4f_t lo = *reinterpret_cast<const v4f_t *>(b), hi = *reinterpret_cast<const v4f_t *>(b + 16);
+  if constexpr (sizeof(R.sb[0]) == 4 * sizeof(float)) {    // PAIR: the even ones (two ds_read2_b32 with dword offsets 0, 2)
+    const float *f = reinterpret_cast<const float *>(b);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { R.sb[h][k] = lo[k]; R.sb[h][4 + k] = hi[k]; }
+    for (int k = 0; k < 4; ++k) R.sb[h][k] = f[2 * k];
+  } else {
+    const v4f_t lo = *reinterpret_cast<const v4f_t *>(b), hi = *reinterpret_cast<const v4f_t *>(b + 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { R.sb[h][k] = lo[k]; R.sb[h][4 + k] = hi[k]; }
+  }
 }
 
 // LDS-DMA through SGPR base + lane offset + instruction offset (which also moves the LDS destination): three consecutive 1 KiB
@@ -1384,8 +1406,8 @@ __device__ __forceinline__ void q_piece(const QDma &d, const uint8_t *wsrc, cons
 // behind the MFMAs of slots 8..15.
 struct QNoEarly { __device__ __forceinline__ void operator()(int) const {} };
 // `early(i)`, i = 0..7: behind the MFMAs of slots 0..7 (step 0 issues the LDS-DMA of stage 1 there; published by the same mid-step barrier)
-template <class C, int SL, class FS, class FD, class FE = QNoEarly>
-__device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[4][8][4], FS sync, FD mid, int ro = 0, int rn = 0,
+template <class C, int SL, bool PAIR, class FS, class FD, class FE = QNoEarly>
+__device__ __forceinline__ void q_step(QRegs<C, PAIR> &R, const char *lds, float (&c)[4][8][4], FS sync, FD mid, int ro = 0, int rn = 0,
                                        bool LAST = false, FE early = FE()) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
   constexpr int NX = SL < 0 ? -1 : (SL + 1) % 3;
 #pragma unroll
@@ -1425,19 +1447,7 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
     // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
     {
       const int j = (i + 15) & 15, dtb = p_tb(j), dh = p_h(j);
-      const float sa = R.sa[dtb & 3];
-      float t[8];
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[dh][2 * r + k], c[2 * dh + k][dtb][r]);
-          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
-        }
+      deq_pair<PAIR>(R.acc[j & 1][0], R.acc[j & 1][1], R.sa[dtb & 3], R.sb[dh], c[2 * dh][dtb], c[2 * dh + 1][dtb]);
     }
     // weight scales: pair 0's registers die with slot 13's de-quantisation (done in slot 14) and take the next stage's values;
     // pair 1's die with the carried pair (slot 15, done in the next step's slot 0) and take the current stage's
@@ -1454,8 +1464,8 @@ __device__ __forceinline__ void q_step(QRegs<C> &R, const char *lds, float (&c)[
 //  * pair slots as in q_step -- the four INT8 MFMAs of slot i (two micro-tiles x two chained halves) are issued before the
 //    de-quantisation of slot i - 1;
 //  * the accumulator starts at the bit pattern of 1.5 * 2^23 (the MFMA's C operand), so that the register read as a float is
-//    12582912 + idot exactly and t = fma(acc, sA8, -12582912 * sA8) IS round_f32(idot * sA8) (the INT8 tile kernel's trick,
-//    gemm_w4a4_v2.hip): no v_cvt_f32_i32, and the 8 + 8 VALU of an int4 pair;
+//    12582912 + idot exactly: one v_sub per element instead of the quarter-rate v_cvt_f32_i32 (rounds 3-4 folded it into
+//    t = fma(acc, sA8, -12582912 * sA8); the round-5 contract multiplies the SCALES first, see deq_pair);
 //  * the weight scales are converted to FP32 once, the token fragments of block tb + 2 are requested behind the last MFMA that reads
 //    block tb's;
 //  * STORE (plain fp16 output): a token block's 64 x 16 outputs are final once its pair h = 1 is de-quantised;
@@ -1475,7 +1485,7 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
   v4i af[4], bf[2];
   v4i af1[4], bf1[2];                                      // the second half's fragments (slot1)
   const long d1 = slot1 - slot;
-  float sb[2][8], sa[2], nms[2];
+  float sb[2][8], sa[2];
   v4i acc[2][2];
   const v4i magic = {kMagicBits, kMagicBits, kMagicBits, kMagicBits};
 #pragma unroll
@@ -1517,27 +1527,18 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
   };
   auto dequant = [&](int j) {                                          // pair slot j: token block j / 2, feature-block pair j % 2
     const int tb = j >> 1, h = j & 1;
-    float t[8];
+    v4f_t f[2];                                                        // the register read as a float is 12582912 + idot: idot exactly
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[4 * k + r] = __builtin_fmaf(__int_as_float(acc[j & 1][k][r]), sa[tb & 1], nms[tb & 1]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        c[2 * h + k][tb][r] = __builtin_fmaf(t[4 * k + r], sb[h][2 * r + k], c[2 * h + k][tb][r]);
-        asm volatile("" : "+v"(c[2 * h + k][tb][r]));
-      }
+      for (int r = 0; r < 4; ++r) f[k][r] = __int_as_float(acc[j & 1][k][r]) - kMagic;
+    deq_pair<false>(f[0], f[1], sa[tb & 1], sb[h], c[2 * h][tb], c[2 * h + 1][tb]);   // (the keeper's scales are per output channel, not per pair: model/qLinearLayer.py:59)
   };
 #pragma unroll
   for (int i = 0; i < 2 * NTB; ++i) {
     const int tb = i >> 1, h = i & 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (h == 0) {                                                      // this block's token scale arrived with its fragment
-      sa[tb & 1] = (float)sah[tb & 1];
-      nms[tb & 1] = -kMagic * sa[tb & 1];
-    }
+    if (h == 0) sa[tb & 1] = (float)sah[tb & 1];                       // this block's token scale arrived with its fragment
 #pragma unroll
     for (int k = 0; k < 2; ++k) acc[i & 1][k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2 * h + k], bf[tb & 1], magic, 0, 0, 0);
     if constexpr (MERGED) {
@@ -1566,7 +1567,9 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
 // kernels').  Bit-identical to fp16 GEMMs + atom_silu_mul_quant_f16; saves writing and re-reading 2 x M x N_inter fp16.
 // TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
 // [0..15] kernel phases, [16 + s] start of K step s, [62], [63] s_memrealtime (100 MHz) at entry and exit
-template <class C, int GU = 0, bool TR = false>
+// PAIR: the caller asserts that output channels 2 j, 2 j + 1 share their weight scales (ATOM_B_SCALE_PAIRS: weight_channel_group = 2,
+// the only form the reference kernel accepts): 6 instead of 8 de-quantisation VALU per MFMA (deq_pair), half the scale registers.
+template <class C, int GU = 0, bool TR = false, bool PAIR = false>
 __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(C::BM == 256 && C::BN == 256 && C::WM == 128 && C::NS == 3 && C::NW == 8, "q kernel: 256x256, 8 waves of 64 x 128");
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   kstamp(2);
 
   const int l15 = lane & 15, kb = lane >> 4;
-  QRegs<C> R;
+  QRegs<C, PAIR> R;
   {
     const int lw = wn * 64 * PITCH + l15 * (2 * PITCH) + kb * 24;
     const int la = C::A_OFF + wm * 128 * PITCH + l15 * (2 * PITCH);
@@ -1686,7 +1689,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     const int g = s + 2;
     const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
     const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
-    q_step<C, SL>(R, lds, c, sync, [&](int i) { q_piece<C, (SL + 2) % 3>(d, wsrc, asrc, sbsrc, i); });
+    q_step<C, SL, PAIR>(R, lds, c, sync, [&](int i) { q_piece<C, (SL + 2) % 3>(d, wsrc, asrc, sbsrc, i); });
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -1696,7 +1699,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     if constexpr (TR) kstamp(16);
     const uint8_t *wsrc = wsrc0 + 2 * wstep, *asrc = asrc0 + 2 * astep;
     const float *sbsrc = sbsrc0 + (int64_t)2 * p.f6_rows_b;
-    q_step<C, 0>(R, lds, c, sync, [&](int i) { q_piece<C, 2>(d, wsrc, asrc, sbsrc, i); }, 0, 0, false,
+    q_step<C, 0, PAIR>(R, lds, c, sync, [&](int i) { q_piece<C, 2>(d, wsrc, asrc, sbsrc, i); }, 0, 0, false,
                  [&](int i) { q_piece<C, 1>(d, wsrc0 + wstep, asrc0 + astep, sbsrc0 + p.f6_rows_b, i); });
     reg(S1(), 1);
     reg(S2(), 2);
@@ -1713,7 +1716,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     const int dsl = g % 3;
     const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
     const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
-    q_step<C, -1>(R, lds, c, sync,
+    q_step<C, -1, PAIR>(R, lds, c, sync,
                   [&](int i) {
                     if (g < G) {
                       if (dsl == 0) q_piece<C, 0>(d, wsrc, asrc, sbsrc, i);
@@ -1723,13 +1726,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
                   },
                   (s % 3) * Q::STAGE, ((s + 1) % 3) * Q::STAGE, s + 1 == G);
   }
-  {                                                         // the carried pair (slot 15) of the last int4 step
-    const float sa = R.sa[3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[2 + k][7][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][7][r]);
-  }
+  deq_pair<PAIR>(R.acc[1][0], R.acc[1][1], R.sa[3], R.sb[1], c[2][7], c[3][7]);   // the carried pair (slot 15) of the last int4 step
   // keeper half 0 was published by the last mid-step barrier; half 1 was issued behind it: ONE step over both once it has landed
   kstamp(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1830,12 +1827,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   }
 }
 
-template <class C, int GU = 0, bool TR = false>
+template <class C, int GU = 0, bool TR = false, bool PAIR = false>
 static int launch_q(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C, GU, TR>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6q_kernel<C, GU, TR, PAIR>), QC<C>::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   const int nbm = (p.M + C::BM - 1) / C::BM, nbn = (p.N + C::BN - 1) / C::BN;
-  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C, GU, TR>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_w4a4_f6q_kernel<C, GU, TR, PAIR>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), QC<C>::LDS_BYTES, s, p);
   return check_launch();
 }
 
@@ -1924,21 +1921,7 @@ __device__ __forceinline__ void qk_step(QkRegs<C> &R, const char *lds, float (&c
     else early(i);
     __builtin_amdgcn_sched_barrier(0);
     const int j = (i + 7) & 7, dtb = j & 3, dh = j >> 2;      // de-quantisation of the previous slot's pair (i == 0: the carried one)
-    if constexpr (!(ABL & 2)) {
-      const float sa = R.sa[dtb];
-      float t[8];
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[4 * k + r] = R.acc[j & 1][k][r] * sa;
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          c[2 * dh + k][dtb][r] = __builtin_fmaf(t[4 * k + r], R.sb[dh][2 * r + k], c[2 * dh + k][dtb][r]);
-          asm volatile("" : "+v"(c[2 * dh + k][dtb][r]));
-        }
-    }
+    if constexpr (!(ABL & 2)) deq_pair<false>(R.acc[j & 1][0], R.acc[j & 1][1], R.sa[dtb], R.sb[dh], c[2 * dh][dtb], c[2 * dh + 1][dtb]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(ABL & 8)) {                              // scales whose last reader was that de-quantisation
       if (i == 0) {
@@ -2112,13 +2095,7 @@ __global__ __launch_bounds__(C::NT * 2, 2) void gemm_w4a4_f6qk_kernel(GemmParams
                         },
                         (t % 3) * Q::STAGE, ((t + 1) % 3) * Q::STAGE, t + 1 == n4);
   }
-  {                                                         // the carried pair (last slot) of the last int4 step
-    const float sa = R.sa[3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[2 + k][NTB - 1][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][NTB - 1][r]);
-  }
+  deq_pair<false>(R.acc[1][0], R.acc[1][1], R.sa[3], R.sb[1], c[2][NTB - 1], c[3][NTB - 1]);   // the carried pair (last slot) of the last int4 step
   int nbar = 1 + ((ABL & 16) ? 0 : n4);
   kstamp(4);
   if (has_keeper) {                                         // half 0 was published by the last mid-step barrier; half 1 was issued behind it
@@ -2349,13 +2326,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_w4a4_f6q2_kernel(GemmParams p) 
                    },
                    (s % 3) * Q::STAGE, ((s + 1) % 3) * Q::STAGE, s + 1 == G);
   }
-  {                                                         // the carried pair (last slot) of the last int4 step
-    const float sa = R.sa[3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[2 + k][3][r] = __builtin_fmaf(R.acc[1][k][r] * sa, R.sb[1][2 * r + k], c[2 + k][3][r]);
-  }
+  deq_pair<false>(R.acc[1][0], R.acc[1][1], R.sa[3], R.sb[1], c[2][3], c[3][3]);   // the carried pair (last slot) of the last int4 step
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   q_keeper<C, true>(p, slot_of(G), slot_of(G + 1), wm, wn, lane, c, m0, n0);
@@ -2417,7 +2388,9 @@ static int launch(const GemmParams &p, hipStream_t s) {
 }  // namespace f6
 
 int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s) {
-  return sim ? f6::launch_q<f6::Cfg<256, 256, 4, 3>, 1>(p, s) : f6::launch_q<f6::Cfg<256, 256, 4, 3>, 2>(p, s);
+  using C = f6::Cfg<256, 256, 4, 3>;
+  if (p.b_pairs) return sim ? f6::launch_q<C, 1, false, true>(p, s) : f6::launch_q<C, 2, false, true>(p, s);
+  return sim ? f6::launch_q<C, 1>(p, s) : f6::launch_q<C, 2>(p, s);
 }
 
 // cfg: 0 = 256x256 (8 waves, the pipelined kernel) and 3 = 128x128 (4 waves, three workgroups per CU) on 16x16x128 MFMA
@@ -2542,7 +2515,8 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   }
 #endif
   if (!p.sB32 || cfg == 30) return f6::launch_p<f6::Cfg<256, 256, 4, 3>>(p, s);   // 256x256, pipelined across K steps (fp16 weight scales; cfg 30: tuning)
-  return f6::launch_q<f6::Cfg<256, 256, 4, 3>>(p, s);                          // ... third generation (ATOM_B_F6S; the headline)
+  if (p.b_pairs) return f6::launch_q<f6::Cfg<256, 256, 4, 3>, 0, false, true>(p, s);   // ... third generation (ATOM_B_F6S; the headline), shared scale products
+  return f6::launch_q<f6::Cfg<256, 256, 4, 3>>(p, s);                          // ... the same for weights whose channel pairs have their own scales
 }
 
 }  // namespace atom

@@ -12,7 +12,7 @@
 //     the same permutation of k on both operands, so two MFMAs give 256 * (the group's integer dot), exactly;
 //   * token blocks of 16 (up to 16) re-use the weight registers; a block's activation chunks come from L2 and are
 //     re-filled in place for the next block as soon as they have been widened;
-//   * per group and 16x16 tile: t = round_f32(idot * sA[m,g]), c = fma(t, sB[g,n], c) -- the contract of
+//   * per group and 16x16 tile: c = fma(idot, sA[m,g] * sB[g,n], c), the scale product exact -- the contract of
 //     include/atom_hip.h; the partial sums of the 8 waves are added in wave order through LDS (the FP32 summation ORDER
 //     therefore differs from the prefill kernels, like the decode kernel's; all are within 1 fp16 ulp of the exact value).
 // Round 3, what did NOT help for 32..256 tokens (profiles/r03_decode.txt): every block of a workgroup requested up front instead of
@@ -47,14 +47,15 @@ __device__ __forceinline__ v4i odd_codes(v4u x) {        // high nibbles -> int8
   return v4i{(int)(x.x & 0xF0F0F0F0u), (int)(x.y & 0xF0F0F0F0u), (int)(x.z & 0xF0F0F0F0u), (int)(x.w & 0xF0F0F0F0u)};
 }
 
-// c[r] += round_f32(idot[r] * sa) * sb[r], r = the lane's 4 features
+// c[r] = fma(idot[r], sa * sb[r], c[r]), r = the lane's 4 features: the contract of include/atom_hip.h (round 5) -- the scale product
+// is exact in FP32 (two fp16 values; the 1/256 of the widened operands folded into sa is a power of two), one rounding per group
 __device__ __forceinline__ void dequant4(const v4i &acc, float sa, const v2u &sb, float (&c)[4]) {
   const half_t *hv = reinterpret_cast<const half_t *>(&sb);
   float t[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) t[r] = (float)acc[r] * sa;
+  for (int r = 0; r < 4; ++r) t[r] = (float)hv[r] * sa;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], (float)hv[r], c[r]);
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf((float)acc[r], t[r], c[r]);
 }
 
 // fused quantiser (QOP): byte offset of red[4] (then the row buffer) behind the packed operand of MQ = 2 rows in LDS

@@ -17,9 +17,10 @@
 //  * int4 -> int8 widening in registers ((v<<4)&0xF0F0F0F0, v&0xF0F0F0F0; even/odd k split on both operands);
 //  * the integer accumulator of a 32x32 tile lives only for the 4 MFMAs of one K-group (one 16-register
 //    temporary instead of a per-tile int32 accumulator), so the FP32 running sums (128 registers) fit; dequant is
-//    2 VALU ops/element (magic-number trick; the weight scale is consumed as fp16 by v_fma_mix_f32).
+//    3 VALU ops/element since round 5 (magic-number trick: idot = acc - 1.5 * 2^23 exactly; scale product; FMA -- rounds 1-4
+//    folded the token scale into the magic fma, 2 ops/element, under the contract that rounded twice per group).
 //
-// Arithmetic contract (include/atom_hip.h): per int4 group  t = round_f32(idot*sA[m,g]); c = fma(t, sB[g,n], c);
+// Arithmetic contract (include/atom_hip.h): per int4 group  s = sA[m,g] * sB[g,n] (exact in FP32); c = fma(idot, s, c);
 // the 128 INT8 keeper columns arrive as two 64-column stages and are multiplied in one step (one de-quantisation).
 #include "common.h"
 
@@ -172,7 +173,6 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
     const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
     if (tm + 1 < TM) request(tm + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const float nms = -kMagic * sa;             // exact: 3*2^22 times an 11-bit significand
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       // one tile at a time: 4 chained MFMAs, then its dequant.  The fence keeps the scheduler from interleaving the
@@ -202,8 +202,8 @@ __device__ __forceinline__ void compute_step(const char *slot, int wm, int wn, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
-        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        const float idot = __int_as_float(a[r]) - kMagic;       // exact (the register read as a float is 12582912 + idot)
+        c[tn][tm][r] = __builtin_fmaf(idot, (float)hv[r & 3] * sa, c[tn][tm][r]);   // the contract: exact scale product, one rounding
         // pin the update HERE: otherwise LLVM defers all 128 second-stage FMAs of a step to its end and keeps 128
         // temporaries alive (measured: 180 spilled VGPRs)
         asm volatile("" : "+v"(c[tn][tm][r]));
@@ -236,7 +236,6 @@ __device__ __forceinline__ void compute_keeper(const char *slot0, const char *sl
     load_frag<false, 0>(slot0, 256 + ml, h, b0);
     load_frag<false, 0>(slot1, 256 + ml, h, b1);
     const float sa = (float)*reinterpret_cast<const half_t *>(slot0 + SA_OFF + ml * 4);
-    const float nms = -kMagic * sa;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       __builtin_amdgcn_sched_barrier(0);
@@ -251,8 +250,8 @@ __device__ __forceinline__ void compute_keeper(const char *slot0, const char *sl
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-        const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
-        c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+        const float idot = __int_as_float(a[r]) - kMagic;       // exact (the register read as a float is 12582912 + idot)
+        c[tn][tm][r] = __builtin_fmaf(idot, (float)hv[r & 3] * sa, c[tn][tm][r]);   // the contract: exact scale product, one rounding
         asm volatile("" : "+v"(c[tn][tm][r]));
       }
     }
@@ -278,7 +277,7 @@ __device__ __forceinline__ void compute_step_pp(const char *slot, int wm, int wn
     for (int s = 1; s < KS; ++s) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[tn][s], bf[s], a, 0, 0, 0);
     return a;
   };
-  auto dequant = [&](const v16i &a, int tn, int tm, float sa, float nms) {
+  auto dequant = [&](const v16i &a, int tn, int tm, float sa) {
     v2u sbp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -286,33 +285,32 @@ __device__ __forceinline__ void compute_step_pp(const char *slot, int wm, int wn
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-      const float t = __builtin_fmaf(__int_as_float(a[r]), sa, nms);
-      c[tn][tm][r] = __builtin_fmaf(t, (float)hv[r & 3], c[tn][tm][r]);
+      const float idot = __int_as_float(a[r]) - kMagic;
+      c[tn][tm][r] = __builtin_fmaf(idot, (float)hv[r & 3] * sa, c[tn][tm][r]);
       asm volatile("" : "+v"(c[tn][tm][r]));
     }
   };
 
   v16i a_prev;
-  float sa_prev = 0.f, nms_prev = 0.f;
+  float sa_prev = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int ml = wm * 128 + tm * 32 + l31;
     v4i bf[4];
     load_frag<INT4, 0>(slot, 256 + ml, h, bf);
     const float sa = (float)*reinterpret_cast<const half_t *>(slot + SA_OFF + ml * 4) * (INT4 ? (1.0f / 256.0f) : 1.0f);
-    const float nms = -kMagic * sa;
     __builtin_amdgcn_sched_barrier(0);
     v16i a0 = chain(bf, 0);                       // tile (tm, 0) in flight ...
     __builtin_amdgcn_sched_barrier(0);
-    if (tm > 0) dequant(a_prev, 1, tm - 1, sa_prev, nms_prev);     // ... while tile (tm-1, 1) is dequantised
+    if (tm > 0) dequant(a_prev, 1, tm - 1, sa_prev);     // ... while tile (tm-1, 1) is dequantised
     __builtin_amdgcn_sched_barrier(0);
     v16i a1 = chain(bf, 1);                       // tile (tm, 1) in flight ...
     __builtin_amdgcn_sched_barrier(0);
-    dequant(a0, 0, tm, sa, nms);                  // ... while tile (tm, 0) is dequantised
+    dequant(a0, 0, tm, sa);                  // ... while tile (tm, 0) is dequantised
     __builtin_amdgcn_sched_barrier(0);
-    a_prev = a1; sa_prev = sa; nms_prev = nms;
+    a_prev = a1; sa_prev = sa;
   }
-  dequant(a_prev, 1, TM - 1, sa_prev, nms_prev);
+  dequant(a_prev, 1, TM - 1, sa_prev);
 }
 
 template <int NS, int ABL = 0, bool O4 = false>

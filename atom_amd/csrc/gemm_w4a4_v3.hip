@@ -179,27 +179,26 @@ __device__ __forceinline__ void load_frag(const char *p0, const char *p1, v4i (&
   }
 }
 
-// De-quantise one 32x32 tile: acc holds the magic-biased FP32 image of the integer dot products.  All 16
-// t = round_f32(idot * sA) first, in place, as one block, then the 16 FMAs by the weight scales: a multiply followed
-// directly by the FMA that reads it issues at 3.2 cycles per instruction instead of 2 (see gemm_w4a4_f6.hip).
-__device__ __forceinline__ void dequant16_magic(const v16i &a, float sa, float nms, const v2u (&sbp)[4], float (&c)[16]) {
-  float t[16];
+// De-quantise one 32x32 tile: acc holds the magic-biased FP32 image of the integer dot products -- the register read as a float is
+// 12582912 + idot exactly, so idot = acc - 12582912 is one exact v_sub (no quarter-rate v_cvt_f32_i32).  The contract (round 5,
+// include/atom_hip.h): s = sA * sB -- exact in FP32 --, c = fma(idot, s, c).  (Rounds 1-4: t = fma(acc, sA, -12582912 sA), c = fma(t, sB, c)
+// -- 2 instead of 3 instructions per element here, but two roundings and no shared scale product for the BF6 kernels the library
+// ships as its fast path; this INT8 kernel serves the plain entry point only.)  Four elements at a time: the wave tile leaves no
+// registers for 16 products.
+__device__ __forceinline__ void dequant16_magic(const v16i &a, float sa, const v2u (&sbp)[4], float (&c)[16]) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = __int_as_float(a[r]);
-  // element 0 through the compiler: its hazard recogniser then places the MFMA->VALU wait states the asm block relies on
-  t[0] = __builtin_fmaf(t[0], sa, nms);
-  asm volatile("" : "+v"(t[0]));
-#define M1(i) "v_fma_f32 %" #i ", %" #i ", %16, %17\n"
-  asm volatile(M1(1) M1(2) M1(3) M1(4) M1(5) M1(6) M1(7) M1(8) M1(9) M1(10) M1(11) M1(12) M1(13) M1(14) M1(15)
-               : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
-                 "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
-               : "v"(sa), "v"(nms));
-#undef M1
+  for (int q = 0; q < 4; ++q) {
+    const half_t *hv = reinterpret_cast<const half_t *>(&sbp[q]);
+    float s[4], t[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const half_t *hv = reinterpret_cast<const half_t *>(&sbp[r >> 2]);
-    c[r] = __builtin_fmaf(t[r], (float)hv[r & 3], c[r]);
-    asm volatile("" : "+v"(c[r]));
+    for (int r = 0; r < 4; ++r) s[r] = (float)hv[r] * sa;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = __int_as_float(a[4 * q + r]) - kMagic;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c[4 * q + r] = __builtin_fmaf(t[r], s[r], c[4 * q + r]);
+      asm volatile("" : "+v"(c[4 * q + r]));
+    }
   }
 }
 
@@ -234,7 +233,6 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
       __builtin_amdgcn_sched_barrier(0);
       const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
       if (tm + 1 < TM) sah = *reinterpret_cast<const half_t *>(psa + (tm + 1) * 128);
-      const float nms = -kMagic * sa;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         __builtin_amdgcn_sched_barrier(0);
@@ -251,7 +249,7 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
-        dequant16_magic(a, sa, nms, sbp, c[tn][tm]);
+        dequant16_magic(a, sa, sbp, c[tn][tm]);
       }
     }
     return;
@@ -278,7 +276,6 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
     const float sa = (float)sah * (INT4 ? (1.0f / 256.0f) : 1.0f);
     if (tm + 1 < TM) request(tm + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const float nms = -kMagic * sa;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +286,7 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
-      dequant16_magic(a, sa, nms, sbp, c[tn][tm]);
+      dequant16_magic(a, sa, sbp, c[tn][tm]);
     }
   }
 }
@@ -333,7 +330,6 @@ __device__ __forceinline__ void compute_keeper(const char *slot0, const char *sl
     const float sa = (float)sah;
     if (tm + 1 < TM) request(tm + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const float nms = -kMagic * sa;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +340,7 @@ __device__ __forceinline__ void compute_keeper(const char *slot0, const char *sl
       v2u sbp[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
-      dequant16_magic(a, sa, nms, sbp, c[tn][tm]);
+      dequant16_magic(a, sa, sbp, c[tn][tm]);
     }
   }
 }

@@ -9,7 +9,7 @@
 //     keeper on v_dot4_i32_i8;
 //   * the (at most 16) activation rows live in LDS (34 KB at K=4096), read with conflict-free ds_read_b128;
 //   * a quantisation group is 4 consecutive chunks = 4 consecutive lanes: integer partials are combined exactly with
-//     two DPP xor-adds, the quad leader applies  t = round_f32(idot*sA[m,g]); c = fma(t, sB[g,n], c);  per-lane sums
+//     two DPP xor-adds, the quad leader applies  c = fma(idot, sA[m,g]*sB[g,n], c) (the scale product is exact);  per-lane sums
 //     are then reduced with a 6-step butterfly, keeper added last (FP32 summation ORDER therefore differs from the
 //     prefill kernel; both are within 1 fp16 ulp of the exact value).
 //   * grid: up to 1024 waves (4 per workgroup) round-robin over the N rows.
@@ -79,8 +79,7 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
         }
         d = quad_sum(d);                                // exact: the group's 128-element integer dot
         if (ok && (lane & 3) == 0) {
-          const float t = (float)d * sAl[m * (G + 1) + g];
-          acc[m] = __builtin_fmaf(t, sb, acc[m]);
+          acc[m] = __builtin_fmaf((float)d, sAl[m * (G + 1) + g] * sb, acc[m]);   // the contract: exact scale product, one rounding
         }
       }
     }
@@ -104,8 +103,7 @@ __global__ __launch_bounds__(256) void gemv_w4a4_kernel(GemmParams p) {
         float s = acc[m];
         s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
         if (lane == 0 && m < p.M) {
-          const float t = (float)d * sAl[m * (G + 1) + G];
-          p.D[(int64_t)m * p.N + n] = f2h(__builtin_fmaf(t, sb8, s));
+          p.D[(int64_t)m * p.N + n] = f2h(__builtin_fmaf((float)d, sAl[m * (G + 1) + G] * sb8, s));
         }
       }
     }
@@ -202,8 +200,7 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
         d = __builtin_amdgcn_sdot8(a[m][2], w[r][2], d, false);
         d = __builtin_amdgcn_sdot8(a[m][3], w[r][3], d, false);
         d = quad_sum(d);                                    // exact: the group's 128-element integer dot
-        const float t = (float)d * saf;
-        const float next = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sbu[r]), acc[r][m]);
+        const float next = __builtin_fmaf((float)d, saf * (float)__builtin_bit_cast(half_t, sbu[r]), acc[r][m]);   // exact scale product
         acc[r][m] = (leader && ok) ? next : acc[r][m];
       }
     }
@@ -223,8 +220,7 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
       float s = acc[r][m];
       s = wave_sum_butterfly(s);                      // xor 32, 16, .., 1 without the LDS pipeline (common.h)
       if (lane == 0 && n0 + r < p.N && m < p.M) {
-        const float t = (float)d * sa8f;
-        const float c = __builtin_fmaf(t, (float)__builtin_bit_cast(half_t, sb8u[r]), s);
+        const float c = __builtin_fmaf((float)d, sa8f * (float)__builtin_bit_cast(half_t, sb8u[r]), s);
         const int n = n0 + r;
         if constexpr (OUT == 0) {
           p.D[(int64_t)m * p.N + n] = f2h(c);

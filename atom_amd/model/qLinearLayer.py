@@ -12,6 +12,8 @@ packed INT4/INT8 form the W4A4 GEMM consumes (the bridge the reference lacks, SU
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -46,6 +48,11 @@ class QLinearLayer(nn.Module):
     # INT4 codes once the F6 form exists (a layer that only sees prefill batches then holds 6.75 bit per weight instead of 10.9);
     # a later decode-size batch re-packs them from `weight` (one atom_pack_weight_w4 launch).
     keep_packed_with_f6 = True
+    # Forwards that arrived with INT4 activation codes and a hot-path configuration but were served by F.linear because the weight is
+    # not on the INT4-g128 / INT8 grid (pack_weight_w4 found off-grid blocks): the reference's own arithmetic, but not the HIP path.
+    # Expected while GPTQ collects Hessians on still-unquantised weights; anywhere else it means the layer was never quantised.
+    # Class-wide total here, per layer in `self.offgrid_fallbacks`; the first one of every layer shape also raises a RuntimeWarning.
+    offgrid_fallbacks_total = 0
 
     def weight_bytes(self):
         """Bytes currently held for this layer's weight, by form."""
@@ -73,6 +80,8 @@ class QLinearLayer(nn.Module):
         self._packed_key = None      # identity of the fp16 weight the packed form was made from
         self._unpackable_key = None  # identity of a weight that pack_weight_w4 found to be off the grid
         self._f6 = None              # (packed B4 it was made from, BF6 repack) for the block-scaled-MFMA kernel
+        self.offgrid_fallbacks = 0   # forwards of THIS layer served by F.linear because its weight is off the grid
+        self._offgrid_blocks = 0     # off-grid (channel_group x 128) blocks of the weight `_unpackable_key` names
 
     # ------------------------------------------------------------------------------------------------ forward
     def _weight_key(self):
@@ -99,6 +108,9 @@ class QLinearLayer(nn.Module):
                 self._packed = (b4, b8, sb, sb8)
                 self._packed_key = key
                 return self._packed
+            self._offgrid_blocks = int(bad)
+        else:
+            self._offgrid_blocks = 0
         self._unpackable_key = key
         return None
 
@@ -127,6 +139,15 @@ class QLinearLayer(nn.Module):
             if self.bias is not None:
                 y = y + self.bias
             return y
+        if codes is not None and packed is None and self._offgrid_blocks and self._unpackable_key == self._weight_key():
+            self.offgrid_fallbacks += 1
+            QLinearLayer.offgrid_fallbacks_total += 1
+            if self.offgrid_fallbacks == 1:
+                n, k = self.weight.shape
+                warnings.warn(f"QLinearLayer {n}x{k}: {self._offgrid_blocks} weight blocks are not on the INT4-g128 / INT8 grid -- this "
+                              "layer runs F.linear on the fake-quantised tensors, not the HIP W4A4 kernels (expected only while GPTQ "
+                              "collects Hessians on unquantised weights; see QLinearLayer.offgrid_fallbacks_total)", RuntimeWarning,
+                              stacklevel=2)
         return torch.functional.F.linear(x, self.weight, self.bias)
 
     def to(self, *args, **kwargs):

@@ -281,7 +281,8 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
                                    a_keeper.data_ptr(), b_keeper.data_ptr(), a_keeper_scale.data_ptr(),
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
                                    _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0))
-                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0),
+                                   | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0)
+                                   | (L.B_SCALE_PAIRS if a_wide == "f6" and getattr(b, "atom_pairs", False) else 0),
                                    L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
@@ -552,6 +553,16 @@ def kv_fake_quant(x: torch.Tensor, n_bits: int = 4, clip: float = 1.0) -> torch.
     return y
 
 
+def scale_pairs_shared(b_scale: torch.Tensor, n: int) -> bool:
+    """True when output channels 2j and 2j+1 share their weight scale in every group (weight_channel_group = 2 -- the only form the
+    reference kernel accepts, Dense_layer_gemm_i4_o16.cuh:413-431): the GEMM is then told so (ATOM_B_SCALE_PAIRS) and forms each scale
+    product once per pair.  Checked on the values (one device round trip, offline with the weight; never during graph capture)."""
+    if n % 2 or torch.cuda.is_current_stream_capturing():
+        return False
+    s = b_scale.reshape(-1, n)
+    return bool((s[:, 0::2] == s[:, 1::2]).all().item())
+
+
 def repack_weight_f6(b4: torch.Tensor, b_scale: torch.Tensor = None) -> torch.Tensor:
     """Packed INT4 weights uint8 [N, K4/2] -> the F6 operand format uint8 [G][f6_rows(N)][104] (atom_repack_weight_f6).
     With the fp16 weight scales `b_scale` [G, N]: atom_repack_weight_f6s -- the returned tensor is a view of a buffer that
@@ -570,6 +581,7 @@ def repack_weight_f6(b4: torch.Tensor, b_scale: torch.Tensor = None) -> torch.Te
         L.check(st, "atom_repack_weight_f6s")
         out = buf[:g * f6_rows(n) * L.F6_PITCH].view(g, f6_rows(n), L.F6_PITCH)
         out.atom_f6s = buf                       # the whole buffer (codes + float32 scales) stays alive with the view
+        out.atom_pairs = scale_pairs_shared(b_scale, n)
         return out
     out = torch.empty((g, f6_rows(n), L.F6_PITCH), dtype=torch.uint8, device=b4.device)
     st = L.lib().atom_repack_weight_f6(b4.contiguous().data_ptr(), n, k4h * 2 + GROUP_SIZE, out.data_ptr(),
@@ -622,7 +634,9 @@ def gate_up_silu_quant_f6(a6, a_keeper, a_keeper_scale, fused, *, quant_mode="ke
     b6s = fused["b6s"]
     st = L.lib().atom_gemm_w4a4_silu_mul_quant_f6(a6.data_ptr(), b6s.atom_f6s.data_ptr(), a_keeper.data_ptr(), fused["b8"].data_ptr(),
                                                   a_keeper_scale.data_ptr(), fused["sb8"].data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
-                                                  _MODES[quant_mode], float(clip), _LAYOUTS[scale_layout], outs[0].data_ptr(),
+                                                  _MODES[quant_mode], float(clip),
+                                                  _LAYOUTS[scale_layout] | (L.B_SCALE_PAIRS if getattr(b6s, "atom_pairs", False) else 0),
+                                                  outs[0].data_ptr(),
                                                   outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), L.ptr(outs[4]),
                                                   L.current_stream(a6.device))
     L.check(st, "atom_gemm_w4a4_silu_mul_quant_f6")

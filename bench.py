@@ -6,7 +6,7 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
-                    [--no-configs] [--with-block] [--workload gemm|block]
+                    [--no-configs] [--no-block] [--workload gemm|block]
                     [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle;
                                      reported as "ramp" in the JSON line)
 
@@ -21,7 +21,8 @@ route three ways: "packed_ws" (C ABI + caller-owned workspace, nothing cached), 
 ATOM_WS_WEIGHT_CACHED: one weight repeated) and "packed_ops" (atom_amd.ops with two weights in alternation: its per-weight
 cache; = "abi_value").  Also at N=1: "cold" (the headline with 512 MB flushed between launches) and "configs" -- the other
 BASELINE configs (config 2 M=1, the corners of config 5, the 4096-wide batch sweep), HIP-graph replay per launch, hot and with
-the weights streamed from HBM (--no-configs skips it; --with-block adds config 4 through --workload block).
+the weights streamed from HBM (--no-configs skips it), and "block" -- BASELINE config 4 (one Llama-7B decoder block at batch 32 x
+seq 2048, KV INT4) through --workload block in its own process, with its GEMM / quantiser / attention split (--no-block skips it).
 
 N > 1: one process per GPU (torch.distributed.run), every rank runs an independent replica (the path is a
 single-device per-layer GEMM: "replicas only", no collective on the data path); value = all ranks' ops / max time.
@@ -210,7 +211,8 @@ def configs_sweep(dev):
             a6, b6 = build_f6_operands(ops_, M, N, K, dev)
             D = torch.empty((M, N), dtype=torch.float16, device=dev)
             ptrs = [a6.data_ptr(), b6.data_ptr()] + [t.data_ptr() for t in ops_[2:]]
-            f = lambda st: lib.atom_gemm_w4a4_f16(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S, st)
+            f6_flags = L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S | (L.B_SCALE_PAIRS if b6.atom_pairs else 0)
+            f = lambda st: lib.atom_gemm_w4a4_f16(*ptrs, D.data_ptr(), M, N, K, 128, 128, f6_flags, st)
             f6 = CB.graph_time([f], 64)
             row.update({"f6_us": round(f6, 2), "f6_tops": round(op / f6 / 1e6, 1), "f6_frac_mfma": round(op / f6 / 1e6 / PEAK_I8_TOPS, 4)})
             del ops_, a6, b6, D
@@ -347,8 +349,10 @@ def main():
                     help="operand format of the headline measurement (the other two are reported beside it at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the side sweep over the other BASELINE configs (N=1 only)")
-    ap.add_argument("--with-block", action="store_true", help="also run --workload block (BASELINE configs[3]) and put its numbers "
-                                                                "into the line's `configs` (adds ~1-2 minutes)")
+    ap.add_argument("--with-block", action="store_true", help="(the default since round 5; kept so that older command lines parse)")
+    ap.add_argument("--no-block", action="store_true", help="skip --workload block (BASELINE configs[3]: one Llama-7B block at batch 32 x "
+                                                              "seq 2048, its own process; ~1 minute), whose numbers otherwise go into "
+                                                              "the line's `block` key (N=1 only)")
     ap.add_argument("--workload", choices=["gemm", "block"], default="gemm",
                     help="gemm = the headline GEMM (BASELINE configs[2]); block = one Llama-7B decoder block, batch 32 x seq 2048, "
                          "KV INT4, through QLlamaDecoderLayer (BASELINE configs[3]; a step = one block forward; --steps 3 is plenty)")
@@ -409,19 +413,22 @@ def main():
     a4 = ops_[0].view(torch.uint8).view(M, (K - 128) // 32, 16)
     wide = torch.stack([(a4 << 4) & 0xF0, a4 & 0xF0], dim=2).reshape(M, K - 128).contiguous()
     a6, b6 = build_f6_operands(ops_, M, N, K, dev)
+    # channel pairs share their weight scales in these operands (make_operands; weight_channel_group = 2, the reference kernel's only
+    # form): the callers say so, as a binding of the reference's launcher would (ATOM_B_SCALE_PAIRS; atom_amd.ops checks the values)
+    PAIRS = L.B_SCALE_PAIRS if b6.atom_pairs else 0
     variants = {
-        "packed": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+        "packed": ([*ptrs], L.SCALE_LAYOUT_PLAIN | PAIRS,
                    "reference format: packed INT4 nibbles (punica.ops ABI), INT8 MFMA after in-kernel widening"),
-        "wide": ([wide.data_ptr()] + ptrs[1:], L.SCALE_LAYOUT_PLAIN | L.A_WIDE,
+        "wide": ([wide.data_ptr()] + ptrs[1:], L.SCALE_LAYOUT_PLAIN | L.A_WIDE | PAIRS,
                  "activations int8 = code*16 (ATOM_A_WIDE), weights packed INT4, INT8 MFMA"),
-        "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S,
+        "f6": ([a6.data_ptr(), b6.data_ptr()] + ptrs[2:], L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S | PAIRS,
                "both operands BF6 group-major (ATOM_AB_F6): v_mfma_f32_16x16x128_f8f6f4, exact integer dot products; the "
                "format the fused quantisers emit for prefill batches"),
-        "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+        "packed_ws": ([*ptrs], L.SCALE_LAYOUT_PLAIN | PAIRS,
                       "reference packed format through atom_gemm_w4a4_f16_ws with a caller-owned workspace, nothing cached: BOTH operands "
                       "are re-coded to BF6 in the workspace by every call, then the BF6 MFMA kernel -- what a one-to-one binding of the "
                       "reference's launcher with a workspace gets (INTEGRATION.md)"),
-        "packed_ws_same_weight": ([*ptrs], L.SCALE_LAYOUT_PLAIN,
+        "packed_ws_same_weight": ([*ptrs], L.SCALE_LAYOUT_PLAIN | PAIRS,
                                   "as packed_ws, REPEATED CALLS WITH ONE WEIGHT: the caller asserts ATOM_WS_WEIGHT_CACHED from the second call "
                                   "on (only the activation is re-coded); holds only while nothing else touches that workspace"),
         "packed_ops": (None, None,
@@ -553,16 +560,28 @@ def main():
             del a6, b6, wide
             torch.cuda.empty_cache()
             out["configs"] = configs_sweep(dev)
-            if args.with_block:                                  # BASELINE configs[3] in the same line (its own process: fresh allocator state)
-                import subprocess
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "block", "--steps", "3", "--warmup", "1",
-                                    "--no-cpu-baseline"], capture_output=True, text=True)
-                try:
-                    b = json.loads(r.stdout.strip().splitlines()[-1])
-                    out["configs"]["block"] = {k: b[k] for k in ("metric", "value", "unit", "block_ms", "gemm_ms", "gemm_share", "module_ms")}
-                    out["configs"]["block"]["frac_mfma"] = b["roofline"]["frac"]
-                except Exception as e:                           # pragma: no cover
-                    out["configs"]["block"] = {"error": f"{type(e).__name__}: {r.stderr[-300:]}"}
+        if world == 1 and not args.no_block:                     # BASELINE configs[3] at its stated size in the same line (its own
+            import subprocess                                    # process: fresh allocator state; ~1 minute)
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "block", "--steps", "3", "--warmup", "1",
+                                "--no-cpu-baseline"], capture_output=True, text=True)
+            try:
+                b = json.loads(r.stdout.strip().splitlines()[-1])
+                mm = b["module_ms"]
+                quant_ms = sum(v for k, v in mm.items() if k.endswith("layernorm"))
+                out["block"] = {"config": b["config"]["workload"], "tokens": b["config"]["tokens"], "steps": b["steps"],
+                                "block_ms": b["block_ms"],
+                                "gemm_ms": b["gemm_ms"], "gemm_tops": b["value"], "gemm_frac_mfma": b["roofline"]["frac"],
+                                "quantiser_ms": round(quant_ms, 3),
+                                "attention_and_rest_ms": round(b["block_ms"] - b["gemm_ms"] - quant_ms, 3),
+                                "gemm_share": b["gemm_share"], "module_ms": mm,
+                                "note": "one QLlamaDecoderLayer forward (model/qLlamaLayer.py:86-127 mirrored) at batch 32 x seq 2048; gemm_ms = "
+                                        "q/k/v/o projections + the MLP module (gate / up / SiLU x up / its quantiser in one launch, then down_proj); "
+                                        "quantiser_ms = the two RMSNorm -> reorder -> quantise launches (the o_proj and down_proj quantisers run "
+                                        "inside attention / the MLP launch); the rest is torch's attention over the fake-quantised INT4 KV, RoPE "
+                                        "and the residual adds"}
+            except Exception as e:                               # pragma: no cover
+                out["block"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N, K)
         print(json.dumps(out), flush=True)

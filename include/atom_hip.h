@@ -104,6 +104,14 @@ int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
  * state: the CALLER asserts it (atom_amd.ops tracks which weight its workspace holds).  Wrong flag = wrong results, never a fault
  * (the region is inside the workspace either way).  Ignored on every other route. */
 #define ATOM_WS_WEIGHT_CACHED 0x1000
+/* OR into `scale_layout` of the GEMM entry points: the caller asserts that output channels 2 j and 2 j + 1 share their weight scales,
+ * sB[g][2 j] == sB[g][2 j + 1] for every group g (weight_channel_group = 2 of model/qLinearLayer.py:63-70 -- the only form the
+ * reference kernel accepts: its dequant applies ONE scale product to both columns of a pair, Dense_layer_gemm_i4_o16.cuh:413-431).
+ * The 256x256 block-scaled-MFMA kernel then forms each (token, channel pair, group) scale product once: 6 instead of 8 de-quantisation
+ * instructions per MFMA.  Same results bit for bit when the assertion holds; channel 2 j + 1 is de-quantised with channel 2 j's scale
+ * when it does not (never a fault).  sB8 -- the keeper's scales are per output channel, model/qLinearLayer.py:59 -- is not covered:
+ * the keeper step always forms one product per channel.  Ignored by kernels that do not use it. */
+#define ATOM_B_SCALE_PAIRS 0x2000
 #define ATOM_F6_PITCH 104
 
 const char *atom_version(void);
@@ -117,10 +125,12 @@ size_t atom_scale_size(int64_t rows, int scale_layout);
  * D[M,N] (fp16) = sum_g (A4_g . B4_g^T) * sA[m,g] * sB[g,n]  +  (A8 . B8^T) * sA8[m] * sB8[n]
  * Replaces: DenseLayerGEMM_i4_o16 (kernels/include/GEMM/Dense_layer_gemm_i4_o16.cuh:728-769) and
  *           DenseLayerGEMM_i4<nv_half> (e2e/punica-atom/punica/ops/csrc/GEMM/DenseLayerGEMM_i4.cu:722-791).
- * Integer dot products are exact (INT8 / BF6 MFMA); per group c = fma(round_f32(idot*sA), sB, c) in FP32, groups in
- * order, then the keeper: ONE dot product over its 128 columns, de-quantised once the same way -- the reference kernel accumulates
- * both keeper k-steps in int32 before its dequant too (Dense_layer_gemm_i4_o16.cuh:640-691; rounds 1-2 of this library de-quantised
- * two 64-column halves separately); D = half(c).  The decode kernels
+ * Integer dot products are exact (INT8 / BF6 MFMA); per group s = sA[m,g] * sB[g,n] -- EXACT in FP32: both are fp16 values, 11-bit
+ * significands -- and c = fma(idot, s, c): one rounding per group, groups in order, then the keeper: ONE dot product over its 128
+ * columns, de-quantised once the same way -- the reference kernel accumulates both keeper k-steps in int32 before its dequant too
+ * (Dense_layer_gemm_i4_o16.cuh:640-691); D = half(c).  This is the reference kernel's own dequant shape -- scale product first
+ * (__hmul2, :417), then accu += c_frag * rs_scale (:419-431) -- without its two extra roundings (the FP16 product, the FP32 multiply
+ * ahead of the add).  (Rounds 1-4 of this library: t = round_f32(idot * sA), c = fma(t, sB, c).)  The decode kernels
  * (M = 1: dot products along K; 2 <= M <= 256 in the packed format: eight waves own an eighth of the groups each) apply
  * the same per-group arithmetic and add their per-lane / per-wave partial sums in a fixed order: deterministic, within
  * 1 fp16 ulp of the exact value like the tile kernels, but not the same FP32 summation order.

@@ -438,16 +438,18 @@ def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
 
 
 def gemm_w4a4_contract(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8, kgroups: int = 1) -> np.ndarray:
-    """The C-ABI arithmetic contract (include/atom_hip.h) in numpy float32, independent of oracle/atom_oracle.c:
+    """The C-ABI arithmetic contract (include/atom_hip.h) in numpy, independent of oracle/atom_oracle.c:
     K steps = the G int4 groups in order, then the keeper (ONE dot product over its 128 columns, one de-quantisation, as the
-    reference kernel: Dense_layer_gemm_i4_o16.cuh:640-691); per step t = f32(idot * sA),
-    c = fma(t, sB, c) (the fma through float64: the product of two float32 is exact there and one rounding of the sum to
-    float32 is the fused result up to double rounding, which the 2^-29 headroom of these operands excludes -- checked against
-    the C restatement in tests).  kgroups = 1: one ordered sum (tile kernels).  kgroups = 2 / 4: the K-group tile kernels
-    (gemm_w4a4_f6.hip) -- the G + 1 steps are cut into ranges [(G+1)k/kg, (G+1)(k+1)/kg), each summed from 0, partial sums added
-    in order.  Returns float16 [M, N]."""
+    reference kernel: Dense_layer_gemm_i4_o16.cuh:640-691); per step s = sA * sB -- exact in float32, both are fp16 values --,
+    c = fma(idot, s, c): the reference's dequant shape (scale product first, then accu += c_frag * rs_scale,
+    Dense_layer_gemm_i4_o16.cuh:413-431) with one rounding per step.  The fma goes through the x87 extended format: idot * s has
+    at most 46 significant bits, exact there, and one rounding of the sum to float32 is the fused result up to double rounding,
+    which needs a 2^-39 coincidence per operation (checked against the C restatement in tests).  kgroups = 1: one ordered sum
+    (tile kernels).  kgroups = 2 / 4: the K-group tile kernels (gemm_w4a4_f6.hip) -- the G + 1 steps are cut into ranges
+    [(G+1)k/kg, (G+1)(k+1)/kg), each summed from 0, partial sums added in order.  Returns float16 [M, N]."""
     M, K4 = qa4.shape
     G = K4 // GROUP
+    wide = np.longdouble
     steps = []
     for g in range(G):
         steps.append((_group_int_dots(qa4, qb4, g), sA[:, g].astype(f32), sB[g].astype(f32)))
@@ -458,8 +460,8 @@ def gemm_w4a4_contract(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8, kgroups: int = 1) -
     for k in range(kgroups):
         c = np.zeros((M, qb4.shape[0]), dtype=f32)
         for I, sa, sb in steps[T * k // kgroups:T * (k + 1) // kgroups]:
-            t = (I * sa[:, None]).astype(f32)
-            c = (t.astype(np.float64) * sb[None, :].astype(np.float64) + c.astype(np.float64)).astype(f32)
+            s = (sa[:, None] * sb[None, :]).astype(f32)                    # exact: 11-bit x 11-bit significands
+            c = (I.astype(wide) * s.astype(wide) + c.astype(wide)).astype(f32)
         total = c if total is None else (total + c).astype(f32)
     with np.errstate(over="ignore"):
         return total.astype(f16)

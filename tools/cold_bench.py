@@ -91,7 +91,7 @@ def gemm_row(M, N, K, quiet=False):
 
     def mk(ops_):
         ptrs = [t.data_ptr() for t in ops_]
-        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | (L.A_WIDE if WIDE else 0), ws.data_ptr(), wsb, st)
+        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS | (L.A_WIDE if WIDE else 0), ws.data_ptr(), wsb, st)   # (bench.make_operands: channel pairs share their scales)
     launchers = [mk(s) for s in sets]
     iters = max(64, 2 * R)
     iters -= iters % R

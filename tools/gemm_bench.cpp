@@ -112,6 +112,9 @@ int main(int argc, char **argv) {
       if (st) { printf("repack: %s\n", atom_strerror(st)); return 1; } }
     layout2 = ATOM_SCALE_LAYOUT_PLAIN | ATOM_AB_F6 | (f6s ? ATOM_B_F6S : 0);
   }
+#ifdef ATOM_B_SCALE_PAIRS
+  if (!getenv("ATOM_NO_PAIRS")) layout2 |= ATOM_B_SCALE_PAIRS;   // hsB above: channel pairs share their scales (ATOM_NO_PAIRS: the generic kernels)
+#endif
   size_t wsb = getenv("ATOM_WS") ? atom_gemm_w4a4_workspace_bytes(M, N, K) : 0;
   void *ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
   printf("workspace bytes %zu\n", wsb);
