@@ -120,6 +120,8 @@ int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmen
 bool skinny_q_fits(int q_op, int64_t M, int64_t K_total);             // ... the shapes its quantiser-in-front variant takes
 int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s);   // ... + the preceding quantiser inside the launch (p.q_*)
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
+int launch_gemm_f6_mid(const GemmParams &p, hipStream_t s);        // gemm_w4a4_mid.hip: the same for BF6 operands (ATOM_AB_F6 | ATOM_B_F6S)
+int launch_gemm_mid(const GemmParams &p, hipStream_t s);           // gemm_w4a4_mid.hip (packed operands, mid-size batches: 64x64 tiles, deep LDS ring)
 int launch_gemm_f6_gateup(const GemmParams &p, int sim, hipStream_t s);   // ... 256x256 kernel + fused SiLU x up -> quant epilogue
 
 // quant_kernels.hip: packed operand (+ scales) -> F6 buffer [G][round_up(rows, 256)][104]

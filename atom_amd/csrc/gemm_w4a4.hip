@@ -56,6 +56,15 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   return N * items <= 420000;
 }
 
+// Mid-size batches in the packed (reference) format: 64x64 tiles over the whole K range on a deep LDS ring (gemm_w4a4_mid.hip).  Takes
+// a shape once its tiles fill a good part of the chip -- below that the decode-batch kernel's one-workgroup-per-16-features grid wins --
+// and up to the batch where the re-coding route to the BF6 kernels (f6_route) pays for its extra launch.
+static bool mid_fits(int64_t M, int64_t N, int64_t K_total) {
+  if (!ATOM_TUNE("ATOM_MID", 1) || (N % 64) != 0) return false;
+  const int64_t tiles = ((M + 63) / 64) * (N / 64);
+  return M > 16 && M <= ATOM_TUNE("ATOM_MID_MAX_M", 1024) && tiles >= ATOM_TUNE("ATOM_MID_MIN_TILES", 96);
+}
+
 // Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt, profiles/r03_f6_dispatch.txt -- every geometry forced
 // on a 48-shape grid: this pick is within 1-3 % of the best one).  256x256 (one workgroup per CU, the q kernel) from 129 tiles in one
 // round, or when its tiles keep >= 60 % of the CU slots of the rounds they need busy -- a full 256x256 tile does four 128x128 tiles'
@@ -146,6 +155,10 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
         const int st = launch_gemv1(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
       }
+      if (mid_fits(M, N, K_total)) {                                // mid-size batches: 64x64 tiles on a deep LDS ring
+        const int st = launch_gemm_mid(p, hs);
+        if (st != ATOM_ERR_SHAPE) return st;
+      }
       if (M > 1 && skinny_fits(M, N, K_total)) {                    // decode batches: weight streaming on the MFMA
         const int st = launch_gemm_skinny(p, hs);
         if (st != ATOM_ERR_SHAPE) return st;
@@ -207,7 +220,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 // Split-K policy: shapes that yield fewer than 512 workgroups of the smallest tile are latency-bound (one pass over K per
 // workgroup at ~1 us per K-group); split the K loop over up to 8 workgroups and reduce FP32 partials in a second launch.
 static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
-  if (M <= gemv_max_m() || skinny_fits(M, N, K_total)) return 1;   // decode kernels
+  if (M <= gemv_max_m() || skinny_fits(M, N, K_total) || mid_fits(M, N, K_total)) return 1;   // decode / mid-size kernels
   const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
   const int force = ATOM_TUNE("ATOM_SPLITS", 0);
@@ -229,12 +242,25 @@ static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
 // weight re-coded by every call.
 static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
   const int off = ATOM_TUNE("ATOM_NO_F6_ROUTE", 0);
-  if (off || N < 2048 || K_total < 1024) return false;
+  if (off || N < 2048 || K_total < 1024 || mid_fits(M, N, K_total)) return false;
   if (M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 257)) return true;
   return M > 128 && !skinny_fits(M, N, K_total);
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;
+}
+
+int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_workspace) {
+  if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  if (with_workspace && atom_gemm_w4a4_workspace_bytes(M, N, K_total) != 0) {
+    if (f6_route(M, N, K_total)) return atom_gemm_w4a4_f6_order(M, N, K_total);      // re-coded to BF6: 1 / 2 / 4
+    return 100 + choose_splits(M, N, K_total);                                       // split-K through the workspace
+  }
+  if (M <= gemv_tokens(K_total)) return 64;                                          // the dot-product kernel
+  if (mid_fits(M, N, K_total)) return 1;
+  if (M > 1 && skinny_fits(M, N, K_total)) return 8;                                 // the decode-batch kernel
+  if (M <= gemv_max_m()) return 63;                                                  // the staged dot-product kernel
+  return 1;                                                                          // tile kernels
 }
 
 int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total) {

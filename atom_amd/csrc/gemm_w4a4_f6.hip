@@ -2463,6 +2463,11 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
   if (cfg == 1) return f6::launch<f6::Cfg<256, 128, 4, 2>, false>(p, s);
   if (cfg == 13) return f6::launch<f6::Cfg<128, 128, 2, 2, 3>, false>(p, s);  // tuning: 128x128 on the 32x32x64 MFMA
 #endif
+  if (cfg == 20) {                                                             // mid-size batches: 64x64 tiles on a deep LDS ring (gemm_w4a4_mid.hip)
+    const int st = launch_gemm_f6_mid(p, s);
+    if (st != ATOM_ERR_SHAPE) return st;
+    cfg = 3;
+  }
   if (cfg == 8) {                                                              // 256x128, qk_step, K steps in order
     if (p.sB32 && p.G >= 2) return f6::launch_q2<f6::Cfg<256, 128, 2, 3, 2, 1>>(p, s);
     cfg = 3;                                                                   // fp16 weight scales: the 128x128 geometry (same order)

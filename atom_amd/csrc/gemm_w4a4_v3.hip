@@ -18,10 +18,13 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // group, with the even / odd channels of every 32-channel block de-interleaved into two 16-byte chunks -- exactly the
 // two operands widen() makes from one packed chunk -- so the kernel skips 3.0 of its 4.5 widening VALU per MFMA.
 // Produced by the activation-quant kernels (ATOM_QUANT_WIDE_CODES); the weights stay packed INT4.
-template <int BM_, int BN_, int NS_, int TM_ = 4, bool AW_ = false>
+template <int BM_, int BN_, int NS_, int TM_ = 4, bool AW_ = false, bool PAIR_ = false>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, NS = NS_, TM = TM_;
   static constexpr bool AW = AW_;
+  // ATOM_B_SCALE_PAIRS (the caller asserts weight_channel_group = 2): the int4 steps form one scale product per channel pair -- 2.5
+  // instead of 3 de-quantisation VALU per element; only the geometries of large batches are instantiated with it
+  static constexpr bool PAIR = PAIR_;
   static constexpr int WM = 32 * TM;                         // rows of activations per wave
   static constexpr int WGM = BM / WM, WGN = BN / 64, NW = WGM * WGN, NT = NW * 64;
   static constexpr int A_ROWB = AW ? 128 : 64;               // bytes per activation row and stage
@@ -185,13 +188,14 @@ __device__ __forceinline__ void load_frag(const char *p0, const char *p1, v4i (&
 // -- 2 instead of 3 instructions per element here, but two roundings and no shared scale product for the BF6 kernels the library
 // ships as its fast path; this INT8 kernel serves the plain entry point only.)  Four elements at a time: the wave tile leaves no
 // registers for 16 products.
+template <bool PAIR = false>
 __device__ __forceinline__ void dequant16_magic(const v16i &a, float sa, const v2u (&sbp)[4], float (&c)[16]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const half_t *hv = reinterpret_cast<const half_t *>(&sbp[q]);
     float s[4], t[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = (float)hv[r] * sa;
+    for (int r = 0; r < 4; ++r) s[r] = (PAIR && (r & 1)) ? s[r - 1] : (float)hv[r] * sa;   // (a lane's four are consecutive channels)
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = __int_as_float(a[4 * q + r]) - kMagic;
 #pragma unroll
@@ -249,7 +253,7 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
-        dequant16_magic(a, sa, sbp, c[tn][tm]);
+        dequant16_magic<C::PAIR && INT4>(a, sa, sbp, c[tn][tm]);
       }
     }
     return;
@@ -286,7 +290,7 @@ __device__ __forceinline__ void compute_step(const char *slot, const LaneOff &lo
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         sbp[q] = *reinterpret_cast<const v2u *>(psb + (tn * 32 + 8 * q) * 2);
-      dequant16_magic(a, sa, sbp, c[tn][tm]);
+      dequant16_magic<C::PAIR && INT4>(a, sa, sbp, c[tn][tm]);
     }
   }
 }
@@ -524,7 +528,8 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     return cfg == 4 ? launch_v3_splitk<v3::Cfg<64, 64, 3, 2>>(p, s) : launch_v3_splitk<v3::Cfg<64, 128, 3, 2>>(p, s);
   }
   switch (cfg) {
-    case 1: return launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
+    case 1: return p.b_pairs ? launch_v3_cfg<v3::Cfg<256, 128, 3, 4, false, true>>(p, s)
+                             : launch_v3_cfg<v3::Cfg<256, 128, 3>>(p, s);   // 4 waves, two workgroups per CU
     case 2: return launch_v3_cfg<v3::Cfg<128, 256, 3>>(p, s);   // 4 waves (1 x 4), two workgroups per CU
     case 3: return launch_v3_cfg<v3::Cfg<256, 128, 2>>(p, s);
     case 4: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2>>(p, s);     // skinny M: one wave per workgroup, 64x64 tile
@@ -535,10 +540,12 @@ int launch_gemm_v3(const GemmParams &p, int cfg, hipStream_t s) {
     case 11: return launch_v3_cfg<v3::Cfg<256, 128, 3>, true>(p, s);
     case 30: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>, true>(p, s);   // traced
 #endif
-    case 20: return launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>>(p, s);   // wide activations (p.A4 = int8 [M, K4])
+    case 20: return p.b_pairs ? launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true, true>>(p, s)
+                              : launch_v3_cfg<v3::Cfg<256, 256, 3, 4, true>>(p, s);   // wide activations (p.A4 = int8 [M, K4])
     case 24: return launch_v3_cfg<v3::Cfg<64, 64, 3, 2, true>>(p, s);
     case 25: return launch_v3_cfg<v3::Cfg<64, 128, 3, 2, true>>(p, s);
-    default: return launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
+    default: return p.b_pairs ? launch_v3_cfg<v3::Cfg<256, 256, 4, 4, false, true>>(p, s)
+                              : launch_v3_cfg<v3::Cfg<256, 256, 4>>(p, s);  // == v2 geometry
   }
 }
 

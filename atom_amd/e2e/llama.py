@@ -9,8 +9,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+import dataclasses
 import math
-import os
 
 from .. import ops
 from ..utils import BatchedKvCacheInt4, BatchLenInfo
@@ -18,23 +18,36 @@ from ..utils import BatchedKvCacheInt4, BatchLenInfo
 GROUP = 128
 
 
-_FUSED_KV_APPEND = os.environ.get("ATOM_FUSED_KV_APPEND", "1") != "0"   # 0: the reference's op sequence in decode steps too
-_FUSED_Q_DECODE = os.environ.get("ATOM_FUSED_Q_DECODE", "1") != "0"      # one or two tokens: quantisers inside their consumers
-# ... which of the four (LlamaDecoderLayer._decode_fused_q).  Default 2 = reorder -> o_proj only: every workgroup of the GEMM repeats the
-# quantiser, which pays while the projection has one workgroup per CU (N = 4096: 6.4 -> 5.3 us for the pair; the decode layer 66.4 ->
-# 64.9 us cold at batch 1) and loses once it has several rounds of them (q / k / v: 11.3 -> 13.8 us, gate / up: 16.0 -> 23.3);
-# SiLU x up -> down_proj measures even (profiles/r03_decode.txt item 7)
-_FUSED_Q_MASK = int(os.environ.get("ATOM_FUSED_Q_MASK", "2"))
-_FUSED_DECODE = os.environ.get("ATOM_FUSED_DECODE", "1") != "0"         # 0: one launch per projection in decode steps (round 2)
+@dataclasses.dataclass
+class DecodeFusion:
+    """Which launches of a decode step are fused -- a constructor argument of the modules below (``fusion=``); every module that gets
+    none shares ``FUSION``, the process-wide default.  (Rounds 2-4 read these switches from environment variables at import.)
+      decode     the projections that share an activation in ONE launch (q / k / v, gate / up), the residual add inside down_proj's
+                 (False: one launch per projection, the reference's call order llama.py:259-292)
+      kv_append  k / v quantised into the paged cache from the FP32 sums (False: the reference's op sequence _o4 GEMM -> append)
+      q_decode   one or two tokens: quantisers inside the GEMM that consumes them (atom_gemm_w4a4_multi_q)
+      q_mask     ... which of the four (LlamaDecoderLayer._decode_fused_q): 1 input_layernorm -> q / k / v, 2 reorder -> o_proj,
+                 4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 2: every workgroup of the GEMM repeats
+                 the quantiser, which pays while the projection has one workgroup per CU (N = 4096: 6.4 -> 5.3 us for the pair; the
+                 decode layer 66.4 -> 64.9 us cold at batch 1) and loses once it has several rounds of them (q / k / v: 11.3 -> 13.8 us,
+                 gate / up: 16.0 -> 23.3); SiLU x up -> down_proj measures even (profiles/r03_decode.txt item 7)"""
+    decode: bool = True
+    kv_append: bool = True
+    q_decode: bool = True
+    q_mask: int = 2
+
+
+FUSION = DecodeFusion()
 
 
 class LinearInt4(nn.Module):
     """reference llama.py:35-68.  ``forward`` takes the 4-tuple an activation-quant op returns."""
 
-    def __init__(self, in_features, out_features, out_dtype, bias=False):
+    def __init__(self, in_features, out_features, out_dtype, bias=False, fusion: DecodeFusion = None):
         super().__init__()
         assert bias is False
         assert out_dtype in ("fp16", "int4")
+        self.fusion = fusion if fusion is not None else FUSION
         self.in_features, self.out_features, self.out_dtype = in_features, out_features, out_dtype
         self.weight_int4 = nn.Parameter(torch.empty(out_features, (in_features - GROUP) // 2, dtype=torch.uint8),
                                         requires_grad=False)
@@ -104,7 +117,7 @@ class LinearInt4(nn.Module):
         """residual + forward(input): decode batches run the add inside the projection's launch (same bits as the torch add)."""
         outlier, norms, outlier_scales, norm_scales = input
         rows = outlier.size(0)
-        if (norms.dim() == 2 and self.out_dtype == "fp16" and _FUSED_DECODE and residual.is_contiguous()
+        if (norms.dim() == 2 and self.out_dtype == "fp16" and self.fusion.decode and residual.is_contiguous()
                 and ops.multi_gemm_fits(rows, self.out_features, 1, self.in_features)):
             return ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self.single(),
                                                  add=residual.view(rows, self.out_features))[0].view(residual.shape)
@@ -138,14 +151,15 @@ class LlamaRMSNormInt4(nn.Module):
 class LlamaMLP(nn.Module):
     """reference llama.py:71-87: down( activate_fp16_i4( gate(x), up(x) ) )."""
 
-    def __init__(self, config):
+    def __init__(self, config, fusion: DecodeFusion = None):
         super().__init__()
         self.config = config
+        self.fusion = fusion if fusion is not None else FUSION
         self.hidden_size = config.hidden_size
         self.intermediate_size = config.intermediate_size
-        self.gate_proj = LinearInt4(self.hidden_size, self.intermediate_size, out_dtype="fp16", bias=False)
-        self.up_proj = LinearInt4(self.hidden_size, self.intermediate_size, out_dtype="fp16", bias=False)
-        self.down_proj = LinearInt4(self.intermediate_size, self.hidden_size, out_dtype="fp16", bias=False)
+        self.gate_proj = LinearInt4(self.hidden_size, self.intermediate_size, out_dtype="fp16", bias=False, fusion=fusion)
+        self.up_proj = LinearInt4(self.hidden_size, self.intermediate_size, out_dtype="fp16", bias=False, fusion=fusion)
+        self.down_proj = LinearInt4(self.intermediate_size, self.hidden_size, out_dtype="fp16", bias=False, fusion=fusion)
 
     FUSED_MIN_ROWS = 512          # the fused launch always runs the 256x256 geometry
 
@@ -178,7 +192,7 @@ class LlamaMLP(nn.Module):
             a6 = norms if norms.dim() == 3 else ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
             act = ops.gate_up_silu_quant_f6(a6, outlier, outlier_scales, self._fused_gate_up())
             return down(act)
-        if norms.dim() == 2 and _FUSED_DECODE and ops.multi_gemm_fits(rows, self.intermediate_size, 2, self.hidden_size):
+        if norms.dim() == 2 and self.fusion.decode and ops.multi_gemm_fits(rows, self.intermediate_size, 2, self.hidden_size):
             # decode batches: gate_proj and up_proj in one launch (they read the same activation operand)
             gate, up = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, self._decode_gate_up())
             return down(ops.activate_fp16_i4(gate, up))
@@ -211,9 +225,10 @@ class LlamaAttention(nn.Module):
     harness); this class attends to the de-quantised projections it has just written to the cache (causal, RoPE at
     positions 0..len-1) -- the values a later decode step reads back."""
 
-    def __init__(self, config, layer_idx: int):
+    def __init__(self, config, layer_idx: int, fusion: DecodeFusion = None):
         super().__init__()
         self.config = config
+        self.fusion = fusion if fusion is not None else FUSION
         self.hidden_size = config.hidden_size
         self.num_heads = config.num_attention_heads
         self.head_dim = self.hidden_size // self.num_heads
@@ -223,10 +238,10 @@ class LlamaAttention(nn.Module):
             raise ValueError(f"hidden_size {self.hidden_size} is not divisible by num_heads {self.num_heads}")
         if self.head_dim != 128:
             raise ValueError("the INT4 KV kernels are built for head_dim 128 (as the reference's, punica_ops.cc:112)")
-        self.q_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False)
-        self.k_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False)
-        self.v_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False)
-        self.o_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False)
+        self.q_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False, fusion=fusion)
+        self.k_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False, fusion=fusion)
+        self.v_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="int4", bias=False, fusion=fusion)
+        self.o_proj = LinearInt4(self.hidden_size, self.hidden_size, out_dtype="fp16", bias=False, fusion=fusion)
         self.reorder_index = nn.Parameter(torch.randperm(self.hidden_size).to(torch.int16), requires_grad=False)
         self.rope_theta = float(getattr(config, "rope_theta", 1e4))
 
@@ -241,9 +256,9 @@ class LlamaAttention(nn.Module):
                 decode_kv: BatchedKvCacheInt4 | None) -> torch.Tensor:
         nh, hd = self.num_heads, self.head_dim
         rows = hidden_states[0].size(0)
-        pure_decode = (len(blen.prefills) == 0 and blen.decode == rows and _FUSED_KV_APPEND
+        pure_decode = (len(blen.prefills) == 0 and blen.decode == rows and self.fusion.kv_append
                        and ops.decode_gemm_fits(rows, self.hidden_size, self.hidden_size))
-        fuse_qkv = (pure_decode and _FUSED_DECODE and hidden_states[1].dim() == 2
+        fuse_qkv = (pure_decode and self.fusion.decode and hidden_states[1].dim() == 2
                     and ops.multi_gemm_fits(rows, self.hidden_size, 3, self.hidden_size))
         q_proj = None if fuse_qkv else self.q_proj(hidden_states)
         if pure_decode:
@@ -294,11 +309,12 @@ class LlamaAttention(nn.Module):
 class LlamaDecoderLayer(nn.Module):
     """reference llama.py:247-292."""
 
-    def __init__(self, config, layer_idx: int):
+    def __init__(self, config, layer_idx: int, fusion: DecodeFusion = None):
         super().__init__()
+        self.fusion = fusion if fusion is not None else FUSION
         self.hidden_size = config.hidden_size
-        self.self_attn = LlamaAttention(config=config, layer_idx=layer_idx)
-        self.mlp = LlamaMLP(config)
+        self.self_attn = LlamaAttention(config=config, layer_idx=layer_idx, fusion=fusion)
+        self.mlp = LlamaMLP(config, fusion=fusion)
         self.input_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = LlamaRMSNormInt4(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -341,16 +357,17 @@ class LlamaDecoderLayer(nn.Module):
             hs, inter = self.hidden_size, self.mlp.intermediate_size
             # only the ops the mask selects have to fit (each with ITS quantiser's bounds); the others run as separate launches
             need = (("rmsnorm", hs, 3, hs), ("reorder", hs, 1, hs), ("add_rmsnorm", inter, 2, hs), ("silu_mul", hs, 1, inter))
-            ok[rows] = all(ops.multi_q_gemm_fits(q, rows, n, nseg, k) for bit, (q, n, nseg, k) in enumerate(need) if (_FUSED_Q_MASK >> bit) & 1)
+            ok[rows] = all(ops.multi_q_gemm_fits(q, rows, n, nseg, k) for bit, (q, n, nseg, k) in enumerate(need) if (self.fusion.q_mask >> bit) & 1)
             # the launches that take the un-fused operands in _decode_fused_q
             ok[rows] = ok[rows] and ops.multi_gemm_fits(rows, hs, 3, hs) and ops.multi_gemm_fits(rows, inter, 2, hs) and ops.multi_gemm_fits(rows, hs, 1, inter)
         return ok[rows]
 
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
         rows = hidden_states.size(0) if torch.is_tensor(hidden_states) else 0
-        if (_FUSED_Q_DECODE and _FUSED_Q_MASK and _FUSED_DECODE and _FUSED_KV_APPEND and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
+        fu = self.fusion
+        if (fu.q_decode and fu.q_mask and fu.decode and fu.kv_append and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
                 and len(blen.prefills) == 0 and blen.decode == rows and decode_kv is not None and self._fused_q_fits(rows)):
-            return self._decode_fused_q(hidden_states, decode_kv, _FUSED_Q_MASK)
+            return self._decode_fused_q(hidden_states, decode_kv, fu.q_mask)
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
         return self.mlp(normed, residual=residual)                                           # ... and the second one (decode: in down_proj's launch)

@@ -11,10 +11,18 @@ this only changes which tile kernel -- and hence which fixed K order -- the W4A4
 """
 from __future__ import annotations
 
+import fnmatch
+
 import torch
 from torch import nn
 
 from .modelutils_llama import capture_first_layer_inputs
+
+
+def pattern_match(patterns, source_list):
+    """The names of ``source_list`` that match any of the shell-style ``patterns`` (reference eval.py:6-11; main.py:314 picks the
+    lm-eval tasks with it).  Unique, in the order of ``source_list`` (the reference returns them in set order)."""
+    return [name for name in source_list if any(fnmatch.fnmatchcase(name, pat) for pat in patterns)]
 
 
 def _for_batch(kw, n):
@@ -37,7 +45,10 @@ def llama_eval(model, testenc, dev, offload: bool = False, rows_per_call: int = 
         layer = layers[i].to(dev)
         for j in range(0, nsamples, step):
             n = min(step, nsamples - j)
-            outs[j:j + n] = layer(inps[j:j + n], **(kw if n == 1 else _for_batch(kw, n)))[0]
+            o = layer(inps[j:j + n], **(kw if n == 1 else _for_batch(kw, n)))
+            o = o[0] if isinstance(o, (tuple, list)) else o            # (decoder layers of newer transformers return the bare tensor)
+            assert o.shape[0] == n, f"layer {i} returned {tuple(o.shape)} for {n} samples"
+            outs[j:j + n] = o
         layers[i] = layer.cpu() if offload else layer
         inps, outs = outs, inps
     head = model.lm_head.to(dev)

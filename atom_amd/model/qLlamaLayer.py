@@ -13,7 +13,6 @@ reference's pin) and 5.x module layouts alike.
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -23,9 +22,6 @@ from .. import ops as _ops
 from .qLinearLayer import QLinearLayer
 from .quant import (ActCodes, Quantizer, _reorder_index_i16, attach_codes, get_codes, hip_act_quant,  # noqa: F401
                     want_wide_codes)
-
-
-_USE_SDPA = os.environ.get("ATOM_ATTN_SDPA", "0") == "1"
 
 
 def rotate_half(x):
@@ -150,6 +146,9 @@ class QLlamaAttention(nn.Module):
         super().__init__()
         self.abits = args.abits
         self.q_kv_cache = args.kv_cache
+        # opt-in through the configuration namespace the reference passes around (args.attn_sdpa = True; absent = False): fused attention
+        # instead of the reference's materialised score matrix.  (Rounds 2-4 read an environment variable at import.)
+        self.use_sdpa = bool(getattr(args, "attn_sdpa", False))
         self.config = getattr(originalAttn, "config", None)
         self.hidden_size = _cfg(originalAttn, "hidden_size")
         self.num_heads = _cfg(originalAttn, "num_heads")
@@ -211,8 +210,8 @@ class QLlamaAttention(nn.Module):
 
         if self.q_kv_cache:
             v = self.v_quant(v)
-        if _USE_SDPA and not output_attentions:
-            # opt-in (ATOM_ATTN_SDPA=1): fused attention instead of the reference's materialised score matrix
+        if self.use_sdpa and not output_attentions:
+            # opt-in (args.attn_sdpa): fused attention instead of the reference's materialised score matrix
             # (qLlamaLayer.py:262-290).  Same mathematics, FP32 softmax inside the kernel; not bit-identical.
             attn_output = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask)
             attn_weights = None

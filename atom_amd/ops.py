@@ -282,7 +282,7 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
                                    b_keeper_scale.data_ptr(), d.data_ptr(), m, n, k, GROUP_SIZE, GROUP_SIZE,
                                    _LAYOUTS[scale_layout] | (L.AB_F6 if a_wide == "f6" else (L.A_WIDE if a_wide else 0))
                                    | (L.B_F6S if a_wide == "f6" and getattr(b, "atom_f6s", None) is not None else 0)
-                                   | (L.B_SCALE_PAIRS if a_wide == "f6" and getattr(b, "atom_pairs", False) else 0),
+                                   | (L.B_SCALE_PAIRS if (getattr(b, "atom_pairs", False) if a_wide == "f6" else _pairs_flag(b_scale, n)) else 0),
                                    L.ptr(ws), ws_bytes,
                                    L.current_stream(a.device))
     L.check(st, "atom_gemm_w4a4_f16_ws")
@@ -561,6 +561,27 @@ def scale_pairs_shared(b_scale: torch.Tensor, n: int) -> bool:
         return False
     s = b_scale.reshape(-1, n)
     return bool((s[:, 0::2] == s[:, 1::2]).all().item())
+
+
+def _pairs_flag(b_scale: torch.Tensor, n: int) -> bool:
+    """scale_pairs_shared() of a weight-scale tensor, remembered ON the tensor object together with its version counter: one device
+    round trip per weight (and per in-place rewrite), none for a model's parameters afterwards.  False during graph capture for a tensor
+    not seen before (the generic kernels are always right)."""
+    tag = getattr(b_scale, "_atom_pairs", None)
+    try:
+        ver = b_scale._version
+    except RuntimeError:                      # inference tensors have no version counter: check every time
+        ver = None
+    if tag is not None and ver is not None and tag[0] == ver:
+        return tag[1]
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    v = scale_pairs_shared(b_scale, n)
+    try:
+        b_scale._atom_pairs = (ver, v)
+    except AttributeError:
+        pass
+    return v
 
 
 def repack_weight_f6(b4: torch.Tensor, b_scale: torch.Tensor = None) -> torch.Tensor:

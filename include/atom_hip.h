@@ -163,6 +163,18 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
                           void *D, int64_t M, int64_t N, int64_t K_total,
                           int group, int keeper, int scale_layout,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The FP32 summation order atom_gemm_w4a4_f16 (with_workspace = 0) / atom_gemm_w4a4_f16_ws with a workspace of
+ * atom_gemm_w4a4_workspace_bytes() bytes (with_workspace = 1) applies to PACKED (reference-format) operands of this shape -- a host-side
+ * function of the shape alone, what the parity tests restate the arithmetic for (oracle/atom_oracle.c):
+ *   1        the K steps (int4 groups, then the keeper) in order: the tile kernels -- among them the mid-size-batch kernel
+ *            (gemm_w4a4_mid.hip: 64 x 64 tiles on a deep LDS ring, M > 16 once the tiles fill a good part of the chip, up to 1024 rows)
+ *   2, 4     two / four ordered ranges of the K steps (the BF6 K-group kernels behind the re-coding route; see ATOM_AB_F6)
+ *   8        the decode-batch kernel: the G + 1 steps dealt to 8 waves in consecutive slices, partial sums added in wave order
+ *   64       the one- / two-token dot-product kernel: groups dealt to 16 quad leaders, 64-lane butterfly, keeper last
+ *   63       the staged dot-product kernel (M <= 7 with a K too long for the decode-batch kernel): per-lane partial sums
+ *   100 + s  split-K over s workgroups through the workspace, partial sums added in split order
+ *   0        unsupported shape */
+int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_workspace);
 
 /*
  * Same GEMM; epilogue asymmetric-quantises every 128-wide output group to u4:

@@ -55,3 +55,29 @@ def test_reference_callers_resolve_to_our_modules(tmp_path):
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert "DROPIN_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_dropin_eval_provides_every_name_the_reference_driver_takes(tmp_path):
+    """main.py:4,12,211 -- ``from eval import *``, ``from eval import pattern_match``, ``eval_func = opt_eval`` -- with atom_amd/dropin
+    ahead of the reference's model/ directory: the import must not fail, pattern_match must behave like the reference's, llama_eval is
+    ours, and opt_eval (OPT: out of scope) resolves to the reference's own function behind us on the path."""
+    (tmp_path / "tqdm.py").write_text("def tqdm(x, *a, **k):\n    return x\n")      # (the reference's eval.py imports it)
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(os.path.join(ROOT, 'atom_amd', 'dropin'))!r}, {ROOT!r}, {str(tmp_path)!r}]
+        sys.path.append({REF!r})
+        from eval import *
+        from eval import pattern_match
+        import eval as E, importlib.util
+        assert E.__file__.startswith({ROOT!r})
+        names = ["arc_easy", "arc_challenge", "piqa", "boolq", "hellaswag"]
+        spec = importlib.util.spec_from_file_location("ref_eval", {REF!r} + "/eval.py")
+        ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+        for pats in (["arc_*"], ["piqa", "bool?"], ["*"], ["nothing"], ["arc_easy", "arc_*"]):
+            assert sorted(pattern_match(pats, names)) == sorted(ref.pattern_match(pats, names)), pats
+        assert llama_eval.__module__ == "atom_amd.model.eval"
+        assert callable(opt_eval) and E._reference_eval().__file__.startswith({REF!r}) and callable(E._reference_eval().opt_eval)
+        print("EVAL_OK")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert "EVAL_OK" in out.stdout, out.stderr[-3000:]

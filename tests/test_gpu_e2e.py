@@ -136,7 +136,7 @@ def test_decoder_layer_prefill_then_decode_is_consistent():
         return KvPoolInt4(num_layers=2, num_heads=4, head_dim=128, capacity=16, block_len=16, device=dev)
 
     import atom_amd.e2e.llama as E
-    fq0, E._FUSED_Q_DECODE = E._FUSED_Q_DECODE, False   # (the spy hooks the stand-alone reorder op: keep it a separate launch here)
+    fq0, E.FUSION.q_decode = E.FUSION.q_decode, False   # (the spy hooks the stand-alone reorder op: keep it a separate launch here)
     ops.reorder_fp16_i4 = spy
     # path A: prefill S, then one decode step
     pool = fresh_pool()
@@ -151,7 +151,7 @@ def test_decoder_layer_prefill_then_decode_is_consistent():
     cs2 = [KvCacheInt4(pool2, n + 1) for n in lens]
     y_full = layer(torch.cat(x), BatchLenInfo([n + 1 for n in lens], 0, dev), BatchedKvCacheInt4(cs2), None)
     ops.reorder_fp16_i4 = orig_reorder
-    E._FUSED_Q_DECODE = fq0
+    E.FUSION.q_decode = fq0
     rows = [lens[0], lens[0] + 1 + lens[1]]
     a_dec, a_full = attn_in[1].float(), attn_in[2][rows].float()
     assert (a_dec - a_full).abs().max().item() <= 2e-3 * a_full.abs().max().item()
@@ -282,11 +282,11 @@ def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
     ctx = 40
     x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
     outs, caches = [], []
-    mask0 = E._FUSED_Q_MASK
+    mask0 = E.FUSION.q_mask
     try:
-        E._FUSED_Q_MASK = 15                                   # all four quantisers fused (the default fuses reorder -> o_proj only)
+        E.FUSION.q_mask = 15                                   # all four quantisers fused (the default fuses reorder -> o_proj only)
         for fq in (False, True):
-            E._FUSED_Q_DECODE = fq
+            E.FUSION.q_decode = fq
             pool = KvPoolInt4(num_layers=1, num_heads=4, head_dim=128, capacity=bsz * 4, block_len=16, device=dev)
             g = torch.Generator(device="cuda").manual_seed(9)
             pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
@@ -297,8 +297,8 @@ def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
             outs.append(layer(x, BatchLenInfo([], bsz, dev), None, BatchedKvCacheInt4(cs)))
             caches.append((pool.buf.clone(), pool.param.clone()))
     finally:
-        E._FUSED_Q_DECODE = True
-        E._FUSED_Q_MASK = mask0
+        E.FUSION.q_decode = True
+        E.FUSION.q_mask = mask0
     if bsz >= 2:
         assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
         assert torch.equal(outs[0], outs[1])
@@ -314,7 +314,7 @@ def test_decoder_layer_quantisers_inside_the_gemms_equal_separate_launches(bsz):
 def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     """A decode step of atom_amd.e2e.LlamaDecoderLayer with the round-3 launch fusions (q / k / v in one launch, gate / up in one
     launch, the second residual add inside down_proj's launch: 14 -> 10 launches) against the same step with one launch per
-    projection (ATOM_FUSED_DECODE = 0, the reference's call order llama.py:259-292): same cache contents and same output, bit for
+    projection (DecodeFusion.decode = False, the reference's call order llama.py:259-292): same cache contents and same output, bit for
     bit (batch 1: o_proj with its quantiser inside the launch runs the decode-batch kernel, o_proj alone the dot-product kernel --
     two summation orders, one fp16 ulp; every other projection of a one-token step takes the dot-product kernel on both sides)."""
     import atom_amd.e2e.llama as E
@@ -329,7 +329,7 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
     outs, caches = [], []
     for fused in (False, True):
-        E._FUSED_DECODE = fused
+        E.FUSION.decode = fused
         pool = KvPoolInt4(num_layers=1, num_heads=4, head_dim=128, capacity=bsz * 4, block_len=16, device=dev)
         g = torch.Generator(device="cuda").manual_seed(9)
         pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
@@ -339,7 +339,7 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
             c.acquire_one()
         outs.append(layer(x, BatchLenInfo([], bsz, dev), None, BatchedKvCacheInt4(cs)))
         caches.append((pool.buf.clone(), pool.param.clone()))
-    E._FUSED_DECODE = True
+    E.FUSION.decode = True
     if bsz >= 2:
         assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
         assert torch.equal(outs[0], outs[1])
@@ -370,7 +370,7 @@ def test_fused_quantiser_query_is_the_launchers_predicate_at_wide_hidden_sizes()
         ops.dense_layer_gemm_i4_multi_q("reorder", x, layer.self_attn.o_proj.single(), reorder_index=layer.self_attn.reorder_index)
     outs = []
     for fq in (True, False):
-        E._FUSED_Q_DECODE = fq
+        E.FUSION.q_decode = fq
         try:
             pool = KvPoolInt4(num_layers=1, num_heads=64, head_dim=128, capacity=8, block_len=16, device=dev)
             g = torch.Generator(device="cuda").manual_seed(9)
@@ -381,6 +381,6 @@ def test_fused_quantiser_query_is_the_launchers_predicate_at_wide_hidden_sizes()
                 c.acquire_one()
             outs.append(layer(x, BatchLenInfo([], 2, dev), None, BatchedKvCacheInt4(cs)))
         finally:
-            E._FUSED_Q_DECODE = True
+            E.FUSION.q_decode = True
     assert layer._fused_q_fits(2) is False and layer._fused_q_fits(1) is True
     assert torch.equal(outs[0], outs[1])

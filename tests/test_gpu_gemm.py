@@ -149,7 +149,8 @@ def test_gemm_bit_exact_vs_c_contract():
     for (M, N, K) in [(40, 128, 640), (257, 64, 384), (3, 320, 1152), (300, 128, 640), (600, 192, 640)]:      # (short K: no split-K through the workspace)
         d = rand_gemm_operands(M, N, K, seed=M * 7 + N)
         out = t2n(ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain"))
-        order = 8 if (1 < M <= 256 and ops.multi_gemm_fits(M, N, 1, K)) else 1      # (== the dispatch's decode-batch condition)
+        order = ops.L.lib().atom_gemm_w4a4_packed_order(M, N, K, 1)                 # the library's own statement of its dispatch
+        assert order in (1, 8)
         want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=order)
         assert np.array_equal(bits16(out), bits16(want)), f"{M}x{N}x{K}: {(bits16(out) != bits16(want)).sum()} elements differ"
 
@@ -719,3 +720,36 @@ def test_two_tokens_take_the_decode_batch_kernel_up_to_k_4096():
     out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
     want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=8)
     assert np.array_equal(bits16(t2n(out)), bits16(want))
+
+
+# mid-size batches in the packed format: gemm_w4a4_mid.hip (64 x 64 tiles over the whole K range on a deep LDS ring; 8 waves on 16
+# stages up to 256 tiles, 4 waves on 8 stages beyond): ragged token tiles, one to 41 int4 groups (fewer stages than ring slots and
+# more), both scale layouts, pair-shared and per-channel weight scales
+MID = [(17, 6144, 256), (64, 8192, 384), (100, 4096, 1152), (256, 4096, 4096), (300, 4096, 640), (129, 13824, 1280),
+       (512, 4096, 2176), (1000, 1024, 5248), (77, 6208, 1408)]
+
+
+@pytest.mark.parametrize("M,N,K", MID)
+@pytest.mark.parametrize("layout", ["ref", "plain"])
+def test_gemm_mid_batches_bit_exact_vs_c_contract(M, N, K, layout):
+    """The mid-size-batch kernel sums the K steps in order -- the contract of include/atom_hip.h as oracle/atom_oracle.c restates it
+    (oracle_gemm_w4a4_f16) -- so whole outputs are compared bit for bit on sampled rows and columns (the C loop is O(M N K))."""
+    from tests import c_oracle as C
+    ops = _ops()
+    assert ops.L.lib().atom_gemm_w4a4_packed_order(M, N, K, 1) == 1 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0
+    d = rand_gemm_operands(M, N, K, seed=M * 3 + N + K)
+    if (M + N) % 2:                                          # per-channel weight scales: the kernels without the shared products
+        g = np.random.default_rng(M)
+        d["sB"] = g.uniform(0.005, 0.05, size=d["sB"].shape).astype(np.float16)
+    t = to_device(d, layout)
+    out = ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout)
+    assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout))
+    g = np.random.default_rng(N)
+    rows = np.unique(np.concatenate([[0, M - 1, min(63, M - 1), min(64, M - 1)], g.integers(0, M, 12)]))
+    cols = np.unique(np.concatenate([np.arange(0, 72), [N - 1, N - 64, N - 33], g.integers(0, N, 100)]))
+    want = C.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"][cols]), d["sA"][rows].T, d["sB"][:, cols], d["qa8"][rows],
+                  d["qb8"][cols], d["sA8"][rows], d["sB8"][cols])
+    got = t2n(out)[np.ix_(rows, cols)]
+    assert np.array_equal(bits16(got), bits16(want)), f"{(bits16(got) != bits16(want)).sum()} of {got.size} sampled elements differ"
+    exact = gemm_ref_torch_f64(d).cpu().numpy()
+    assert_gemm_close(t2n(out), exact, f"mid batch {M}x{N}x{K} {layout}")
