@@ -56,13 +56,17 @@ static bool skinny_fits(int64_t M, int64_t N, int64_t K_total) {
   return N * items <= 420000;
 }
 
-// Mid-size batches in the packed (reference) format: 64x64 tiles over the whole K range on a deep LDS ring (gemm_w4a4_mid.hip).  Takes
-// a shape once its tiles fill a good part of the chip -- below that the decode-batch kernel's one-workgroup-per-16-features grid wins --
-// and up to the batch where the re-coding route to the BF6 kernels (f6_route) pays for its extra launch.
+// Mid-size batches in the packed (reference) format: 64x64 tiles over the whole K range on a deep LDS ring (gemm_w4a4_mid.hip, the INT8
+// form).  Its K step costs ~120 instructions per wave -- widening nibbles, converting integers -- against ~60 of the BF6 form, so it
+// only takes what neither the decode-batch kernel (skinny_fits: it wins wherever it applies, profiles/r05/mid_ab.txt) nor a cheap
+// re-coding reaches: up to 256 rows, at most one tile per CU, K up to 11,264 (64 x 13824 x 5120: 27.3 -> 20.0 us, 256 x 4096 x 11008:
+// 48.0 -> 38.9 us without a workspace; at 64 x 5120 x 13824 the split-K tiles stay ahead, 32.5 vs 47.6).
+static bool skinny_fits(int64_t M, int64_t N, int64_t K_total);
 static bool mid_fits(int64_t M, int64_t N, int64_t K_total) {
   if (!ATOM_TUNE("ATOM_MID", 1) || (N % 64) != 0) return false;
-  const int64_t tiles = ((M + 63) / 64) * (N / 64);
-  return M > 16 && M <= ATOM_TUNE("ATOM_MID_MAX_M", 1024) && tiles >= ATOM_TUNE("ATOM_MID_MIN_TILES", 96);
+  const int64_t tiles = ((M + 63) / 64) * (N / 64), items = (K_total - kKeeper) / kGroup + 1;
+  if (ATOM_TUNE("ATOM_MID_MIN_TILES", 0)) return tiles >= ATOM_TUNE("ATOM_MID_MIN_TILES", 0) && M <= ATOM_TUNE("ATOM_MID_MAX_M", 1024);   // (tuning builds)
+  return M > 16 && M <= 256 && tiles >= 96 && tiles <= 256 && items <= 88 && !skinny_fits(M, N, K_total);
 }
 
 // Tile geometry of the F6 kernels by shape (measured: profiles/r02_f6_dispatch.txt, profiles/r03_f6_dispatch.txt -- every geometry forced
@@ -76,14 +80,24 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int64_t t64 = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t rounds = (t256 + 255) / 256, steps = (K_total - kKeeper) / kGroup + 2;
+  // up to two 64x64 tiles per CU: the mid-size-batch kernel (gemm_w4a4_mid.hip; needs the float32 weight scales, else launch_gemm_f6
+  // falls back to the 128x128 geometry -- the same K order).  Same box, us, K-group / 128x128 kernels -> this one
+  // (profiles/r05/mid_f6c.txt): 64 x 4096 x 4096 13.6 -> 9.9, 256 x 4096 x 4096 14.3 -> 10.6, 512 x .. 16.9 -> 16.4, 64 x 13824 x 5120
+  // 19.1 -> 12.2, 64 x 5120 x 13824 40.5 -> 24.6, 256 x 4096 x 11008 33.7 -> 22.9, 256 x 5120 x 5120 18.2 -> 17.3; beyond 512 tiles the
+  // larger tiles win (1024 x 4096 x 4096 22.5 vs 29.2, 256 x 13824 x 5120 25.7 vs 33.6, 256 x 11008 x 4096 21.0 vs 23.2)
+  if ((N % 64) == 0 && ((M + 63) / 64) * (N / 64) <= 512 && ATOM_TUNE("ATOM_F6_MID", 1)) return 20;
   // (one round: from 129 tiles -- 768x11008x4096, 129 tiles: 47.7 us against 51.6 on 128x128 tiles; with 128 or fewer the 256x128
   // kernel below has a tile for every CU.  Several rounds: only while >= 60 % of the slots are busy.  profiles/r03_f6_dispatch.txt)
   if (t256 >= 129 && (rounds == 1 || 5 * t256 >= 3 * rounds * 256)) return 0;
   // at most one tile per CU: a lone 4-wave workgroup is latency-bound (barrier, fragment loads: ~1 us per K step), so two
   // groups of 4 waves share the tile and its K steps (profiles/r02_mid_m.txt: 1024x4096x4096 33.1 -> 23.4 us, 512x..: 26.3 ->
   // 18.4).  The result is the sum of two (four) ordered ranges of the K steps (atom_gemm_w4a4_f6_order).
+#ifdef ATOM_TOOLS   // (rounds 2-4: up to 256 tiles of 64x128 four / two K groups shared the tile; the mid-size-batch kernel above takes those shapes now)
   if (steps >= 16 && t64 <= 256) return 12;               // ... four groups on a 64x128 tile (K = 4096: 17.9 -> 15.0 us at 256 rows)
   if (steps >= 8 && t64 <= 256) return 9;
+#else
+  (void)t64;
+#endif
   if (steps >= 8 && t128 <= 256) return 6;
   // more 128x128 tiles than CUs, but at most one 256x128 tile per CU and more than half of them busy: the 256x128 q-step kernel
   // (ATOM_B_F6S weights; launch_gemm_f6 runs the 128x128 geometry otherwise -- same K order)
@@ -97,7 +111,7 @@ extern "C" {
 int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   const int cfg = f6_pick_cfg(M, N, K_total);
-  return cfg == 12 ? 4 : ((cfg == 5 || cfg == 6 || cfg == 9) ? 2 : 1);
+  return cfg == 12 ? 4 : ((cfg == 5 || cfg == 6 || cfg == 9) ? 2 : 1);   // (12 / 9 / 5: tuning builds only)
 }
 
 const char *atom_version(void) { return "atom_hip 0.1 (gfx950)"; }

@@ -2501,6 +2501,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 1>, false, 2>(p, s);
     return f6::launch_x16<f6::Cfg<128, 128, 2, 3, 3, 2>, false, 2>(p, s);
   }
+#ifdef ATOM_TOOLS   // the 64x128 K-group kernels of rounds 2-4: no shape is dispatched to them since the mid-size-batch kernel (cfg 20)
   if (cfg == 9) {                                                              // 64x128 (32-token wave tiles), groups half a step apart
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 1>, false, 2, true>(p, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 3, 3, 2>, false, 2, true>(p, s);
@@ -2509,6 +2510,7 @@ int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s) {
     if (p.sB32) return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 1>, false, 4>(p, s);
     return f6::launch_x16<f6::Cfg<64, 128, 1, 2, 4, 2>, false, 4>(p, s);
   }
+#endif
 #ifdef ATOM_TOOLS   // tuning builds only
   if (cfg == 51 && p.sB32) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 1>>(p, s);   // tuning: the two scale forms of cfg 3
   if (cfg == 52) return f6::launch_x16<f6::Cfg<128, 128, 2, 2, 3, 2>>(p, s);

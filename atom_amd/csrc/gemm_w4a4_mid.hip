@@ -301,10 +301,11 @@ constexpr int W_OFF = 0, A_OFF = 7168, SB_OFF = 14336, STAGE = 14592;
 // keeper halves in the same slot: the packed kernel's layout (4 + 4 pieces in MFMA order, fp16 weight scales, token scales as dwords)
 constexpr int K_W = 0, K_A = 4096, K_SB = 8192, K_SA = 8448;
 
-template <int NS_, bool PAIR_, int ABL_ = 0>
+template <int NS_, bool PAIR_, int ABL_ = 0, bool S16_ = false>
 struct Cfg {
   static constexpr int NW = 8, NS = NS_, NT = 512;
   static constexpr bool PAIR = PAIR_;
+  static constexpr bool S16 = S16_;                // weights without appended float32 scales (atom_repack_weight_f6): the dense fp16 array, converted per step
   static constexpr int ABL = ABL_;                 // tools build only: 1 no LDS-DMA in the K loop, 2 no barrier, 4 no MFMA, 8 no LDS loads, 16 no de-quantisation
   static constexpr int PPW = 2;                    // DMA instructions per wave and stage: waves 0..6 weight piece w + token piece w, wave 7 the scales
   static constexpr int LDS_BYTES = NS * STAGE;
@@ -333,6 +334,9 @@ __device__ __forceinline__ v4f lds128f(unsigned a) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
   return r;
 }
+template <bool PAIR_, bool KEEPER_>
+struct DeqTag { static constexpr bool value = PAIR_, keeper = KEEPER_; };   // what a de-quantisation runs on: a BF6 step (shared products?) or the keeper
+
 struct KeeperDma {         // per lane: the keeper pieces of the packed kernel (row * 128 + 16 * source chunk), the wave's operand and scales
   unsigned kvoff, svoff;
   const uint8_t *d8;
@@ -362,7 +366,9 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   // lanes), wave 7 the 64 float32 weight scales (twice: the count per wave stays uniform)
   const uint8_t *wsrc0 = p.B4 + (int64_t)n0 * PITCH, *asrc0 = p.A4 + (int64_t)m0 * PITCH;
   const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
-  const float *sbsrc0 = p.sB32 + n0;
+  const float *sbsrc0 = C::S16 ? reinterpret_cast<const float *>(p.sB) : p.sB32 + n0;   // (S16: fp16 [G][N]; 128 bytes per tile and group)
+  const int64_t sbstep = C::S16 ? p.N / 2 : p.f6_rows_b;                                   // floats between groups
+  const unsigned sbvoff = C::S16 ? (unsigned)min(n0 + 2 * lane, p.N - 2) * 2u : (unsigned)lane * 4u;
   const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
   const bool piece_ok = wave < 6 || (wave == 6 && lane < 32);
   KeeperDma kd;
@@ -390,13 +396,13 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
         lds_dma_sv<16>(asrc, voff, slot + A_OFF + wave * 1024);
       }
     } else {
-      lds_dma_sv<4>(sbsrc, (unsigned)lane * 4u, slot + SB_OFF);
-      lds_dma_sv<4>(sbsrc, (unsigned)lane * 4u, slot + SB_OFF);
+      lds_dma_sv<4>(sbsrc, sbvoff, slot + SB_OFF);
+      lds_dma_sv<4>(sbsrc, sbvoff, slot + SB_OFF);
     }
   };
   auto issue = [&](int st, unsigned slot) {                // any stage (prologue and the last NS - 1 steps)
     if (st < G) {
-      issue_int4(wsrc0 + st * wstep, asrc0 + st * astep, sbsrc0 + (int64_t)st * p.f6_rows_b, slot);
+      issue_int4(wsrc0 + st * wstep, asrc0 + st * astep, sbsrc0 + (int64_t)st * sbstep, slot);
     } else {                                               // keeper half st - G: piece `wave` of the packed kernel's stage + a scale piece
       lds_dma_sv<16>(kd.d8 + (st - G) * 64, kd.kvoff, slot + wave * 1024);
       if (wave & 1) lds_dma_sv<2>(kd.s8, kd.svoff, slot + K_SA);
@@ -404,14 +410,14 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     }
   };
 #pragma unroll 1
-  for (int s = 0; s < NS - 1; ++s) issue(min(s, T - 1), lds0 + s * STAGE);
+  for (int s = 0; s < min(NS - 1, T); ++s) issue(s, lds0 + s * STAGE);
 
   const int l15 = lane & 15, kb = lane >> 4;
   // fragment (h, k) row l15 = record 32 h + 2 l15 + k; token block tb row l15 = record 32 (tb >> 1) + (tb & 1) + 2 l15
   const unsigned aw = lds0 + W_OFF + (32 * h + 2 * l15) * PITCH + kb * 24;                  // + PITCH: k = 1
   const unsigned aa = lds0 + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + kb * 24;
   const unsigned as_ = lds0 + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + 100;  // the token's float32 scale
-  const unsigned asb = lds0 + SB_OFF + (32 * h + 8 * kb) * 4;
+  const unsigned asb = lds0 + SB_OFF + (32 * h + 8 * kb) * (C::S16 ? 2 : 4);
 
   float c[2][4];
 #pragma unroll
@@ -430,7 +436,15 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   // c[k][r] = fma(idot, sa * sb, c): token = the lane's, feature 32 h + 8 kb + 2 r + k (the contract; PAIR: one product per channel pair)
   auto dequant = [&](const Pend &q, auto pair) {
     constexpr bool PR = decltype(pair)::value;
-    const float sbv[8] = {q.sb0[0], q.sb0[1], q.sb0[2], q.sb0[3], q.sb1[0], q.sb1[1], q.sb1[2], q.sb1[3]};
+    float sbv[8];
+    if constexpr (C::S16 && !decltype(pair)::keeper) {     // eight halves in sb0
+      const half_t *hv = reinterpret_cast<const half_t *>(&q.sb0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sbv[j] = (float)hv[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sbv[j] = q.sb0[j]; sbv[4 + j] = q.sb1[j]; }
+    }
     float s[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -445,18 +459,23 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
         asm volatile("" : "+v"(c[k][r]));
       }
   };
-  // One K step on the stage at ring byte offset `so`: every LDS load of the step is requested first (fragments, token scale, weight
-  // scales -- into the register set `cur`), the LDS-DMA of the stage NS - 1 ahead is issued behind them (its ~100 issue cycles per piece
-  // overlap the loads' latency), the previous step's products (`prv`) are de-quantised, then this step's MFMAs (consumed next step)
-  auto compute = [&](unsigned so, Pend &cur, const Pend &prv, auto dma) {
+  // One K step on the stage in ring slot SL (compile time: the slot's byte offset rides in the loads' immediate offsets -- no address
+  // arithmetic at all) or at the run-time byte offset `so` (SL < 0: the last steps).  Every LDS load of the step is requested first
+  // (fragments, token scale, weight scales -- into the register set `cur`), the LDS-DMA of the stage NS - 1 ahead is issued behind
+  // them (its ~100 issue cycles per piece overlap the loads' latency), the previous step's products (`prv`) are de-quantised, then
+  // this step's MFMAs (consumed in the next step).
+  auto compute = [&](auto slc, unsigned so, Pend &cur, const Pend &prv, auto dma) {
+    constexpr int SL = decltype(slc)::value;
+    constexpr int O = SL < 0 ? 0 : SL * STAGE;
+    const unsigned xw = SL < 0 ? aw + so : aw, xa = SL < 0 ? aa + so : aa, xs = SL < 0 ? as_ + so : as_, xb = SL < 0 ? asb + so : asb;
     v2u f[9];                                              // w0, w1, bf: three 8-byte pieces each
     if constexpr (!(C::ABL & 8)) {
-      f[0] = lds64<0>(aw + so); f[1] = lds64<8>(aw + so); f[2] = lds64<16>(aw + so);
-      f[3] = lds64<PITCH>(aw + so); f[4] = lds64<PITCH + 8>(aw + so); f[5] = lds64<PITCH + 16>(aw + so);
-      f[6] = lds64<0>(aa + so); f[7] = lds64<8>(aa + so); f[8] = lds64<16>(aa + so);
-      cur.sa = lds32f<0>(as_ + so);
-      cur.sb0 = lds128f<0>(asb + so);
-      cur.sb1 = lds128f<16>(asb + so);
+      f[0] = lds64<O>(xw); f[1] = lds64<O + 8>(xw); f[2] = lds64<O + 16>(xw);
+      f[3] = lds64<O + PITCH>(xw); f[4] = lds64<O + PITCH + 8>(xw); f[5] = lds64<O + PITCH + 16>(xw);
+      f[6] = lds64<O>(xa); f[7] = lds64<O + 8>(xa); f[8] = lds64<O + 16>(xa);
+      cur.sa = lds32f<O>(xs);
+      cur.sb0 = lds128f<O>(xb);
+      if constexpr (!C::S16) cur.sb1 = lds128f<O + 16>(xb);
     } else {
 #pragma unroll
       for (int i = 0; i < 9; ++i) f[i] = v2u{so + i, so};
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(C::ABL & 1)) dma();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(C::ABL & 16)) dequant(prv, std::integral_constant<bool, C::PAIR>());
+    if constexpr (!(C::ABL & 16)) dequant(prv, DeqTag<C::PAIR, false>());
     else { c[0][0] += prv.acc[0][0] + prv.acc[1][3]; asm volatile("" : "+v"(c[0][0])); }
     // The loads above are invisible to the compiler: until they have landed, their destination registers must stay allocated and
     // unread -- also the components nothing reads later (PAIR uses every other weight scale), which the register allocator would
@@ -487,38 +506,58 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     }
   };
 
-  int slot = 0, dslot = NS - 1, step = 0;
-  auto advance = [&]() {
-    slot = slot + 1 == NS ? 0 : slot + 1;
-    dslot = dslot + 1 == NS ? 0 : dslot + 1;
-    ++step;
+  // `allowed` stages of this wave's LDS-DMA may still be in flight (everything older has landed), then the workgroup barrier: every
+  // wave's pieces of the step's stage are in LDS, and every wave is done reading the slot of the previous step
+  auto sync = [&](int allowed) {
+    if constexpr (!(C::ABL & 1)) {
+      if (allowed >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (NS - 2)) : "memory");
+      else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
+      else if (allowed == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * 2) : "memory");
+      else if (allowed == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * 3) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (!(C::ABL & 2)) __builtin_amdgcn_s_barrier();
   };
-  auto sync = [&]() {
-    if constexpr (!(C::ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (NS - 2)) : "memory");   // this wave's pieces of stage `step` have landed
-    if constexpr (!(C::ABL & 2)) __builtin_amdgcn_s_barrier();                 // ... everybody's; and the slot of step - 1 is free
-  };
-  {                                                        // steps whose LDS-DMA is an int4 stage: running pointers, no selection; two per trip
+  static_assert(NS - 2 <= 4, "sync(): one immediate per possible count");
+  int step = 0;
+  if constexpr (NS == 4) {
+    // steps whose LDS-DMA is an int4 stage, NS per trip: ring slots, register sets and DMA destinations are compile-time constants,
+    // the operand pointers run
     const uint8_t *wsrc = wsrc0 + (NS - 1) * wstep, *asrc = asrc0 + (NS - 1) * astep;
-    const float *sbsrc = sbsrc0 + (int64_t)(NS - 1) * p.f6_rows_b;
-    auto dma = [&]() {
-      issue_int4(wsrc, asrc, sbsrc, lds0 + dslot * STAGE);
-      wsrc += wstep; asrc += astep; sbsrc += p.f6_rows_b;
+    const float *sbsrc = sbsrc0 + (int64_t)(NS - 1) * sbstep;
+    auto one = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      sync(NS - 2);
+      const unsigned dst = lds0 + ((k + NS - 1) % NS) * STAGE;
+      auto dma = [&]() {
+        issue_int4(wsrc, asrc, sbsrc, dst);
+        wsrc += wstep; asrc += astep; sbsrc += sbstep;
+      };
+      compute(std::integral_constant<int, k>(), 0u, P[k & 1], P[(k & 1) ^ 1], dma);
     };
-    while (step + NS < G) {
-      sync(); compute((unsigned)(slot * STAGE), P[0], P[1], dma); advance();
-      sync(); compute((unsigned)(slot * STAGE), P[1], P[0], dma); advance();
+    static_assert(NS == 4, "the unrolled trip is written for a ring of four");
+    while (step + 2 * NS - 2 < G) {                        // the trip's last request is stage step + 2 NS - 2
+      one(std::integral_constant<int, 0>());
+      one(std::integral_constant<int, 1>());
+      one(std::integral_constant<int, 2>());
+      one(std::integral_constant<int, 3>());
+      step += NS;
     }
   }
-  // the last steps (their LDS-DMA: the remaining int4 stages, the keeper halves, then repeats into dead slots: the count stays uniform)
+  // the remaining steps (their LDS-DMA: the last int4 stages, then the keeper's halves, then nothing: the waits count what is in flight)
   while (step < G) {
-    auto dma = [&]() { issue(min(step + NS - 1, T - 1), lds0 + dslot * STAGE); };
-    sync();
-    if (step & 1) compute((unsigned)(slot * STAGE), P[1], P[0], dma);
-    else compute((unsigned)(slot * STAGE), P[0], P[1], dma);
-    advance();
+    const int slot = step % NS;
+    sync(min(NS - 2, T - step - 1));
+    auto dma = [&]() {
+      if (step + NS - 1 < T) issue(step + NS - 1, lds0 + ((step + NS - 1) % NS) * STAGE);
+    };
+    if (step & 1) compute(std::integral_constant<int, -1>(), (unsigned)(slot * STAGE), P[1], P[0], dma);
+    else compute(std::integral_constant<int, -1>(), (unsigned)(slot * STAGE), P[0], P[1], dma);
+    ++step;
   }
-  if (G & 1) dequant(P[0], std::integral_constant<bool, C::PAIR>());
-  else dequant(P[1], std::integral_constant<bool, C::PAIR>());
+  if (G & 1) dequant(P[0], DeqTag<C::PAIR, false>());
+  else dequant(P[1], DeqTag<C::PAIR, false>());
+  const int slot = G % NS;
   v4f acc[2];
   float sa, sb[8];
   // the keeper (INT8, both halves in one step, per-channel scales)
@@ -552,7 +591,7 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     Pend kq;
     kq.acc[0] = acc[0]; kq.acc[1] = acc[1]; kq.sa = sa;
     kq.sb0 = v4f{sb[0], sb[1], sb[2], sb[3]}; kq.sb1 = v4f{sb[4], sb[5], sb[6], sb[7]};
-    dequant(kq, std::false_type());
+    dequant(kq, DeqTag<false, true>());
   }
   const int m = m0 + 32 * (tb >> 1) + (tb & 1) + 2 * l15;
   if (m < p.M) {
@@ -579,43 +618,36 @@ static int launch(const GemmParams &p, hipStream_t s) {
 }  // namespace f6m
 }  // namespace mid
 
-// BF6 operands with appended float32 weight scales (ATOM_AB_F6 | ATOM_B_F6S), fp16 output, N % 64 == 0
+// BF6 operands (ATOM_AB_F6; with the appended float32 weight scales of ATOM_B_F6S or the dense fp16 array), fp16 output, N % 64 == 0
 int launch_gemm_f6_mid(const GemmParams &p, hipStream_t s) {
-  if (!p.f6_rows_a || !p.sB32 || (p.N % mid::BN) != 0 || !p.D) return ATOM_ERR_SHAPE;
-  const int64_t tiles = (int64_t)((p.M + mid::BM - 1) / mid::BM) * (p.N / mid::BN);
-  const int fns = ATOM_TUNE("ATOM_MID_NS", 0);
-  const int ns = fns ? fns : (tiles <= 256 ? 10 : 5);
+  if (!p.f6_rows_a || (p.N % mid::BN) != 0 || !p.D) return ATOM_ERR_SHAPE;
   using namespace mid::f6m;
+  if (!p.sB32) return launch<Cfg<4, false, 0, true>>(p, s);
 #ifdef ATOM_TOOLS
   switch (ATOM_TUNE("ATOM_MID_ABL", 0)) {
-#define ATOM_ABL(a) case a: return launch<Cfg<5, true, a>>(p, s);
-    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(8) ATOM_ABL(16) ATOM_ABL(20) ATOM_ABL(28) ATOM_ABL(31) ATOM_ABL(9) ATOM_ABL(11) ATOM_ABL(27)
+#define ATOM_ABL(a) case a: return launch<Cfg<4, true, a>>(p, s);
+    ATOM_ABL(1) ATOM_ABL(2) ATOM_ABL(3) ATOM_ABL(4) ATOM_ABL(8) ATOM_ABL(16) ATOM_ABL(27) ATOM_ABL(31)
 #undef ATOM_ABL
     default: break;
   }
 #endif
-  if (ns >= 10) return p.b_pairs ? launch<Cfg<10, true>>(p, s) : launch<Cfg<10, false>>(p, s);
-  if (ns >= 8) return p.b_pairs ? launch<Cfg<8, true>>(p, s) : launch<Cfg<8, false>>(p, s);
-  return p.b_pairs ? launch<Cfg<5, true>>(p, s) : launch<Cfg<5, false>>(p, s);
+  return p.b_pairs ? launch<Cfg<4, true>>(p, s) : launch<Cfg<4, false>>(p, s);
 }
 
 namespace mid {
 }  // namespace mid
 
-// Packed operands (reference format), fp16 output, N % 64 == 0 (the library's constraint anyway).  Geometry by tile count: up to one
-// tile per CU -- 8 waves (16 tokens x 32 features each: two waves per SIMD keep its VALU fed) on a 16-stage ring; more -- 4 waves
-// (32 x 32: 25 % fewer widening instructions per MFMA) on 8 stages, two workgroups per CU.
+// Packed operands (reference format), fp16 output, N % 64 == 0 (the library's constraint anyway).  8 waves (16 tokens x 32 features
+// each: two waves per SIMD keep its VALU fed) on an 8-stage ring (profiles/r05/mid_ab.txt: 16 stages measure 1 us slower -- the
+// prologue issues them all --, 4 waves of 32 x 32 a third slower at one tile per CU).
 int launch_gemm_mid(const GemmParams &p, hipStream_t s) {
   if (p.a_wide || p.f6_rows_a || (p.N % mid::BN) != 0 || !p.D) return ATOM_ERR_SHAPE;
-  const int64_t tiles = (int64_t)((p.M + mid::BM - 1) / mid::BM) * (p.N / mid::BN);
-  const int fnw = ATOM_TUNE("ATOM_MID_NW", 0), fns = ATOM_TUNE("ATOM_MID_NS", 0);      // (tuning builds)
-  const int nw = fnw ? fnw : (tiles <= 256 ? 8 : 4), ns = fns ? fns : (tiles <= 256 ? 16 : 8);
-  if (nw == 8) {
-    if (ns == 16) return p.b_pairs ? mid::launch<mid::Cfg<8, 16, true>>(p, s) : mid::launch<mid::Cfg<8, 16, false>>(p, s);
-    return p.b_pairs ? mid::launch<mid::Cfg<8, 8, true>>(p, s) : mid::launch<mid::Cfg<8, 8, false>>(p, s);
-  }
-  if (ns == 16) return p.b_pairs ? mid::launch<mid::Cfg<4, 16, true>>(p, s) : mid::launch<mid::Cfg<4, 16, false>>(p, s);
-  return p.b_pairs ? mid::launch<mid::Cfg<4, 8, true>>(p, s) : mid::launch<mid::Cfg<4, 8, false>>(p, s);
+#ifdef ATOM_TOOLS
+  const int nw = ATOM_TUNE("ATOM_MID_NW", 8), ns = ATOM_TUNE("ATOM_MID_NS", 8);
+  if (nw == 8 && ns == 16) return p.b_pairs ? mid::launch<mid::Cfg<8, 16, true>>(p, s) : mid::launch<mid::Cfg<8, 16, false>>(p, s);
+  if (nw == 4 && ns == 8) return p.b_pairs ? mid::launch<mid::Cfg<4, 8, true>>(p, s) : mid::launch<mid::Cfg<4, 8, false>>(p, s);
+#endif
+  return p.b_pairs ? mid::launch<mid::Cfg<8, 8, true>>(p, s) : mid::launch<mid::Cfg<8, 8, false>>(p, s);
 }
 
 }  // namespace atom

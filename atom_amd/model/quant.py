@@ -39,13 +39,13 @@ class ActCodes:
 
 def want_wide_codes(rows: int):
     """Which activation-code format the fused quantisers should emit for a batch of ``rows`` tokens:
-    "f6"   rows >= 256: the BF6 group-major format of the block-scaled-MFMA kernels (three tile geometries, picked by
-           shape; measured against the INT8 kernels over Llama projection shapes in profiles/r01_f6_dispatch.txt: ahead
-           from 256 rows up, 1.3-1.4x at 1k-2k rows);
-    False  rows <= 255: packed nibbles -- the decode kernels (gemv / decode-batch GEMM, up to 256 rows where the shape
-           fits) take only these, and at these sizes the INT8 tile kernels run packed and pre-widened codes equally fast.
+    "f6"   rows > 128: the BF6 group-major format of the block-scaled-MFMA kernels (tile geometries picked by shape; measured
+           against the INT8 kernels over Llama projection shapes in profiles/r01_f6_dispatch.txt: ahead from 256 rows up, 1.3-1.4x at
+           1k-2k rows; round 5: the mid-size-batch kernel runs 129 .. 256 rows in ~10 us at 4096 x 4096 where the decode-batch kernel
+           takes 9.4 (128 rows) .. 15.5 (256), profiles/r05/mid_f6c.txt);
+    False  rows <= 128: packed nibbles -- the decode kernels (gemv / decode-batch GEMM) take only these.
     (True = pre-widened int8 codes for the INT8 tile kernels is still accepted by every op; nothing here asks for it.)"""
-    if rows >= 256:
+    if rows > 128:
         return "f6"
     return False
 

@@ -188,7 +188,7 @@ def configs_sweep(dev):
     4096-wide batch sweep of the reference's own NVBench driver (bench_dense_layer_gemm_i4_o16.cu:64-69).  Packed (reference-format)
     operands through atom_gemm_w4a4_f16_ws, timed per launch by HIP-graph replay (the Python launch loop is slower than a 3 us kernel):
     hot = one operand set replayed, cold = the graph cycles through enough distinct weight sets (>= 600 MB) that every launch streams
-    its weights from HBM -- what a model's layers do (tools/cold_bench.py).  From 257 rows the native BF6 operand format is timed
+    its weights from HBM -- what a model's layers do (tools/cold_bench.py).  From 129 rows the native BF6 operand format is timed
     beside it (`f6_us`, hot).  Fractions: of 8 TB/s on the algorithmic bytes (`frac_hbm`), of the dense INT8 MFMA peak (`frac_mfma`)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import cold_bench as CB
@@ -206,7 +206,7 @@ def configs_sweep(dev):
                "cold_gbps": round(by / cold / 1e3, 1), "cold_frac_hbm": round(by / cold / 1e6 / 8.0, 4),
                "hot_frac_hbm": round(by / hot / 1e6 / 8.0, 4),
                "cold_tops": round(op / cold / 1e6, 1), "cold_frac_mfma": round(op / cold / 1e6 / PEAK_I8_TOPS, 4)}
-        if M >= 257:
+        if M >= 129:                                            # (the drop-in modules ask the quantisers for BF6 codes from 129 rows)
             ops_ = make_operands(M, N, K, dev, seed=1)
             a6, b6 = build_f6_operands(ops_, M, N, K, dev)
             D = torch.empty((M, N), dtype=torch.float16, device=dev)
@@ -299,6 +299,11 @@ def block_workload(args, rank, world, dev):
     t0 = time.perf_counter()
     r = block_bench.run(bsz=32, seq=2048, iters=steps, warmup=max(1, min(args.warmup, 3)), verbose=False)
     torch.cuda.synchronize(dev)
+    # beside it: the same block with the attention opt-in of the configuration namespace (args.attn_sdpa: torch's fused attention
+    # instead of the reference's materialised 32 x 32 x 2048 x 2048 score tensor -- same mathematics, not part of the W4A4 hot path)
+    torch.cuda.empty_cache()
+    r2 = block_bench.run(bsz=32, seq=2048, iters=steps, warmup=1, verbose=False, attn_sdpa=True)
+    torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     block_ms, gemm_ms = max_over_ranks([r["block_ms"], r["gemm_ms"]], dist, dev)
@@ -314,6 +319,7 @@ def block_workload(args, rank, world, dev):
                           "parallelism": f"replicas x{world}"},
                "block_ms": round(block_ms, 3), "gemm_ms": round(gemm_ms, 3), "gemm_share": round(gemm_ms / block_ms, 4),
                "module_ms": r["spans"],
+               "block_ms_attn_sdpa": round(r2["block_ms"], 3), "gemm_ms_attn_sdpa": round(r2["gemm_ms"], 3),
                "roofline": {"bound": "mfma", "achieved": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12, 2), "peak": PEAK_I8_TOPS,
                             "unit": "TFLOP/s", "frac": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12 / PEAK_I8_TOPS, 4),
                             "traffic": None, "algorithmic_ops": int(r["gemm_ops"])},
@@ -575,11 +581,13 @@ def main():
                                 "quantiser_ms": round(quant_ms, 3),
                                 "attention_and_rest_ms": round(b["block_ms"] - b["gemm_ms"] - quant_ms, 3),
                                 "gemm_share": b["gemm_share"], "module_ms": mm,
+                                "block_ms_attn_sdpa": b.get("block_ms_attn_sdpa"), "gemm_ms_attn_sdpa": b.get("gemm_ms_attn_sdpa"),
                                 "note": "one QLlamaDecoderLayer forward (model/qLlamaLayer.py:86-127 mirrored) at batch 32 x seq 2048; gemm_ms = "
                                         "q/k/v/o projections + the MLP module (gate / up / SiLU x up / its quantiser in one launch, then down_proj); "
                                         "quantiser_ms = the two RMSNorm -> reorder -> quantise launches (the o_proj and down_proj quantisers run "
-                                        "inside attention / the MLP launch); the rest is torch's attention over the fake-quantised INT4 KV, RoPE "
-                                        "and the residual adds"}
+                                        "inside attention / the MLP launch); the rest is torch's attention over the fake-quantised INT4 KV -- the "
+                                        "reference's materialised score matrix, model/qLlamaLayer.py:262-290 --, RoPE and the residual adds; "
+                                        "*_attn_sdpa = the same block with the opt-in args.attn_sdpa (torch's fused attention)"}
             except Exception as e:                               # pragma: no cover
                 out["block"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -59,14 +59,14 @@ def test_product_does_not_import_oracle():
 
 def test_f6_summation_order_query():
     """atom_gemm_w4a4_f6_order is a host-side function of the shape alone: K steps in order for shapes that fill the chip with
-    256x256 / 128x128 tiles, two ranges up to 256 tiles of 128x128, four up to 256 tiles of 64x128 with >= 16 K steps; 0 for an
-    unsupported shape.  (What the GPU tests restate the arithmetic for: oracle gemm_core nsplit = -order.)"""
+    256x256 / 128x128 tiles and -- round 5 -- for up to 512 tiles of 64x64 (the mid-size-batch kernel), two ranges beyond that up to 256
+    tiles of 128x128; 0 for an unsupported shape.  (What the GPU tests restate the arithmetic for: oracle gemm_core nsplit = -order.)"""
     from atom_amd import _lib
     order = _lib.lib().atom_gemm_w4a4_f6_order
     assert order(4096, 4096, 4096) == 1 and order(65536, 11008, 4096) == 1 and order(2048, 4096, 4096) == 1
     assert order(1024, 4096, 4096) == 2 and order(768, 4096, 11008) == 2 and order(256, 13824, 5120) == 2
-    assert order(300, 1088, 1152) == 2                        # 10 K steps: two groups on 64x128 tiles
-    assert order(512, 4096, 4096) == 4 and order(256, 4096, 11008) == 4 and order(100, 4096, 4096) == 4
+    assert order(300, 1088, 1152) == 1 and order(512, 4096, 4096) == 1 and order(256, 4096, 11008) == 1 and order(100, 4096, 4096) == 1
+    assert order(64, 13824, 5120) == 1 and order(513, 4096, 4096) == 2     # 512 / 576 tiles of 64x64
     assert order(1500, 1408, 640) == 1                        # fewer than 8 K steps: no K groups
     assert order(16, 4096, 4000) == 0 and order(0, 4096, 4096) == 0 and order(16, 32, 4096) == 0
 

@@ -16,7 +16,7 @@ def _weights(ops, N, K, g, scale):
 
 
 @pytest.mark.parametrize("M,N,K,order", [(512, 256, 384, 1), (1000, 1408, 640, 1), (2048, 11008, 4096, 1), (512, 11008, 4096, 1),
-                                         (300, 512, 1152, 2), (512, 1024, 4096, 4)])
+                                         (300, 512, 1152, 1), (512, 1024, 4096, 1), (1100, 2048, 1152, 2)])
 @pytest.mark.parametrize("mode,clip", [("sim", 0.9), ("kernel", 1.0)])
 @pytest.mark.parametrize("layout", ["plain", "ref"])
 def test_fused_gate_up_equals_three_launches(M, N, K, order, mode, clip, layout):

@@ -378,23 +378,25 @@ def test_gemm_f6_operands_bit_identical(M, N, K):
         assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout="plain"))
 
 
-# mid-size prefill batches (at most one tile per CU): 64x128 / 128x128 tiles shared by two groups of 4 waves that split the K
-# steps.  Whole and ragged tiles in both dimensions, odd and even step counts, with and without the appended fp32 weight scales.
-@pytest.mark.parametrize("M,N,K,want_cfg", [(1024, 4096, 4096, "128x128"), (512, 4096, 4096, "64x128"), (300, 1088, 1152, "64x128"),
-                                            (700, 2112, 2176, "64x128"), (1000, 3136, 1408, "128x128"), (257, 10880, 1024, "128x128"),
-                                            (2048, 2048, 1152, "128x128")])
+# mid-size prefill batches in the BF6 format: up to 512 tiles of 64x64 the mid-size-batch kernel (gemm_w4a4_mid.hip: the K steps in
+# order); beyond, while at most 256 tiles of 128x128 exist, 128x128 tiles shared by two groups of 4 waves that split the K steps.  Whole
+# and ragged tiles in both dimensions, odd and even step counts, with and without the appended fp32 weight scales.
+@pytest.mark.parametrize("M,N,K,want_cfg", [(1024, 4096, 4096, "128x128"), (512, 4096, 4096, "mid"), (300, 1088, 1152, "mid"),
+                                            (700, 2112, 2176, "mid"), (1000, 3136, 1408, "128x128"), (257, 10880, 1024, "128x128"),
+                                            (2048, 2048, 1152, "128x128"), (129, 4096, 4096, "mid"), (70, 13824, 640, "mid")])
 @pytest.mark.parametrize("f6s", [True, False])
 def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
-    """Bit for bit against the C restatement with the K steps summed in two / four ordered ranges (oracle gemm_core, nsplit = -2 / -4), on
-    rows from the first, a middle and the last tile; the whole output against the exact value."""
+    """Bit for bit against the C restatement in the kernel's summation order -- the K steps in order (the mid-size-batch kernel) or in
+    two ordered ranges (oracle gemm_core, nsplit = -2) -- on rows from the first, a middle and the last tile; the whole output against
+    the exact value."""
     from tests import c_oracle
     from tests.helpers import f6_codes
     ops = _ops()
     lib = ops.L.lib()
-    t64, t128 = -(-M // 64) * -(-N // 128), -(-M // 128) * -(-N // 128)
-    assert (t64 <= 256) == (want_cfg == "64x128") and t128 <= 256                       # the dispatch rule this case is meant to hit
+    t64, t128 = -(-M // 64) * (N // 64), -(-M // 128) * -(-N // 128)
+    assert (t64 <= 512) == (want_cfg == "mid") and (want_cfg == "mid" or t128 <= 256)   # the dispatch rule this case is meant to hit
     order = lib.atom_gemm_w4a4_f6_order(M, N, K)
-    assert order == (4 if want_cfg == "64x128" and K // 128 + 1 >= 16 else 2)           # four K groups from 16 K steps on 64x128 tiles
+    assert order == (1 if want_cfg == "mid" else 2)
     d = rand_gemm_operands(M, N, K, seed=5 * M + N + 3 * K)
     t = to_device(d, "plain")
     a6 = torch.from_numpy(f6_codes(d["qa4"], d["sA"])).cuda()
@@ -403,11 +405,11 @@ def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
     assert_gemm_close(t2n(out), _exact(d), f"f6 two K groups {M}x{N}x{K}")
     rows = np.unique(np.r_[0:6, M // 2 - 3:M // 2 + 3, M - 6:M])
     want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
-                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order)
+                         d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order if order > 1 else 1)
     assert np.array_equal(bits16(t2n(out)[rows]), bits16(want))
     # the plain entry point takes the same route (no workspace involved)
     D = torch.empty_like(out)
-    flags = ops.L.SCALE_LAYOUT_PLAIN | ops.L.AB_F6 | (ops.L.B_F6S if f6s else 0)
+    flags = ops.L.SCALE_LAYOUT_PLAIN | ops.L.AB_F6 | (ops.L.B_F6S if f6s else 0) | (ops.L.B_SCALE_PAIRS if getattr(b6, "atom_pairs", False) else 0)
     bbuf = b6.atom_f6s if f6s else b6
     st = lib.atom_gemm_w4a4_f16(a6.data_ptr(), bbuf.data_ptr(), *[x.data_ptr() for x in t[2:]], D.data_ptr(), M, N, K, 128, 128, flags,
                                 ops.L.current_stream(D.device))
@@ -508,7 +510,7 @@ def test_gemm_f6_random_shapes_bit_exact_vs_c_contract():
         want = c_oracle.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"]), np.ascontiguousarray(d["sA"][rows].T), d["sB"],
                              d["qa8"][rows], d["qb8"], d["sA8"][rows], d["sB8"], nsplit=-order if order > 1 else 1)
         assert np.array_equal(bits16(t2n(out)[rows]), bits16(want)), (M, N, K, f6s, order)
-    assert seen == {1, 2, 4}
+    assert seen == {1, 2}          # (order 4 -- four K groups on 64x128 tiles -- left the dispatch in round 5: the mid-size-batch kernel takes those shapes, K steps in order)
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 4096, 4096), (1000, 4096, 1152), (700, 3968, 2176), (1024, 4096, 1024), (130, 16384, 1280)])
@@ -722,11 +724,10 @@ def test_two_tokens_take_the_decode_batch_kernel_up_to_k_4096():
     assert np.array_equal(bits16(t2n(out)), bits16(want))
 
 
-# mid-size batches in the packed format: gemm_w4a4_mid.hip (64 x 64 tiles over the whole K range on a deep LDS ring; 8 waves on 16
-# stages up to 256 tiles, 4 waves on 8 stages beyond): ragged token tiles, one to 41 int4 groups (fewer stages than ring slots and
-# more), both scale layouts, pair-shared and per-channel weight scales
-MID = [(17, 6144, 256), (64, 8192, 384), (100, 4096, 1152), (256, 4096, 4096), (300, 4096, 640), (129, 13824, 1280),
-       (512, 4096, 2176), (1000, 1024, 5248), (77, 6208, 1408)]
+# mid-size batches in the packed format: gemm_w4a4_mid.hip, INT8 form (64 x 64 tiles over the whole K range on a deep LDS ring).  The
+# dispatch gives it what the decode-batch kernel does not take and one tile per CU covers: up to 256 rows, 96 .. 256 tiles, K <= 11264
+# (gemm_w4a4.hip mid_fits).  Ragged token tiles, 33 .. 86 int4 groups, both scale layouts, pair-shared and per-channel weight scales.
+MID = [(64, 13824, 5120), (40, 13824, 4224), (100, 8192, 8192), (256, 4096, 11008), (129, 4096, 6272), (77, 6208, 10368)]
 
 
 @pytest.mark.parametrize("M,N,K", MID)

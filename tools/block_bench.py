@@ -15,12 +15,13 @@ from atom_amd.model import qLlamaLayer, quant  # noqa: E402
 from atom_amd.model.qLinearLayer import QLinearLayer  # noqa: E402
 
 
-def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True):
-    """Returns dict(block_ms, gemm_ms, gemm_tops, spans={module: ms}) -- also what `bench.py --workload block` reports."""
+def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True, attn_sdpa=False):
+    """Returns dict(block_ms, gemm_ms, gemm_tops, spans={module: ms}) -- also what `bench.py --workload block` reports.
+    attn_sdpa: the configuration opt-in args.attn_sdpa (torch's fused attention instead of the reference's materialised score matrix)."""
     args = types.SimpleNamespace(wbits=4, abits=4, a_sym=True, w_sym=True, act_group_size=128, weight_group_size=128,
                                  weight_channel_group=2, keeper=128, keeper_precision=3, a_clip_ratio=0.9,
                                  w_clip_ratio=0.85, kv_clip_ratio=1.0, tiling=0, exponential=False, quant_type="int",
-                                 static=False, reorder=True, kv_cache=True)
+                                 static=False, reorder=True, kv_cache=True, attn_sdpa=bool(attn_sdpa))
     orig = G.build_original(hidden, heads, inter, seed=7)
     idx, _, _, _ = G.make_inputs(hidden, inter, 1, 8, seed=8)
     m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
