@@ -260,6 +260,12 @@ static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
   if (M >= ATOM_TUNE("ATOM_F6_ROUTE_MIN_M", 257)) return true;
   return M > 128 && !skinny_fits(M, N, K_total);
 }
+// ... and with the weight's BF6 form already in the workspace (ATOM_WS_WEIGHT_CACHED) from 129 rows whatever the decode kernels take: only
+// the activation is re-coded, and the mid-size-batch kernel runs 129 .. 256 rows in ~10 us at 4096 x 4096 (decode-batch kernel: 9.4 .. 15.5)
+static bool f6_route_cached(int64_t M, int64_t N, int64_t K_total) {
+  if (ATOM_TUNE("ATOM_NO_F6_ROUTE", 0) || N < 2048 || K_total < 1024) return false;
+  return M > 128;
+}
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;
 }
@@ -267,8 +273,9 @@ static size_t f6_bytes(int64_t rows, int64_t K_total) {
 int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_workspace) {
   if (M < 1 || N < 64 || (N % 64) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
   if (with_workspace && atom_gemm_w4a4_workspace_bytes(M, N, K_total) != 0) {
-    if (f6_route(M, N, K_total)) return atom_gemm_w4a4_f6_order(M, N, K_total);      // re-coded to BF6: 1 / 2 / 4
-    return 100 + choose_splits(M, N, K_total);                                       // split-K through the workspace
+    if (f6_route(M, N, K_total) || (with_workspace == 2 && f6_route_cached(M, N, K_total)))
+      return atom_gemm_w4a4_f6_order(M, N, K_total);                                 // re-coded to BF6: 1 / 2
+    if (choose_splits(M, N, K_total) > 1) return 100 + choose_splits(M, N, K_total); // split-K through the workspace
   }
   if (M <= gemv_tokens(K_total)) return 64;                                          // the dot-product kernel
   if (mid_fits(M, N, K_total)) return 1;
@@ -284,7 +291,8 @@ int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total) {
 
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
-  if (f6_route(M, N, K_total)) return f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;   // B: + float32 scales
+  if (f6_route(M, N, K_total) || f6_route_cached(M, N, K_total))
+    return f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;   // B: + float32 scales
   const int s = choose_splits(M, N, K_total);
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -301,7 +309,10 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   if (st != ATOM_OK) return st;
   if (!aligned16(D) || !aligned16(workspace) || (N % 8) != 0) return ATOM_ERR_ALIGN;
   p.D = (half_t *)D;
-  if (!p.a_wide && !p.f6_rows_a && f6_route(M, N, K_total)) {        // packed operands -> F6 copies in the workspace
+  const bool wcached = (scale_layout & ATOM_WS_WEIGHT_CACHED) != 0;
+  if (!p.a_wide && !p.f6_rows_a && !f6_route(M, N, K_total) && !(wcached && f6_route_cached(M, N, K_total)) && choose_splits(M, N, K_total) <= 1)
+    return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);   // (129 .. 256 rows, nothing cached)
+  if (!p.a_wide && !p.f6_rows_a && (f6_route(M, N, K_total) || (wcached && f6_route_cached(M, N, K_total)))) {   // packed operands -> F6 copies in the workspace
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     // layout: weight records, their float32 scales, then the activation records -- the weight region does not move with M, so a
     // weight re-coded once serves later calls of any batch size (ATOM_WS_WEIGHT_CACHED)
@@ -309,7 +320,7 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
     float *sb32 = reinterpret_cast<float *>(b6 + f6_bytes(N, K_total));
     uint8_t *a6 = b6 + f6_bytes(N, K_total) / 104 * 108;
     // ATOM_WS_WEIGHT_CACHED: b6 / sb32 hold this weight's F6 form since an earlier call (the caller's assertion): activation only
-    const int r = (scale_layout & ATOM_WS_WEIGHT_CACHED)
+    const int r = wcached
                       ? launch_repack_f6(p.A4, M, p.K4h, p.G, p.sA, p.ldA, p.ref_layout, a6, hs)
                       : launch_repack_f6_pair(p.A4, M, p.sA, p.ldA, p.ref_layout, a6, p.sB, sb32, p.B4, N, b6, p.K4h, p.G, hs);
     if (r != ATOM_OK) return r;

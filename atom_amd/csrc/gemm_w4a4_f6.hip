@@ -1706,10 +1706,14 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     s = 3;
   }
   for (; s + 4 < G; s += 3) { reg(S0(), s); reg(S1(), s + 1); reg(S2(), s + 2); }
-  // The last 2..4 steps run on ONE generic code body (run-time stage slots): 0..2 regular steps, then the two whose LDS-DMA is a
-  // keeper half instead of an int4 stage (the second one has no next int4 stage to prefetch from).  (Round 3 tried compile-time
-  // slots for these steps too -- five step bodies, a wave-uniform branch per DMA group: ~750 cycles fewer per tail step in the
-  // s_memtime trace, no change in wall time at 4096^3 and -0.8 % at 8192^3 under the power cap; profiles/r03_gemm_experiments.txt.)
+  // s is a multiple of 3 here and 2..4 steps remain: the ones that still fetch an int4 stage (0..2 of them) are regular steps in
+  // slots 0 and 1 -- compile-time bodies again (round 5: ~50 address instructions fewer per wave and step than the generic body) --,
+  // the last two, whose LDS-DMA is a keeper half, run on ONE generic code body with run-time stage slots (the second one has no next
+  // int4 stage to prefetch from).  (Round 3 tried compile-time slots for those two as well -- a wave-uniform branch per DMA group:
+  // ~750 cycles fewer per tail step in the s_memtime trace, no change in wall time at 4096^3 and -0.8 % at 8192^3 under the power
+  // cap; profiles/r03_gemm_experiments.txt.)
+  if (s + 2 < G) { reg(S0(), s); ++s; }
+  if (s + 2 < G) { reg(S1(), s); ++s; }
   for (; s < G; ++s) {
     if constexpr (TR) { if (s < 44) kstamp(16 + s); }
     const int g = s + 2;                                    // the stage this step's LDS-DMA fetches: int4 g, or keeper half g - G

@@ -993,9 +993,55 @@ __global__ __launch_bounds__(256) void repack_f6_kernel(RepackF6Pair pp) {
     *reinterpret_cast<v4u *>(out + i * 16) = *reinterpret_cast<const v4u *>(rec + i * 16);
 }
 
+// The same for a FEW rows (activations of mid-size batches: the re-coding launch in front of the mid-size-batch GEMM): a block of 64
+// rows x one group per workgroup, four threads per row (32 codes = one conversion each) -- 4 x (rows / 64) x G waves instead of
+// (rows / 256) x G workgroups of one row per thread, which is 31 workgroups on a 256-CU chip at 256 x 4096.  Rows [rows, 64-row block
+// end) are zero records, rows beyond are not written (pad rows of an F6 operand may hold any bytes, include/atom_hip.h).
+__global__ __launch_bounds__(256) void repack_f6_rows64_kernel(RepackF6Params p) {
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  typedef unsigned v6u __attribute__((ext_vector_type(6)));
+  __shared__ __attribute__((aligned(16))) unsigned char rec[64 * 104];
+  const int g = blockIdx.y;
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x, r = t >> 2, q = t & 3;
+  const int64_t n = n0 + r;
+  unsigned *dst = reinterpret_cast<unsigned *>(rec + r * 104);
+  if (n < p.N) {
+    const v4u raw = *reinterpret_cast<const v4u *>(p.B4 + n * p.K4h + g * 64 + 16 * q);
+    v16f ea, eb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const unsigned byte = (raw[i >> 2] >> (8 * (i & 3))) & 0xFF;
+      ea[i] = (float)((int)(byte << 28) >> 28);
+      eb[i] = (float)((int)(byte << 24) >> 28);
+    }
+    const v6u f = cvt_2xpk16_bf6(ea, eb);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[6 * q + k] = f[k];
+    if (q == 0) {
+      const half_t sv = p.scale[(int64_t)g * p.ld + (p.ref_layout ? ref_scale_index((int)n) : (int)n)];
+      dst[24] = (unsigned)__builtin_bit_cast(unsigned short, sv);
+      dst[25] = __builtin_bit_cast(unsigned, (float)sv);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[6 * q + k] = 0u;
+    if (q == 0) { dst[24] = 0u; dst[25] = 0u; }
+  }
+  __syncthreads();
+  uint8_t *out = p.out + ((int64_t)g * p.rows_pad + n0) * 104;
+  for (int i = t; i < 64 * 104 / 16; i += 256)
+    *reinterpret_cast<v4u *>(out + i * 16) = *reinterpret_cast<const v4u *>(rec + i * 16);
+}
+
 // packed operand [rows, K4/2] (+ its scales, for activations) -> F6 buffer [G][round_up(rows, 256)][104]
 int launch_repack_f6(const uint8_t *src, int64_t rows, int K4h, int G, const half_t *scale, int64_t ld, int ref_layout,
                      uint8_t *out, hipStream_t s) {
+  if (scale && rows <= 2048) {                             // few rows: 64-row blocks, four threads per row
+    const RepackF6Params q{src, out, rows, (rows + 255) / 256 * 256, K4h, G, scale, ld, ref_layout, nullptr, nullptr};
+    hipLaunchKernelGGL(repack_f6_rows64_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)G), dim3(256), 0, s, q);
+    return check_launch();
+  }
   RepackF6Pair pp;
   pp.op[0] = RepackF6Params{src, out, rows, (rows + 255) / 256 * 256, K4h, G, scale, ld, ref_layout, nullptr, nullptr};
   pp.op[1] = pp.op[0];

@@ -270,7 +270,9 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide == "f6" or (a_wide and m >= 2048)) else 0
     # packed operands of prefill size (the re-coding route): with the weight's F6 form cached (per weight, _weight_f6s) only the
     # activation is re-coded, into a fresh tensor, and the F6 kernel runs on the two -- the kernel and the bits of the workspace route
-    if ws_bytes and not a_wide and lib.atom_gemm_w4a4_ws_recodes(m, n, k):
+    # (with the weight's BF6 form cached the route starts at 129 rows -- only the activation is re-coded and the mid-size-batch BF6
+    # kernel beats the decode kernels there: ATOM_WS_WEIGHT_CACHED's rule in include/atom_hip.h)
+    if ws_bytes and not a_wide and (lib.atom_gemm_w4a4_ws_recodes(m, n, k) or (m > 128 and n >= 2048 and k >= 1024)):
         f6w = _weight_f6s(b, b_scale, n, k)
         if f6w is not None:
             a6 = repack_act_f6(a.view(torch.uint8), a_scale, scale_layout=scale_layout)

@@ -206,6 +206,9 @@ def configs_sweep(dev):
                "cold_gbps": round(by / cold / 1e3, 1), "cold_frac_hbm": round(by / cold / 1e6 / 8.0, 4),
                "hot_frac_hbm": round(by / hot / 1e6 / 8.0, 4),
                "cold_tops": round(op / cold / 1e6, 1), "cold_frac_mfma": round(op / cold / 1e6 / PEAK_I8_TOPS, 4)}
+        if M >= 129:                                            # the C ABI with one workspace per weight (ATOM_WS_WEIGHT_CACHED): activation re-coded per call
+            wh, wc = CB.gemm_row(M, N, K, quiet=True, weight_cached=True)
+            row.update({"wcached_hot_us": round(wh, 2), "wcached_cold_us": round(wc, 2)})
         if M >= 129:                                            # (the drop-in modules ask the quantisers for BF6 codes from 129 rows)
             ops_ = make_operands(M, N, K, dev, seed=1)
             a6, b6 = build_f6_operands(ops_, M, N, K, dev)
@@ -215,11 +218,23 @@ def configs_sweep(dev):
             f = lambda st: lib.atom_gemm_w4a4_f16(*ptrs, D.data_ptr(), M, N, K, 128, 128, f6_flags, st)
             f6 = CB.graph_time([f], 64)
             row.update({"f6_us": round(f6, 2), "f6_tops": round(op / f6 / 1e6, 1), "f6_frac_mfma": round(op / f6 / 1e6 / PEAK_I8_TOPS, 4)})
+            if M <= 1024:                                       # ... and with the BF6 weights streamed from HBM: distinct copies >= 600 MB cycled
+                wb = b6.atom_f6s.numel()
+                copies = [b6.atom_f6s] + [b6.atom_f6s.clone() for _ in range(max(1, -(-CB.COLD_BYTES // wb)) - 1)]
+                fs = []
+                for w in copies:
+                    pw = [a6.data_ptr(), w.data_ptr()] + [t.data_ptr() for t in ops_[2:]]
+                    fs.append(lambda st, pw=pw: lib.atom_gemm_w4a4_f16(*pw, D.data_ptr(), M, N, K, 128, 128, f6_flags, st))
+                n_it = max(64, 2 * len(fs))
+                row["f6_cold_us"] = round(CB.graph_time(fs, n_it - n_it % len(fs)), 2)
+                del copies, fs
             del ops_, a6, b6, D
         rows.append(row)
         torch.cuda.empty_cache()
     return {"method": "HIP-graph replay, per launch; hot = one operand set, cold = distinct weight sets >= 600 MB cycled (every launch "
-                      "streams its weights from HBM); packed reference-format operands through atom_gemm_w4a4_f16_ws; f6_* = native BF6 operands",
+                      "streams its weights from HBM); packed reference-format operands through atom_gemm_w4a4_f16_ws, nothing cached; "
+                      "wcached_* = the same with one workspace per weight and ATOM_WS_WEIGHT_CACHED (its weight region filled once by "
+                      "atom_repack_weight_f6s: only the activation is re-coded per call); f6_* = native BF6 operands",
             "rows": rows}
 
 

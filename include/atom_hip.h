@@ -102,7 +102,12 @@ int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
  * holds the F6 form of exactly these B4 / sB (N, K_total) -- written by an earlier call with the same workspace and weight (the
  * weight of a layer is static) -- so only the activation is re-coded: 5 instead of 10 us of re-coding at 4096^3.  The library keeps no
  * state: the CALLER asserts it (atom_amd.ops tracks which weight its workspace holds).  Wrong flag = wrong results, never a fault
- * (the region is inside the workspace either way).  Ignored on every other route. */
+ * (the region is inside the workspace either way).  Ignored on every other route.
+ * Round 5: with the flag the re-coding route starts at 129 rows (N >= 2048, K >= 1024) -- only the activation is re-coded, and the
+ * mid-size-batch kernel behind it runs 129 .. 256 rows in ~10 us at 4096 x 4096 where the decode-batch kernel takes 9.4 .. 15.5 --, so a
+ * caller that keeps ONE workspace per weight (a layer's weight is static) fills its weight region once, offline, with
+ * atom_repack_weight_f6s(B4, sB, N, K_total, workspace, stream) -- the region's layout is exactly that function's output -- and passes
+ * the flag on every call; atom_gemm_w4a4_workspace_bytes() covers those shapes, atom_gemm_w4a4_packed_order(.., 2) names their order. */
 #define ATOM_WS_WEIGHT_CACHED 0x1000
 /* OR into `scale_layout` of the GEMM entry points: the caller asserts that output channels 2 j and 2 j + 1 share their weight scales,
  * sB[g][2 j] == sB[g][2 j + 1] for every group g (weight_channel_group = 2 of model/qLinearLayer.py:63-70 -- the only form the
@@ -173,7 +178,8 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
  *   64       the one- / two-token dot-product kernel: groups dealt to 16 quad leaders, 64-lane butterfly, keeper last
  *   63       the staged dot-product kernel (M <= 7 with a K too long for the decode-batch kernel): per-lane partial sums
  *   100 + s  split-K over s workgroups through the workspace, partial sums added in split order
- *   0        unsupported shape */
+ *   0        unsupported shape
+ * with_workspace = 2: a workspace AND ATOM_WS_WEIGHT_CACHED (the re-coding route from 129 rows). */
 int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_workspace);
 
 /*

@@ -246,7 +246,7 @@ def test_llama7b_projections_teacher_forced_on_256_reference_rows(golden_dir):
         # ... and against the C restatement of the contract on the same integer operands (the sampled features of the HIP weights)
         # (in the summation order of the kernel this shape is dispatched to: the library's own queries)
         N, K = b4.shape[0], H
-        order = lib.atom_gemm_w4a4_packed_order(M, N, K, 1)               # 1: K steps in order (tile kernels), 2 / 4: ordered K ranges (BF6
+        order = lib.atom_gemm_w4a4_packed_order(M, N, K, 2)               # (ops keeps every weight's BF6 form) 1: K steps in order (tile kernels), 2 / 4: ordered K ranges (BF6
         assert order in (1, 2, 4, 8), order                               # K-group kernels), 8: the decode-batch kernel
         nsplit = -order if order in (2, 4) else order
         Dc = C.gemm(o4.cpu().numpy().view(np.uint8), b4[cols].cpu().numpy().view(np.uint8), sA.cpu().numpy(),

@@ -734,10 +734,13 @@ MID = [(64, 13824, 5120), (40, 13824, 4224), (100, 8192, 8192), (256, 4096, 1100
 @pytest.mark.parametrize("layout", ["ref", "plain"])
 def test_gemm_mid_batches_bit_exact_vs_c_contract(M, N, K, layout):
     """The mid-size-batch kernel sums the K steps in order -- the contract of include/atom_hip.h as oracle/atom_oracle.c restates it
-    (oracle_gemm_w4a4_f16) -- so whole outputs are compared bit for bit on sampled rows and columns (the C loop is O(M N K))."""
+    (oracle_gemm_w4a4_f16) -- so outputs are compared bit for bit on sampled rows and columns (the C loop is O(M N K)).  Called through
+    the plain C entry point (no workspace: the INT8 form) and through atom_amd.ops (which, above 128 rows, re-codes the activation and
+    runs the BF6 form on its cached weight: the same order here)."""
     from tests import c_oracle as C
     ops = _ops()
-    assert ops.L.lib().atom_gemm_w4a4_packed_order(M, N, K, 1) == 1 and ops.L.lib().atom_gemm_w4a4_workspace_bytes(M, N, K) == 0
+    lib = ops.L.lib()
+    assert lib.atom_gemm_w4a4_packed_order(M, N, K, 0) == 1 and lib.atom_gemm_w4a4_packed_order(M, N, K, 2) == 1
     d = rand_gemm_operands(M, N, K, seed=M * 3 + N + K)
     if (M + N) % 2:                                          # per-channel weight scales: the kernels without the shared products
         g = np.random.default_rng(M)
@@ -745,12 +748,17 @@ def test_gemm_mid_batches_bit_exact_vs_c_contract(M, N, K, layout):
     t = to_device(d, layout)
     out = ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout)
     assert torch.equal(out, ops.dense_layer_gemm_i4_fp16(*t, scale_layout=layout))
+    plain = torch.empty_like(out)
+    flags = ops._LAYOUTS[layout] | (ops.L.B_SCALE_PAIRS if ops.scale_pairs_shared(t[3], N) else 0)
+    ops.L.check(lib.atom_gemm_w4a4_f16(*[x.data_ptr() for x in t], plain.data_ptr(), M, N, K, 128, 128, flags,
+                                       ops.L.current_stream(plain.device)), "atom_gemm_w4a4_f16")
+    assert torch.equal(plain, out)                           # INT8 form == BF6 form / ops route: one order, exact integer dots
     g = np.random.default_rng(N)
     rows = np.unique(np.concatenate([[0, M - 1, min(63, M - 1), min(64, M - 1)], g.integers(0, M, 12)]))
     cols = np.unique(np.concatenate([np.arange(0, 72), [N - 1, N - 64, N - 33], g.integers(0, N, 100)]))
     want = C.gemm(O.pack_int4(d["qa4"][rows]), O.pack_int4(d["qb4"][cols]), d["sA"][rows].T, d["sB"][:, cols], d["qa8"][rows],
                   d["qb8"][cols], d["sA8"][rows], d["sB8"][cols])
-    got = t2n(out)[np.ix_(rows, cols)]
+    got = t2n(plain)[np.ix_(rows, cols)]
     assert np.array_equal(bits16(got), bits16(want)), f"{(bits16(got) != bits16(want)).sum()} of {got.size} sampled elements differ"
     exact = gemm_ref_torch_f64(d).cpu().numpy()
     assert_gemm_close(t2n(out), exact, f"mid batch {M}x{N}x{K} {layout}")

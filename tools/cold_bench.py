@@ -81,18 +81,27 @@ def gemm_sets(M, N, K, R):
     return sets
 
 
-def gemm_row(M, N, K, quiet=False):
+def gemm_row(M, N, K, quiet=False, weight_cached=False):
+    """weight_cached: the caller keeps ONE workspace per weight, its weight region filled once by atom_repack_weight_f6s, and passes
+    ATOM_WS_WEIGHT_CACHED (include/atom_hip.h) -- what a binding that owns its layers does; only the activation is re-coded per call."""
     wbytes = N * (K - 128) // 2 + N * 128 + 2 * N * ((K - 128) // 128 + 1)
     R = max(2, -(-COLD_BYTES // wbytes))
     sets = gemm_sets(M, N, K, R)
     D = torch.empty((M, N), dtype=torch.float16, device=dev)
     wsb = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    flags = L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS | (L.A_WIDE if WIDE else 0)   # (bench.make_operands: channel pairs share their scales)
+    cached = weight_cached and wsb > 0 and lib.atom_gemm_w4a4_packed_order(M, N, K, 2) in (1, 2, 4)
 
     def mk(ops_):
         ptrs = [t.data_ptr() for t in ops_]
-        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS | (L.A_WIDE if WIDE else 0), ws.data_ptr(), wsb, st)   # (bench.make_operands: channel pairs share their scales)
+        if cached:
+            w = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            L.check(lib.atom_repack_weight_f6s(ptrs[1], ptrs[3], N, K, w.data_ptr(), None), "atom_repack_weight_f6s")
+            return lambda st, w=w: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, flags | L.WS_WEIGHT_CACHED, w.data_ptr(), wsb, st)
+        return lambda st: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, flags, ws.data_ptr(), wsb, st)
     launchers = [mk(s) for s in sets]
+    torch.cuda.synchronize()
     iters = max(64, 2 * R)
     iters -= iters % R
     hot = graph_time(launchers[:1], iters)

@@ -1,10 +1,10 @@
-# Round profile of the headline command (run on the GPU box through gpurun; raw outputs in gpurun_out/prof/, summaries
+# Round profile of the headline command (run on the GPU box through gpurun; raw outputs in /tmp on the box, summaries
 # written by tools/summarize_profile.py into gpurun_out/prof_summary/ -- copy those into profiles/rNN/).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof
+OUT=/tmp/atom_prof_raw          # (raw rocprofv3 output stays on the box: gpurun copies at most 64 MiB of gpurun_out/ back)
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $R/bench.py --no-cpu-baseline --no-configs --steps 500 --warmup 100"   # 500 timed + 100 warm-up launches per operand format (+ the 1500-launch ramp)
+CMD="python $R/bench.py --no-cpu-baseline --no-configs --no-block --steps 500 --warmup 100"   # 500 timed + 100 warm-up launches per operand format (+ the 1500-launch ramp)
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
@@ -12,4 +12,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o bench -- $CMD > $OUT/sq1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM --output-format csv -d $OUT/sq2 -o bench -- $CMD > $OUT/sq2.log 2>&1
 tail -1 $OUT/stats.log
+# controls for the FETCH_SIZE / WRITE_SIZE corrections (tools/probes/fetch_control.cpp: 512 MiB streamed once per launch by LDS-DMA, by
+# 16-byte loads into registers, by 16-byte stores), in the same kind of pass
+CTL="$R/build/tools/fetch_control 512 5"
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ctl_fetch -o ctl -- $CTL > $OUT/ctl_fetch.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/ctl_write -o ctl -- $CTL > $OUT/ctl_write.log 2>&1
 cd $R && python tools/summarize_profile.py $OUT $R/gpurun_out/prof_summary
