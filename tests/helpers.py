@@ -132,3 +132,34 @@ def f6_fields(buf):
     f = np.stack([(w >> (6 * i)) & 0x3F for i in range(4)], axis=-1).reshape(*buf.shape[:2], 128).astype(np.uint8)
     f[f == 0x20] = 0
     return f
+
+
+def recover_fake_quant(v, qmax, group):
+    """Integer codes and the per-(row, group) fp16 scale of a fake-quantised tensor v = half(code * s) (what the reference's
+    quantisers return, model/quant.py:141-181): the largest-code candidate s = half(max|v| / k), k = qmax + 1 .. 1 (and its fp16
+    neighbours), for which every element is reproduced EXACTLY by an integer code in [-qmax - 1, qmax].  Where several (code, s)
+    pairs describe the same numbers they differ by a power of two and the GEMM contract gives identical sums.  Returns
+    (codes int32 [rows, cols], scales fp16 [rows, groups]); raises if a group is on no such grid.  (The same search as
+    tests/golden/gen_golden_block7b.py:recover_scales, which wrote the wide 7B fixture with it.)"""
+    v = np.asarray(v, dtype=np.float16)
+    r, h = v.shape
+    x = v.astype(np.float32).reshape(r, h // group, group)
+    vmax = np.abs(x).max(-1)
+    best = np.zeros(vmax.shape, dtype=np.float16)
+    done = vmax == 0
+    best[done] = 1.0
+    for k in range(qmax + 1, 0, -1):
+        base = (vmax / k).astype(np.float16)
+        for dlt in (0, 1, -1):
+            cand = (base.view(np.int16) + dlt).view(np.float16)
+            cf = cand.astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                c = np.rint(x / cf[..., None])
+            ok = (np.abs(c).max(-1) <= qmax + 1) & (c.max(-1) <= qmax) & np.isfinite(cf) & (cf > 0)
+            ok &= ((c * cf[..., None]).astype(np.float16) == x.astype(np.float16)).all(-1)
+            take = ok & ~done
+            best[take] = cand[take]
+            done |= take
+    assert done.all(), "fake-quantised group not reproducible by integer codes: %d of %d" % ((~done).sum(), done.size)
+    codes = np.rint(x / best.astype(np.float32)[..., None]).astype(np.int32).reshape(r, h)
+    return codes, best

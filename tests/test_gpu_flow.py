@@ -11,8 +11,14 @@ repository's mirror; that the reference's own flow code drives our classes ident
 Statements, sharp to statistical:
   (1) every projection's fake-quantised fp16 weight after reorder + RTN equals the reference's bit for bit (probe + checksum):
       the reorder wiring (input columns, gate/up output rows, q/k/v sharing k_proj's order) and the packer are the reference's;
-  (2) the first quantiser of the model (RMSNorm -> gather -> INT4/INT8) reproduces the reference's tensor: <= 0.5 % one-code flips
-      (the a8 tolerance, torch's unspecified reduction order);
+  (2) the first quantiser of the model (RMSNorm -> gather -> INT4/INT8) reproduces the reference's tensor, counted the way
+      tests/test_gpu_ref.py counts: INT4 / INT8 CODES that differ (<= 0.5 %, by one step: the a8 tolerance, torch's unspecified reduction
+      order) and, separately, (row, group) SCALES that moved (<= 3 % of the groups, by one fp16 ulp: a last-bit difference in a row's
+      variance moves a whole group's scale -- and with it all 128 of its fake-quantised values, which is why the plain count of
+      differing ELEMENTS reads 1.3 %);
+  (2b) ABSOLUTE, uncalibrated: every recorded projection of the reference run (q / o / gate / down of both layers, the rows the golden
+      holds) teacher-forced -- the HIP GEMM on the reference's OWN fake-quantised input (codes and scales recovered exactly) against the
+      reference's OWN output: <= 1e-3 relative Frobenius, every element within 1e-2 of max(|ref|, rms) (north_star's tolerance);
   (3) layer outputs, quantiser inputs downstream and the perplexity within bounds calibrated as in tests/test_gpu_block.py: W4A4 is
       chaotic in its rounding, an integer-exact GEMM differs from F.linear on fp16-rounded fake-quant operands by ~3e-4, and that
       flips codes downstream.  A mis-wired flow (a wrong reorder index, a quantiser left unconfigured, a layer skipped) lands far
@@ -25,7 +31,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, "gpurun_out", "r04", "flow_parity.txt")
+REPORT = os.path.join(ROOT, "gpurun_out", "r05", "flow_parity.txt")
 
 
 def _tokens(golden_dir, prefix):
@@ -40,6 +46,27 @@ def _rel(a, b):
 
 def _flips(a, b):
     return float((a != b).mean())
+
+
+def _code_and_scale_moves(got, ref):
+    """A fake-quantised activation tensor [rows, hidden] (INT4 groups of 128, the last 128 channels INT8) against the reference's:
+    (fraction of codes that differ, largest code difference, fraction of (row, group) scales that differ, largest scale difference
+    in fp16 ulps)."""
+    from tests.helpers import bits16, recover_fake_quant
+    flips, steps, moved, ulps, n, ng = 0, 0, 0, 0, 0, 0
+    for sl, qmax in ((slice(None, -128), 7), (slice(-128, None), 127)):
+        cg, sg = recover_fake_quant(got[:, sl], qmax, 128)
+        cr, sr = recover_fake_quant(ref[:, sl], qmax, 128)
+        # a pair (code, s) and (2 code, s / 2) is the same tensor: compare codes on the reference's scale grid
+        ratio = sg.astype(np.float32) / sr.astype(np.float32)
+        pow2 = (ratio == 2.0) | (ratio == 0.5) | (ratio == 4.0) | (ratio == 0.25)
+        cgn = np.where(np.repeat(pow2, 128, axis=1), np.rint(cg * np.repeat(ratio, 128, axis=1)), cg).astype(np.int32)
+        d = np.abs(cgn - cr)
+        flips += int((d > 0).sum()); steps = max(steps, int(d.max())); n += d.size
+        du = np.abs(bits16(sg).astype(np.int32) - bits16(sr).astype(np.int32))
+        du = np.where(pow2, 0, du)
+        moved += int((du > 0).sum()); ulps = max(ulps, int(du.max())); ng += du.size
+    return flips / n, steps, moved / ng, ulps
 
 
 def _report(lines):
@@ -57,6 +84,7 @@ def _measure(got, ref, seqlens):
     m = {}
     for s in seqlens:
         m[s, "first_q_flips"] = _flips(got[f"s{s}.L0.q_proj.in"], ref[f"s{s}.L0.q_proj.in"])
+        m[s, "first_q_codes"] = _code_and_scale_moves(got[f"s{s}.L0.q_proj.in"], ref[f"s{s}.L0.q_proj.in"])
         m[s, "first_q"] = _rel(got[f"s{s}.L0.q_proj.in"], ref[f"s{s}.L0.q_proj.in"])
         for key in KEYS:
             m[s, key] = _rel(got[f"s{s}.{key}"], ref[f"s{s}.{key}"])
@@ -84,8 +112,34 @@ class _Calibration:
     (B) the reference-order run -- packed operands dropped, so QLinearLayer.forward is the reference's F.linear on the fake-quant
     fp16 tensors, quantisers still HIP; (C) run B with every GEMM output perturbed by Gaussian noise of run A's measured size."""
 
-    def __init__(self):
+    def __init__(self, ref=None, seqlens=()):
         self.gemm_rel = {}
+        self.ref, self.seqlens = ref, seqlens
+        self.forced = []                 # (key, seqlen, rel. Frobenius, worst element / max(|ref|, rms)) of the teacher-forced projections
+
+    def teacher_force(self, model):
+        """Statement (2b) of the module docstring: the HIP GEMM of every recorded projection on the reference's own input."""
+        from atom_amd import ops
+        from oracle import atom_oracle as O
+        from tests.helpers import recover_fake_quant
+        for s in self.seqlens:
+            for i, layer in enumerate(model.model.layers):
+                for mod, proj in (("self_attn", "q_proj"), ("self_attn", "o_proj"), ("mlp", "gate_proj"), ("mlp", "down_proj")):
+                    key = f"L{i}.{proj}"
+                    x, y = self.ref[f"s{s}.{key}.in"], self.ref[f"s{s}.{key}.out"].astype(np.float64)
+                    lin = getattr(getattr(layer, mod), proj)
+                    w = lin.weight.detach().half().cuda().contiguous()       # the evaluation moves the layers itself; this is a copy
+                    b4, b8, sb, sb8, bad = ops.pack_weight_w4(w, int(lin.args.weight_channel_group), strict=False)
+                    assert bad == 0, (key, bad)
+                    c4, s4 = recover_fake_quant(x[:, :-128], 7, 128)
+                    c8, s8 = recover_fake_quant(x[:, -128:], 127, 128)
+                    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                    D = ops.dense_layer_gemm_i4_fp16(f(O.pack_int4(c4.astype(np.int8))), b4, f(s4.T), sb, f(c8.astype(np.int8)), b8, f(s8[:, 0]), sb8,
+                                                     scale_layout="plain")
+                    d = D.double().cpu().numpy()
+                    rel = float(np.linalg.norm(d - y) / np.linalg.norm(y))
+                    worst = float((np.abs(d - y) / np.maximum(np.abs(y), np.sqrt((y ** 2).mean()))).max())
+                    self.forced.append((key, s, rel, worst))
 
     @staticmethod
     def _linears(model):
@@ -103,6 +157,8 @@ class _Calibration:
             return f
         for key, lin in self._linears(model):
             lin.register_forward_hook(hook(key))
+        if self.ref is not None:
+            self.teacher_force(model)
 
     @staticmethod
     def _drop_packed(model):
@@ -134,7 +190,7 @@ def _calibrated(tag, config, tokens, ref, seqlens, gptq_q=None):
     """The HIP run against the golden, bounded by what the SAME flow does when its GEMMs are the reference's F.linear perturbed by
     the HIP GEMM's own measured deviation (see the module docstring, (3))."""
     from tests import flow_run
-    cal = _Calibration()
+    cal = _Calibration(ref, seqlens)
     runs = {}
     for name, prep in (("HIP", cal.hip), ("reference-order", cal.reference_order), ("perturbed reference-order", cal.perturbed)):
         got = flow_run.run("atom", config, tokens, gptq_q=gptq_q, prepare=prep)
@@ -144,14 +200,21 @@ def _calibrated(tag, config, tokens, ref, seqlens, gptq_q=None):
             lines.append(f"W4A4 GEMM vs F.linear on its own fake-quant operands, rel. Frobenius: worst call {worst:.2e}, "
                          f"mean {np.mean([np.mean(v) for v in cal.gemm_rel.values()]):.2e} ({sum(len(v) for v in cal.gemm_rel.values())} calls)")
             assert worst <= 2e-3, worst
+            fr, fw = max(t[2] for t in cal.forced), max(t[3] for t in cal.forced)
+            lines.append(f"teacher-forced on the reference's own inputs ({len(cal.forced)} projection x sequence-length cases): HIP GEMM vs "
+                         f"the reference's own outputs, worst rel. Frobenius {fr:.2e}, worst element / max(|ref|, rms) {fw:.2e}")
+            assert fr <= 1e-3 and fw <= 1e-2, cal.forced
         runs[name] = _measure(got, ref, seqlens)
     bad = []
     for s in seqlens:
         h, b, c = (runs[n] for n in ("HIP", "reference-order", "perturbed reference-order"))
         lines.append(f"seqlen {s}: first quantiser (L0 input_layernorm -> q/k/v) vs the reference's tensor: differing elements "
                      f"{h[s, 'first_q_flips']:.5f}, rel. Frobenius {h[s, 'first_q']:.6f}")
-        if not (h[s, "first_q_flips"] <= 3e-2 and h[s, "first_q"] <= 1e-3):
-            bad.append((s, "first quantiser"))
+        cf, cstep, sm, sulp = h[s, "first_q_codes"]
+        lines.append(f"    ... of which codes that differ {cf:.5f} (by at most {cstep} step), (row, group) scales that moved {sm:.5f} "
+                     f"(by at most {sulp} fp16 ulp)")
+        if not (cf <= 5e-3 and cstep <= 1 and sm <= 3e-2 and sulp <= 1 and h[s, "first_q"] <= 1e-3):
+            bad.append((s, "first quantiser", h[s, "first_q_codes"]))
         lines.append(f"seqlen {s}: rel. Frobenius vs the reference golden      HIP    ref-order   perturbed ref-order")
         for key in KEYS + ("layer0", "layer1"):
             lines.append(f"    {key:18s} {h[s, key]:10.4f} {b[s, key]:10.4f} {c[s, key]:10.4f}")
