@@ -17,4 +17,7 @@ tail -1 $OUT/stats.log
 CTL="$R/build/tools/fetch_control 512 5"
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ctl_fetch -o ctl -- $CTL > $OUT/ctl_fetch.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/ctl_write -o ctl -- $CTL > $OUT/ctl_write.log 2>&1
+# config 4 (the Llama-7B decoder block of the default bench line's `block` key) under the same tracer: per-kernel split of one block
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/block -o block -- python $R/tools/block_bench.py > $OUT/block.log 2>&1
+tail -12 $OUT/block.log
 cd $R && python tools/summarize_profile.py $OUT $R/gpurun_out/prof_summary

@@ -24,6 +24,17 @@ def kernel_source_sha():
 
 def main(raw, out):
     os.makedirs(out, exist_ok=True)
+    bstats = glob.glob(os.path.join(raw, "block", "**", "*kernel_stats.csv"), recursive=True)
+    if bstats:                                             # the decoder block (tools/block_bench.py) -> block_kernel_stats.csv
+        rows = list(csv.DictReader(open(bstats[0])))
+        with open(os.path.join(out, "block_kernel_stats.csv"), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+            for r in rows:
+                w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+        if os.path.exists(os.path.join(raw, "block.log")):
+            with open(os.path.join(out, "block_bench_under_rocprof.txt"), "w") as f:
+                f.write(open(os.path.join(raw, "block.log")).read()[-4000:])
     stats = glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
