@@ -580,7 +580,10 @@ static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   constexpr bool NORMOP = OP == OP_RMSNORM || OP == OP_ADD_RMSNORM;
   const size_t base = (OP == OP_ADD_RMSNORM ? 4 : 2) * rowb + 1024;
   p.w_lds = NORMOP && base + rowb <= 160 * 1024;
-  const size_t lds = base + (p.w_lds ? rowb : 0);
+  size_t lds = base + (p.w_lds ? rowb : 0);
+#ifdef ATOM_TOOLS   // occupancy experiments: unused LDS that lowers the number of resident workgroups (profiles/r05/quant_occupancy.txt)
+  if (const char *e = getenv("ATOM_Q_EXTRA_LDS")) lds = lds + (size_t)atoi(e) <= 160 * 1024 ? lds + (size_t)atoi(e) : lds;
+#endif
   // the dynamic-LDS attribute is per device (ensure_max_lds); the occupancy answer depends on the device and on the LDS size, i.e.
   // on H: one cached (lds, resident) word per device slot and kernel (a race re-computes the same value)
   static std::atomic<uint64_t> lds_set{0};
