@@ -42,6 +42,7 @@ SIGNATURES = {
     "atom_gemm_w4a4_f16": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_ws_recodes": (_int, [_i64, _i64, _i64]),
+    "atom_gemm_w4a4_ws_recodes_cached": (_int, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_packed_order": (_int, [_i64, _i64, _i64, _int]),
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_multi_fits": (_int, [_i64, _i64, _int, _i64]),

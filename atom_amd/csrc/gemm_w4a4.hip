@@ -262,9 +262,12 @@ static bool f6_route(int64_t M, int64_t N, int64_t K_total) {
 }
 // ... and with the weight's BF6 form already in the workspace (ATOM_WS_WEIGHT_CACHED) from 129 rows whatever the decode kernels take: only
 // the activation is re-coded, and the mid-size-batch kernel runs 129 .. 256 rows in ~10 us at 4096 x 4096 (decode-batch kernel: 9.4 .. 15.5)
+// -- and from 17 rows where the decode-batch kernel does not take the shape (large N x K): re-coding 64 activation rows costs ~2.5 us and
+// the BF6 mid-size-batch kernel then runs 64 x 13824 x 5120 in 12.2 us where the INT8 form takes 22.4, 64 x 5120 x 13824 in 24.6 against
+// 32.5 on split-K tiles (profiles/r05/mid_f6c.txt, bench.py configs rows)
 static bool f6_route_cached(int64_t M, int64_t N, int64_t K_total) {
   if (ATOM_TUNE("ATOM_NO_F6_ROUTE", 0) || N < 2048 || K_total < 1024) return false;
-  return M > 128;
+  return M > 128 || (M > 16 && !skinny_fits(M, N, K_total));
 }
 static size_t f6_bytes(int64_t rows, int64_t K_total) {
   return (size_t)((K_total - kKeeper) / kGroup) * (size_t)((rows + 255) / 256 * 256) * 104;
@@ -289,12 +292,19 @@ int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total) {
   return f6_route(M, N, K_total) ? 1 : 0;
 }
 
+int atom_gemm_w4a4_ws_recodes_cached(int64_t M, int64_t N, int64_t K_total) {
+  if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  return f6_route(M, N, K_total) || f6_route_cached(M, N, K_total) ? 1 : 0;
+}
+
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
-  if (f6_route(M, N, K_total) || f6_route_cached(M, N, K_total))
-    return f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;   // B: + float32 scales
   const int s = choose_splits(M, N, K_total);
-  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t split = s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t f6 = f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;     // B: + float32 scales
+  if (f6_route(M, N, K_total)) return f6;
+  if (f6_route_cached(M, N, K_total)) return f6 > split ? f6 : split;             // (splits K without ATOM_WS_WEIGHT_CACHED, re-codes with it)
+  return split;
 }
 
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB, const void *A8, const void *B8,

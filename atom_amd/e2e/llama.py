@@ -90,11 +90,10 @@ class LinearInt4(nn.Module):
 
     def forward(self, input):
         outlier, norms, outlier_scales, norm_scales = input
-        if (norms.dim() == 2 and self.out_dtype == "fp16" and outlier.size(0) >= 512 and self.out_features >= 2048
-                and self.in_features >= 1024):
-            # prefill batch in the reference's packed format (from 512 rows: with the cached weight the F6 kernels win from there): the GEMM would
-            # re-code BOTH operands to F6 in its workspace on every call; re-code the activation here and use the layer's cached F6
-            # weight instead (same kernel, same bits)
+        if norms.dim() == 2 and self.out_dtype == "fp16" and ops.gemm_recodes_cached(outlier.size(0), self.out_features, self.in_features):
+            # a batch in the reference's packed format that the BF6 kernels serve faster once the weight's BF6 form exists (from 129 rows; from
+            # 17 where the decode-batch kernel does not take the shape): re-code the activation here and use the layer's own cached BF6
+            # weight (same kernel, same bits as the workspace route of the GEMM op, which would keep a second copy of the weight)
             norms = ops.repack_act_f6(norms.view(torch.uint8), norm_scales)
         if norms.dim() == 3:                                  # the F6 activation operand [G][rows_pad][104] (fp16 output only)
             assert self.out_dtype == "fp16"

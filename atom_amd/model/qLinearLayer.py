@@ -126,15 +126,20 @@ class QLinearLayer(nn.Module):
         packed = self.packed_weight(need_codes=codes.wide != "f6" or self._f6 is None) if codes is not None else None
         if packed is not None and codes.hidden == self.weight.shape[1] and x.is_cuda:
             b4, b8, sb, sb8 = packed
-            if codes.wide == "f6":                        # BF6 operands: the weight is repacked once per packed form
+            o4, wide = codes.o4, codes.wide
+            if not wide and _ops.gemm_recodes_cached(o4.shape[0], self.weight.shape[0], self.weight.shape[1]):
+                # packed codes of a batch the BF6 kernels serve faster with the weight's BF6 form at hand (large N x K below 129 rows):
+                # re-code the activation and use this layer's BF6 weight, instead of a second copy in the GEMM op's per-weight cache
+                o4, wide = _ops.repack_act_f6(o4.view(torch.uint8), codes.s4, scale_layout=codes.layout), "f6"
+            if wide == "f6":                              # BF6 operands: the weight is repacked once per packed form
                 if self._f6 is None or self._f6[0] != self._packed_key:
                     if b4 is None:
                         b4 = self.packed_weight(need_codes=True)[0]
                     self._f6 = (self._packed_key, _ops.repack_weight_f6(b4, sb))
                     self.release_codes()                  # keep_packed_with_f6 = False (see the class comment)
                 b4 = self._f6[1]
-            y = _ops.dense_layer_gemm_i4_fp16(codes.o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
-                                              scale_layout=codes.layout, a_wide=codes.wide)
+            y = _ops.dense_layer_gemm_i4_fp16(o4, b4, codes.s4, sb, codes.o8, b8, codes.s8, sb8,
+                                              scale_layout=codes.layout, a_wide=wide)
             y = y.view(*x.shape[:-1], self.weight.shape[0])
             if self.bias is not None:
                 y = y + self.bias

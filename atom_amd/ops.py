@@ -243,6 +243,13 @@ def _weight_f6s(b, b_scale, n, k):
     return f6
 
 
+def gemm_recodes_cached(m, n, k):
+    """True where a packed activation of m rows should be re-coded to BF6 for a weight [n, k] whose BF6 form is at hand (the rule of
+    ATOM_WS_WEIGHT_CACHED, atom_gemm_w4a4_ws_recodes_cached in include/atom_hip.h): what modules that own their weight's BF6 form ask,
+    so that it is not made a second time in this module's per-weight cache."""
+    return bool(L.lib().atom_gemm_w4a4_ws_recodes_cached(int(m), int(n), int(k)))
+
+
 def _gemm_dims(a, b, a_keeper, a_wide=False, b_keeper=None):
     if a_wide == "f6":                                             # [G][rows_pad][104]: sizes come from the keepers
         return a_keeper.size(0), b_keeper.size(0), a.size(0) * GROUP_SIZE + a_keeper.size(1)
@@ -270,9 +277,10 @@ def dense_layer_gemm_i4_fp16(a, b, a_scale, b_scale, a_keeper, b_keeper, a_keepe
     ws_bytes = lib.atom_gemm_w4a4_workspace_bytes(m, n, k) if not (a_wide == "f6" or (a_wide and m >= 2048)) else 0
     # packed operands of prefill size (the re-coding route): with the weight's F6 form cached (per weight, _weight_f6s) only the
     # activation is re-coded, into a fresh tensor, and the F6 kernel runs on the two -- the kernel and the bits of the workspace route
-    # (with the weight's BF6 form cached the route starts at 129 rows -- only the activation is re-coded and the mid-size-batch BF6
-    # kernel beats the decode kernels there: ATOM_WS_WEIGHT_CACHED's rule in include/atom_hip.h)
-    if ws_bytes and not a_wide and (lib.atom_gemm_w4a4_ws_recodes(m, n, k) or (m > 128 and n >= 2048 and k >= 1024)):
+    # (with the weight's BF6 form cached the route starts at 129 rows, and at 17 where the decode-batch kernel does not take the shape
+    # -- only the activation is re-coded and the mid-size-batch BF6 kernel beats what runs otherwise: ATOM_WS_WEIGHT_CACHED's rule,
+    # atom_gemm_w4a4_ws_recodes_cached in include/atom_hip.h)
+    if ws_bytes and not a_wide and lib.atom_gemm_w4a4_ws_recodes_cached(m, n, k):
         f6w = _weight_f6s(b, b_scale, n, k)
         if f6w is not None:
             a6 = repack_act_f6(a.view(torch.uint8), a_scale, scale_layout=scale_layout)

@@ -206,7 +206,7 @@ def configs_sweep(dev):
                "cold_gbps": round(by / cold / 1e3, 1), "cold_frac_hbm": round(by / cold / 1e6 / 8.0, 4),
                "hot_frac_hbm": round(by / hot / 1e6 / 8.0, 4),
                "cold_tops": round(op / cold / 1e6, 1), "cold_frac_mfma": round(op / cold / 1e6 / PEAK_I8_TOPS, 4)}
-        if M >= 129:                                            # the C ABI with one workspace per weight (ATOM_WS_WEIGHT_CACHED): activation re-coded per call
+        if lib.atom_gemm_w4a4_ws_recodes_cached(M, N, K):      # the C ABI with one workspace per weight (ATOM_WS_WEIGHT_CACHED): activation re-coded per call
             wh, wc = CB.gemm_row(M, N, K, quiet=True, weight_cached=True)
             row.update({"wcached_hot_us": round(wh, 2), "wcached_cold_us": round(wc, 2)})
         if M >= 129:                                            # (the drop-in modules ask the quantisers for BF6 codes from 129 rows)

@@ -163,6 +163,10 @@ size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total);
 /* 1 when atom_gemm_w4a4_f16_ws takes use (2) for packed operands of this shape (the workspace then starts with the re-coded weight:
  * F6 records + float32 scales, atom_f6_weight_bytes(N, K_total) bytes, whatever M is -- what ATOM_WS_WEIGHT_CACHED refers to) */
 int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total);
+/* ... the same question for a call that passes ATOM_WS_WEIGHT_CACHED (the weight region holds this weight's BF6 form already, only the
+ * activation is re-coded): additionally every shape of 129 rows and more, and from 17 rows the shapes the decode-batch kernel does not
+ * take (N >= 2048, K >= 1024 throughout).  What a binding that keeps one workspace per weight asks. */
+int atom_gemm_w4a4_ws_recodes_cached(int64_t M, int64_t N, int64_t K_total);
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB,
                           const void *A8, const void *B8, const void *sA8, const void *sB8,
                           void *D, int64_t M, int64_t N, int64_t K_total,

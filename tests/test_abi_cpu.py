@@ -85,6 +85,14 @@ def test_packed_route_query():
     G = (4096 - 128) // 128
     assert wsb(300, 4096, 4096) == G * 512 * 104 + G * 4096 * 108
     assert rec(0, 4096, 4096) == 0 and rec(300, 4096, 4000) == 0
+    # with the weight's BF6 form cached (ATOM_WS_WEIGHT_CACHED): every shape from 129 rows, and from 17 rows what the decode-batch kernel
+    # does not take
+    recc = L.atom_gemm_w4a4_ws_recodes_cached
+    assert recc(4096, 4096, 4096) == 1 and recc(256, 4096, 4096) == 1 and recc(129, 4096, 4096) == 1
+    assert recc(64, 13824, 5120) == 1 and recc(64, 5120, 13824) == 1 and recc(100, 8192, 8192) == 1
+    assert recc(64, 4096, 4096) == 0 and recc(128, 11008, 4096) == 0 and recc(16, 13824, 5120) == 0 and recc(64, 1024, 13824) == 0
+    assert wsb(64, 13824, 5120) > 0 and L.atom_gemm_w4a4_packed_order(64, 13824, 5120, 2) == 1
+    assert L.atom_gemm_w4a4_packed_order(64, 5120, 13824, 1) > 100 and wsb(64, 5120, 13824) >= 8 * 64 * 5120 * 4   # split K without the flag
 
 
 def test_fused_quantiser_shape_query():

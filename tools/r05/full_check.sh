@@ -1,17 +1,16 @@
 #!/bin/bash
-# Round 5: the whole GPU suite + the driver's bench command on the current tree (one gpurun call)
+# Round 5: the whole GPU suite + the default driver line on the current tree
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/r05; mkdir -p $O
-python -m pytest tests -m gpu -q > $O/pytest_full.txt 2>&1; echo "pytest rc $?" >> $O/pytest_full.txt
-tail -12 $O/pytest_full.txt
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt; echo "bench rc $?"
-python - <<'P'
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 > $O/pytest_gpu_full.txt
+cat $O/pytest_gpu_full.txt
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+tail -c 600 $O/bench_default.err
+python3 - <<PY
 import json
-d=json.loads(open("gpurun_out/r05/bench_line.json").read().strip().splitlines()[-1])
-print("value", d["value"], "kernel_us", d["roofline"]["kernel_us"], "frac", d["roofline"]["frac"], "cold", d.get("cold",{}).get("kernel_us"))
-print("block", json.dumps(d.get("block"))[:600])
-for r in d.get("configs",{}).get("rows",[]):
-    print(r["config"], r["M"], r["N"], r["K"], "hot", r["hot_us"], "cold", r["cold_us"], "f6", r.get("f6_us"))
-for k,v in d.get("other_operand_formats",{}).items(): print(k, v["kernel_us"], v["bit_identical_to_headline_output"])
-P
-tail -5 $O/bench_err.txt
+d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+print({k:d[k] for k in ("value","ms_per_step")}, d["roofline"]["frac"], d["roofline"]["kernel_us"], d["roofline"]["traffic"])
+for r in d["configs"]["rows"]:
+    print({k:r[k] for k in ("M","N","K","hot_us","cold_us") }, {k:v for k,v in r.items() if k.startswith(("wcached","f6_us","f6_cold"))})
+print(d.get("block",{}).get("block_ms"), d.get("block",{}).get("gemm_tops"))
+PY
