@@ -17,6 +17,7 @@ Keyword-only extras (defaults reproduce the reference CUDA kernels exactly):
 from __future__ import annotations
 
 import collections
+import weakref
 
 import torch
 
@@ -183,14 +184,38 @@ def _workspace(device, nbytes):
 # (12 vs 6 us at 4096 x 4096).  So the F6 form of every weight seen here is kept -- per WEIGHT (its own tensor, nothing shares it), keyed
 # by the storage addresses and version counters of the packed weight and its scales, least recently used first out under a byte cap.
 # A Llama-7B's 224 projections are 5.5 GB in this form (0.84 B per weight) next to 288 GB of HBM.
-#   * an entry holds references to the packed tensors' storages, so a cached address cannot be handed to another tensor;
+#   * an entry dies with the packed weight: weakref finalizers on the storages of the weight and of its scales drop it (so a cached
+#     address is never handed to another tensor while its entry lives, and deleting a model frees its BF6 forms -- rounds 3-4 held
+#     strong references);
+#   * the byte cap defaults to an eighth of the device's memory, at most 32 GiB (set_weight_f6_cache_bytes changes it);
+#   * an entry is complete before its first use on ANY stream: the stream that re-coded the weight is synchronised once, at creation;
+#   * tensors made under torch.inference_mode() have no version counter: they count as version -1 (they cannot be written in place);
 #   * a weight rewritten in place bumps its version counter -> miss (writes through a `.data` / `.detach()` alias do NOT bump it:
 #     call forget_weight_f6(b) after such a write);
 #   * HIP-graph capture: nothing executes during capture, so an entry is never CREATED there (the call takes the workspace route and
 #     re-codes both operands inside the captured graph -- always right); a HIT during capture pins the entry for good, because the
 #     captured launch keeps pointing at it.
-_F6W = collections.OrderedDict()      # key -> [f6s tensor, storages kept alive, bytes, pinned]
-_F6W_STATE = {"limit": 32 << 30, "bytes": 0, "hits": 0, "misses": 0}
+_F6W = collections.OrderedDict()      # key -> [f6s tensor, finalizers, bytes, pinned]
+_F6W_STATE = {"limit": None, "bytes": 0, "hits": 0, "misses": 0}
+
+
+def _f6w_limit(device):
+    if _F6W_STATE["limit"] is None:
+        _F6W_STATE["limit"] = min(32 << 30, torch.cuda.get_device_properties(device).total_memory // 8)
+    return _F6W_STATE["limit"]
+
+
+def _version_of(t):
+    try:
+        return t._version
+    except RuntimeError:                                     # inference tensors do not track a version counter
+        return -1
+
+
+def _drop_f6w(key):
+    e = _F6W.pop(key, None)
+    if e is not None:
+        _F6W_STATE["bytes"] -= e[2]
 
 
 def set_weight_f6_cache_bytes(limit: int):
@@ -200,6 +225,9 @@ def set_weight_f6_cache_bytes(limit: int):
 
 
 def clear_weight_f6_cache():
+    for e in _F6W.values():
+        for f in e[1]:
+            f.detach()
     _F6W.clear()
     _F6W_STATE.update(bytes=0, hits=0, misses=0)
 
@@ -207,21 +235,23 @@ def clear_weight_f6_cache():
 def forget_weight_f6(b: torch.Tensor):
     """Drop the cached F6 form(s) of the packed weight ``b`` (after writing it through an alias that keeps the version counter)."""
     for key in [k for k in _F6W if k[1] == b.data_ptr() and k[0] == b.device]:
-        _F6W_STATE["bytes"] -= _F6W.pop(key)[2]
+        _drop_f6w(key)
 
 
 def _evict_f6w():
     for key in list(_F6W):
-        if _F6W_STATE["bytes"] <= _F6W_STATE["limit"]:
+        if _F6W_STATE["limit"] is None or _F6W_STATE["bytes"] <= _F6W_STATE["limit"]:
             break
         if not _F6W[key][3]:
-            _F6W_STATE["bytes"] -= _F6W.pop(key)[2]
+            for f in _F6W[key][1]:
+                f.detach()
+            _drop_f6w(key)
 
 
 def _weight_f6s(b, b_scale, n, k):
     """The cached F6 form (codes + float32 scales, ATOM_B_F6S) of a packed weight, or None when there is none and none may be made."""
     capturing = torch.cuda.is_current_stream_capturing()
-    key = (b.device, b.data_ptr(), b._version, b_scale.data_ptr(), b_scale._version, n, k)
+    key = (b.device, b.data_ptr(), _version_of(b), b_scale.data_ptr(), _version_of(b_scale), n, k)
     e = _F6W.get(key)
     if e is not None:
         _F6W.move_to_end(key)
@@ -229,7 +259,7 @@ def _weight_f6s(b, b_scale, n, k):
         if capturing:
             e[3] = True
         return e[0]
-    if capturing or _F6W_STATE["limit"] <= 0:
+    if capturing or _f6w_limit(b.device) <= 0:
         return None
     _F6W_STATE["misses"] += 1
     g = k // GROUP_SIZE - 1
@@ -237,7 +267,9 @@ def _weight_f6s(b, b_scale, n, k):
     nbytes = f6.atom_f6s.numel()
     if nbytes > _F6W_STATE["limit"]:
         return f6
-    _F6W[key] = [f6, (b.untyped_storage(), b_scale.untyped_storage()), nbytes, False]
+    torch.cuda.current_stream(b.device).synchronize()        # complete before any other stream (or a graph captured later) reads it
+    fin = tuple(weakref.finalize(st, _drop_f6w, key) for st in (b.untyped_storage(), b_scale.untyped_storage()))
+    _F6W[key] = [f6, fin, nbytes, False]
     _F6W_STATE["bytes"] += nbytes
     _evict_f6w()
     return f6
@@ -405,8 +437,11 @@ def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, 
     """NEW (decode steps of one or two tokens; no reference counterpart): dense_layer_gemm_i4_multi with the quantiser that precedes
     it in the reference's call order INSIDE the launch -- ``q_op`` "reorder" (reorder_fp16_i4), "rmsnorm" (rmsnorm_fp16_i4, ``x2`` = the
     norm weight), "add_rmsnorm" (add_rmsnorm_fp16_i4: returns x + residual as well) or "silu_mul" (activate_fp16_i4, ``x2`` = the second
-    factor); kernel-flavoured quantiser arithmetic.  ``x`` fp16 [M, K].  Returns (outs, residual_out): bit-identical to the quantiser op
-    followed by dense_layer_gemm_i4_multi."""
+    factor); kernel-flavoured quantiser arithmetic.  ``x`` fp16 [M, K].  Returns (outs, residual_out).  The quantised operand is
+    bit-identical to the quantiser op's; the GEMM behind it always runs the decode-batch kernel (summation order 8: eight wave slices,
+    atom_gemm_w4a4_packed_order), so the outputs are bit-identical to quantiser op + dense_layer_gemm_i4_multi wherever THAT runs the
+    decode-batch kernel too -- two tokens with K <= 4096 -- and within one fp16 ulp where it runs the dot-product kernel (order 64): one
+    token, and two tokens with K > 4096 (the rule of gemv_tokens() in csrc/gemm_w4a4.hip).  tests/test_gpu_e2e.py states both."""
     _require_cuda_half(x, "x")
     code = _Q_OPS[q_op]
     m = x.size(0)

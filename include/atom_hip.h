@@ -228,7 +228,10 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
  *                              (NOT in place: every workgroup reads x and residual, workgroup 0 writes residual_out)
  *          ATOM_Q_SILU_MUL     x2 = the second factor [M, K_total]; no reorder index  = atom_silu_mul_quant_f16
  * in the kernel-flavoured arithmetic (quant_mode 0), clip as there.  Outputs, segments, f32_mask, add0_f16 as atom_gemm_w4a4_multi.
- * Bit-identical to the quantiser op followed by atom_gemm_w4a4_multi (tests/test_gpu_gemm.py).
+ * The quantised operand is bit-identical to the quantiser op's; the GEMM always runs the decode-batch kernel (summation order 8), so the
+ * outputs are bit-identical to the quantiser op followed by atom_gemm_w4a4_multi wherever that call runs the decode-batch kernel too
+ * (two tokens with K_total <= 4096), and within one fp16 ulp where it runs the dot-product kernel (order 64: one token; two tokens with
+ * K_total > 4096) -- atom_gemm_w4a4_packed_order(M, N, K_total, 0) tells which (tests/test_gpu_gemm.py, tests/test_gpu_e2e.py).
  */
 #define ATOM_Q_REORDER 1
 #define ATOM_Q_RMSNORM 2

@@ -417,6 +417,30 @@ def test_gemm_f6_two_k_group_kernels(M, N, K, want_cfg, f6s):
     assert torch.equal(D, out)
 
 
+@pytest.mark.parametrize("M,K,layout", [(64, 5120, "plain"), (1, 1152, "plain"), (200, 4224, "ref"), (2048, 1152, "plain"), (2049, 1408, "ref"),
+                                        (4096, 4096, "plain")])
+def test_repack_kernels_write_the_f6_records_bit_for_bit(M, K, layout):
+    """atom_repack_act_f6 (the 64-row-block kernel up to 2,048 rows, the 256-row LDS kernel beyond) and atom_repack_weight_f6s against
+    the numpy restatement of the record format (tests/helpers.f6_codes): code fields, the fp16 scale at byte 96, the same value as
+    float32 at byte 100, pad rows zero in the fields the GEMM reads; the weight's appended float32 scales."""
+    from tests.helpers import f6_codes, f6_fields
+    ops = _ops()
+    N = 320
+    d = rand_gemm_operands(M, N, K, seed=M + K)
+    t = to_device(d, layout)
+    a6 = t2n(ops.repack_act_f6(t[0].view(torch.uint8), t[2], scale_layout=layout))
+    want = f6_codes(d["qa4"], d["sA"])
+    assert a6.shape == want.shape
+    assert np.array_equal(f6_fields(a6[:, :M]), f6_fields(want[:, :M])) and np.array_equal(a6[:, :M, 96:98], want[:, :M, 96:98])
+    assert np.array_equal(a6[:, :M, 100:104], want[:, :M, 100:104])
+    b6 = ops.repack_weight_f6(t[1], t[3])
+    wb = f6_codes(d["qb4"])
+    assert np.array_equal(f6_fields(t2n(b6)[:, :N]), f6_fields(wb[:, :N]))
+    G, rp = wb.shape[0], wb.shape[1]
+    s32 = t2n(b6.atom_f6s)[G * rp * 104:].view(np.float32).reshape(G, rp)
+    assert np.array_equal(s32[:, :N], d["sB"].astype(np.float32))
+
+
 def test_gemm_f6_full_size_from_the_quantiser():
     """Headline shape end to end in the native format: activation quantiser (ATOM_QUANT_F6_CODES) -> F6 GEMM equals
     activation quantiser (packed) -> INT8 GEMM, bit for bit."""
@@ -619,6 +643,43 @@ def test_packed_route_weight_f6_cache():
     dev1[1].data.copy_(dev2[1].flip(0)); dev1[3].data.copy_(dev2[3])
     ops.forget_weight_f6(dev1[1])
     assert torch.equal(ops.dense_layer_gemm_i4_fp16(*dev1, scale_layout="plain"), uncached(dev1))
+    ops.clear_weight_f6_cache()
+
+
+def test_weight_f6_cache_lifetime_streams_and_inference_tensors():
+    """The per-weight BF6 cache of atom_amd.ops: an entry dies with its packed weight (weakref finalizers on the storages:
+    deleting a model frees its BF6 forms, and a freed address cannot hit a stale entry); an entry made on one stream is complete for a
+    call on another; weights created under torch.inference_mode() (no version counter) take the cache too."""
+    import gc
+    from atom_amd import ops
+    N, K = 2048, 1152
+    ops.clear_weight_f6_cache()
+    st = ops._F6W_STATE
+    d = to_device(rand_gemm_operands(512, N, K, seed=31), "plain")
+    ops.set_weight_f6_cache_bytes(0)
+    want = ops.dense_layer_gemm_i4_fp16(*d, scale_layout="plain")
+    ops.set_weight_f6_cache_bytes(32 << 30)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                            # the entry is made on a side stream ...
+        y0 = ops.dense_layer_gemm_i4_fp16(*d, scale_layout="plain")
+    assert len(ops._F6W) == 1 and st["misses"] == 1
+    y1 = ops.dense_layer_gemm_i4_fp16(*d, scale_layout="plain")   # ... and hit from the default stream straight away
+    side.synchronize()
+    assert st["hits"] == 1 and torch.equal(y0, want) and torch.equal(y1, want)
+    # the weight goes away: so does the entry
+    d = list(d)
+    d[1] = d[3] = None
+    gc.collect()
+    assert len(ops._F6W) == 0 and st["bytes"] == 0, (len(ops._F6W), st["bytes"])
+    # inference tensors
+    with torch.inference_mode():
+        di = to_device(rand_gemm_operands(512, N, K, seed=31), "plain")
+        y2 = ops.dense_layer_gemm_i4_fp16(*di, scale_layout="plain")
+        y3 = ops.dense_layer_gemm_i4_fp16(*di, scale_layout="plain")
+    assert torch.equal(y2, want) and torch.equal(y3, want) and len(ops._F6W) == 1
+    del di
+    gc.collect()
     ops.clear_weight_f6_cache()
 
 
