@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       for (int m2 = 0; m2 < MQ; ++m2) {
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
         const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
-        rinv[m2] = 1.0f / sqrtf(var + p.q_eps);
+        rinv[m2] = rinv_sqrt_exact(var + p.q_eps);
       }
     }
 #pragma unroll

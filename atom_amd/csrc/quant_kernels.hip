@@ -24,6 +24,7 @@
 // Arithmetic is specified to the bit (see oracle/atom_oracle.py): ATOM_QUANT_SIM follows
 // model/quant.py:141-181 (FP16 opmath), ATOM_QUANT_KERNEL follows Reorder.cuh:137-178 (FP32).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "quant_math.h"
@@ -231,12 +232,16 @@ __device__ __forceinline__ void quant_slot_h(const unsigned (&z)[8], const ActQu
 }
 
 // reorder / rmsnorm: persistent workgroups, LDS-DMA double buffer.  NP = slots (16 channels) per thread per row.
-template <int OP, bool SIM, bool DQ, int NP, int FMT>
+// HC != 0: an instance for ONE hidden size (the launcher picks it when p.H == HC).  Everything derived from H folds, and -- what pays --
+// the two row buffers sit at compile-time LDS offsets: the row loop is unrolled by two and a gathered channel's address is its
+// loop-invariant offset register + an IMMEDIATE, where the generic form adds the buffer base to 16 offsets per thread and row
+// (18 of the ~280 VALU instructions a wave spends on a row; round 5).
+template <int OP, bool SIM, bool DQ, int NP, int FMT, int HC = 0>
 __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = p.H;
+  const int H = HC ? HC : p.H;
   const int nslots = H >> 4;
   const int Gt = H >> 7;
   const int K4h = (H - kKeeper) >> 1;
@@ -356,7 +361,10 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       }
     }
   };
-  for (; r < rend; r += rstep, b ^= 1) {
+  // one row: bc = the buffer it sits in as a compile-time constant (HC instances: 0 / 1) or -1 = the run-time value brt
+  auto do_row = [&](auto bc, const int64_t r, const int brt) {
+    constexpr int BC = decltype(bc)::value;
+    const int b = BC < 0 ? brt : BC;
     __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0): my DMA writes have landed
     __syncthreads();
     const int64_t rn = r + rstep;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       const float tot = ((red[b * 4 + 0] + red[b * 4 + 1]) + red[b * 4 + 2]) + red[b * 4 + 3];
       // correctly rounded divide, sqrt and divide (hipcc default); a power-of-two H divides exactly by multiplying
       const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
-      rinv = 1.0f / sqrtf(var + p.eps);
+      rinv = rinv_sqrt_exact(var + p.eps);
     }
     if constexpr (SIM) {
       // the simulated path in the FP16 domain (quant_math.h): a slot as 8 half pairs, pair i = channels (pair_lo(i), pair_lo(i) + 4)
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
           }
         }
         flush(r);
-        continue;
+        return;
       }
     }
 
@@ -510,6 +518,18 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
       }
     }
     flush(r);
+  };
+  if constexpr (HC != 0) {
+    while (true) {
+      if (r >= rend) break;
+      do_row(std::integral_constant<int, 0>(), r, 0);
+      r += rstep;
+      if (r >= rend) break;
+      do_row(std::integral_constant<int, 1>(), r, 1);
+      r += rstep;
+    }
+  } else {
+    for (; r < rend; r += rstep, b ^= 1) do_row(std::integral_constant<int, -1>(), r, b);
   }
 }
 
@@ -573,7 +593,7 @@ static int resident_blocks(K kernel, size_t lds) {           // persistent grid:
   return per_cu * cus;
 }
 
-template <int OP, bool SIM, bool DQ, int NP, int FMT>
+template <int OP, bool SIM, bool DQ, int NP, int FMT, int HC = 0>
 static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   ActQuantParams p = p0;
   const size_t rowb = (size_t)((p.H * 2 + 1023) & ~1023);
@@ -588,7 +608,7 @@ static int launch_act_quant2_np(const ActQuantParams &p0, hipStream_t s) {
   // on H: one cached (lds, resident) word per device slot and kernel (a race re-computes the same value)
   static std::atomic<uint64_t> lds_set{0};
   static std::atomic<uint64_t> cache[64];
-  const auto kernel = act_quant2_kernel<OP, SIM, DQ, NP, FMT>;
+  const auto kernel = act_quant2_kernel<OP, SIM, DQ, NP, FMT, HC>;
   if (const int st = ensure_max_lds(reinterpret_cast<const void *>(kernel), 160 * 1024, lds_set); st != ATOM_OK) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return ATOM_ERR_LAUNCH;
@@ -612,6 +632,12 @@ static int launch_act_quant2_fmt(const ActQuantParams &p, hipStream_t s) {
     return ATOM_OK;
   } else {
     const int np = ((p.H >> 4) + 255) >> 8;
+    // the hidden size of Llama-7B has its own instances of the RMSNorm kernels (same box, 4096 / 65,536 rows: RMSNorm-quant 14.2-14.7 ->
+    // 13.7-13.8 / 160-162 -> 153-156 us, kernel-flavoured 15.0-15.8 -> 14.1-14.2 / 166 -> 158; the plain reorder gains nothing at
+    // 4,096 rows and loses 9 % at 65,536 in the kernel-flavoured mode: it keeps the generic form; profiles/r05/quant_valu.txt)
+    if constexpr (OP != OP_REORDER) {
+      if (np == 1 && p.H == 4096) return launch_act_quant2_np<OP, SIM, DQ, 1, FMT, 4096>(p, s);
+    }
     if (np == 1) return launch_act_quant2_np<OP, SIM, DQ, 1, FMT>(p, s);
     if (np == 2) return launch_act_quant2_np<OP, SIM, DQ, 2, FMT>(p, s);
     if (np == 3) return launch_act_quant2_np<OP, SIM, DQ, 3, FMT>(p, s);
