@@ -141,7 +141,7 @@ def test_gemm_error_behaviour():
 
 def test_gemm_bit_exact_vs_c_contract():
     """The arithmetic contract of include/atom_hip.h restated in plain C (oracle/atom_oracle.c): exact integer dots,
-    t = round_f32(idot*sA), c = fmaf(t, sB, c), groups in order, then the keeper (one dot product over its 128 columns, one
+    c = fmaf((float)idot, sA * sB, c) with the scale product exact in FP32, groups in order, then the keeper (one dot product over its 128 columns, one
     de-quantisation), D = half(c).  Bit-for-bit -- in the summation order of the kernel the shape is dispatched to: one ordered sum
     for the tile kernels, the G + 1 items dealt to 8 waves for decode batches (2 <= M <= 256 where the decode-batch kernel fits)."""
     from tests import c_oracle as C
