@@ -297,26 +297,31 @@ namespace f6m {
 typedef int v8i __attribute__((ext_vector_type(8)));
 constexpr int PITCH = 104;
                                                   // (a tile's 64 records are 6,656 contiguous bytes: seven 1 KiB pieces, the last one half)
-constexpr int W_OFF = 0, A_OFF = 7168;
-// TM = token blocks of 16 per wave: 1 = 64 x 64 tiles; 2 = 128 x 64 tiles (round 5, last step) -- the same 8 waves, each with two token
-// blocks (tq and tq + 4) against its 32 features: 4 MFMAs per wave and step on 20 KB of LDS-DMA instead of 2 on 14.5 KB.  The step of
-// this kernel is bound by what a CU's LDS-DMA path moves, so shapes with 257 .. 512 tiles of 64 x 64 -- two workgroups
-// per CU, 29 KB per CU and step -- run a third faster as up to 256 tiles of 128 x 64 (one per CU, 20 KB).  Same K order: the bits do not
-// change with the tile.
-template <int NS_, bool PAIR_, int ABL_ = 0, bool S16_ = false, int TM_ = 1>
+// TM / TN = token blocks of 16 / feature blocks of 32 per wave (the same 8 waves = 4 token-block slots x 2 feature halves): 1 x 1 =
+// 64 x 64 tiles; 2 x 1 = 128 x 64 (two token blocks per wave, tq and tq + 4: 4 MFMAs per wave and step on 20 KB of LDS-DMA instead of 2 on
+// 14.5 KB); 2 x 2 = 128 x 128 (+ feature halves h and h + 2: 8 MFMAs on 26.5 KB).  The step of this kernel is bound by what a CU's
+// LDS-DMA path moves and by the issue of the LDS-DMA pieces, so a shape takes the largest tile that still gives
+// (nearly) every CU one.  Same K order whatever the tile: the bits do not change.
+template <int NS_, bool PAIR_, int ABL_ = 0, bool S16_ = false, int TM_ = 1, int TN_ = 1>
 struct Cfg {
-  static constexpr int NW = 8, NS = NS_, NT = 512, TM = TM_, BMT = 64 * TM_;
-  static constexpr int A_PIECES = (BMT * PITCH + 1023) / 1024;          // 1 KiB LDS-DMA pieces of the token records: 7 (the last one half) / 13
-  static constexpr int SB_OFF = A_OFF + (TM_ == 1 ? 7168 : A_PIECES * 1024), STAGE = SB_OFF + 256;
-  // keeper halves in the same slot: the packed kernel's layout (4 weight fragments + 4 TM token blocks in MFMA order, fp16 weight
+  static constexpr int NW = 8, NS = NS_, NT = 512, TM = TM_, TN = TN_, BMT = 64 * TM_, BNT = 64 * TN_;
+  // a tile side of 64 records is 6,656 contiguous bytes = seven 1 KiB LDS-DMA pieces (the last one half); of 128: thirteen
+  static constexpr int W_PIECES = TN_ == 1 ? 7 : 13, A_PIECES = TM_ == 1 ? 7 : 13;
+  static constexpr int W_OFF = 0, A_OFF = W_PIECES * 1024, SB_OFF = A_OFF + A_PIECES * 1024;
+  static constexpr int STAGE = SB_OFF + 256 * TN_;                       // + the tile's float32 weight scales
+  // keeper halves in the same slot: the packed kernel's layout (4 TN weight fragments + 4 TM token blocks in MFMA order, fp16 weight
   // scales, token scales as dwords)
-  static constexpr int K_W = 0, K_A = 4096, K_SB = K_A + 4096 * TM_, K_SA = K_SB + 256;
+  static constexpr int K_W = 0, K_A = 4096 * TN_, K_SB = K_A + 4096 * TM_, K_SA = K_SB + 256;
   static_assert(K_SA + 256 * TM_ <= STAGE, "the keeper's pieces fit a stage");
-  static_assert((NS_ - 1) * STAGE + PITCH + 24 + 16 * 24 < 65536, "slot offsets ride in 16-bit instruction offsets");
+  // ring slots whose byte offset fits the 16-bit instruction offset of a DS load behind ONE address register; further slots use a second
+  // register set (+ SPB stages)
+  static constexpr int SPB = (65535 - PITCH - 24) / STAGE + 1 < NS_ ? (65535 - PITCH - 24) / STAGE + 1 : NS_;
+  static_assert(SPB >= 2 && 2 * SPB >= NS_, "at most two address-register sets");
   static constexpr bool PAIR = PAIR_;
   static constexpr bool S16 = S16_;                // weights without appended float32 scales (atom_repack_weight_f6): the dense fp16 array, converted per step
+  static_assert(!(S16_ && TN_ > 1), "the 128-feature tile takes float32 weight scales only");
   static constexpr int ABL = ABL_;                 // tools build only: 1 no LDS-DMA in the K loop, 2 no barrier, 4 no MFMA, 8 no LDS loads, 16 no de-quantisation
-  static constexpr int PPW = 1 + TM_;              // DMA instructions per wave and stage: waves 0..6 weight piece w + token piece(s) w (, 7 + w), wave 7 the scales
+  static constexpr int PPW = TM_ + TN_;            // DMA instructions per wave and stage: waves 0..6 the weight / token pieces w (, 7 + w), wave 7 the scales
   static constexpr int LDS_BYTES = NS * STAGE;
   static_assert(NS >= 3 && PPW * (NS - 2) < 64 && LDS_BYTES <= 160 * 1024, "ring depth");
 };
@@ -361,29 +366,32 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 8);
-  const int h = wave & 1, tb = wave >> 1;                  // wave tile: token block(s) tb (, tb + 4) (16 tokens each) x feature half h (32 features)
-  constexpr int TM = C::TM, STAGE = C::STAGE, SB_OFF = C::SB_OFF, K_W = C::K_W, K_A = C::K_A, K_SB = C::K_SB, K_SA = C::K_SA;
-  const int nbm = (p.M + C::BMT - 1) / C::BMT, nbn = p.N / BN;
+  // wave tile: token block(s) tb (, tb + 4) of 16 tokens x feature block(s) h (, h + 2) of 32 features
+  const int h = wave & 1, tb = wave >> 1;
+  constexpr int TM = C::TM, TN = C::TN, STAGE = C::STAGE, W_OFF = C::W_OFF, A_OFF = C::A_OFF, SB_OFF = C::SB_OFF;
+  constexpr int K_W = C::K_W, K_A = C::K_A, K_SB = C::K_SB, K_SA = C::K_SA, PPW = C::PPW;
+  const int nbm = (p.M + C::BMT - 1) / C::BMT, nbn = p.N / C::BNT;
   int id = blockIdx.x;
   {
     const int nwg = nbm * nbn;
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int m0 = (id % nbm) * C::BMT, n0 = (id / nbm) * BN;
+  const int m0 = (id % nbm) * C::BMT, n0 = (id / nbm) * C::BNT;
   const int G = p.G, T = G + 2;
 
   // ---- LDS-DMA, loop invariant.  int4 stage g: waves 0..6 piece w of the weight records and piece w of the token records (piece 6: 32
-  // lanes), wave 7 the 64 float32 weight scales (twice: the count per wave stays uniform)
+  // lanes when the side is 64 records; a side of 128 records has 13 full pieces: waves 0..5 also take piece 7 + w, wave 6 repeats its
+  // piece), wave 7 the float32 weight scales (repeated: the count per wave stays uniform at PPW)
   const uint8_t *wsrc0 = p.B4 + (int64_t)n0 * PITCH, *asrc0 = p.A4 + (int64_t)m0 * PITCH;
   const int64_t wstep = p.f6_rows_b * PITCH, astep = p.f6_rows_a * PITCH;
   const float *sbsrc0 = C::S16 ? reinterpret_cast<const float *>(p.sB) : p.sB32 + n0;   // (S16: fp16 [G][N]; 128 bytes per tile and group)
   const int64_t sbstep = C::S16 ? p.N / 2 : p.f6_rows_b;                                   // floats between groups
   const unsigned sbvoff = C::S16 ? (unsigned)min(n0 + 2 * lane, p.N - 2) * 2u : (unsigned)lane * 4u;
   const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
-  const int wave2 = wave < 6 ? 7 + wave : wave;            // (TM = 2) the wave's second token piece
+  const int wave2 = wave < 6 ? 7 + wave : wave;            // the wave's second piece of a 13-piece side
   const unsigned voff2 = (unsigned)(wave2 * 1024 + lane * 16);
-  const bool piece_ok = wave < 6 || (wave == 6 && lane < 32);
+  const bool half_ok = wave < 6 || (wave == 6 && lane < 32);   // piece w of a 7-piece side exists (piece 6: its first half)
   KeeperDma kd;
   {
     const int i = lane >> 2, j = lane & 3;
@@ -394,8 +402,8 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
       kd.kvoff = row * (unsigned)kKeeper + chunk;          // (token blocks interleaved like the BF6 records: block b row i = token 32 (b >> 1) + (b & 1) + 2 i)
       kd.d8 = is_w ? p.B8 : p.A8;
       kd.kvoff_w = 0; kd.dst = (unsigned)wave * 1024u; kd.dst_w = 0; kd.sdst = (wave & 1) ? K_SA : K_SB;
-    } else {                                               // wave w: token block w (8 of them) and weight fragment w & 3 (waves 4..7 repeat 0..3: same bytes, same place)
-      const int f = wave & 3;
+    } else {                                               // wave w: token block w (8 of them) and weight fragment w (TN = 1: w & 3 -- waves 4..7 repeat 0..3: same bytes, same place)
+      const int f = TN == 2 ? wave : (wave & 3);
       kd.kvoff = (unsigned)min(m0 + 32 * (wave >> 1) + (wave & 1) + 2 * i, p.M - 1) * (unsigned)kKeeper + chunk;
       kd.kvoff_w = (unsigned)(n0 + 32 * (f >> 1) + 2 * i + (f & 1)) * (unsigned)kKeeper + chunk;
       kd.d8 = p.A8;
@@ -407,26 +415,29 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
       kd.svoff = (unsigned)(p.ref_layout ? ref_scale_index(m) : m) * 2u;
       kd.s8 = p.sA8;
     } else {
-      kd.svoff = (unsigned)min(n0 + 2 * lane, p.N - 2) * 2u;
+      kd.svoff = (unsigned)min(n0 + 2 * lane, p.N - 2) * 2u;     // (one dword piece = 128 halves: all the weight scales of a 128-feature tile)
       kd.s8 = p.sB8;
     }
   }
   const unsigned lds0 = lds_addr(lds);
   auto issue_int4 = [&](const uint8_t *wsrc, const uint8_t *asrc, const float *sbsrc, unsigned slot) {
     if (wave < 7) {
+      if constexpr (TN == 1) {
+        if (half_ok) lds_dma_sv<16>(wsrc, voff, slot + W_OFF + wave * 1024);
+      } else {
+        lds_dma_sv<16>(wsrc, voff, slot + W_OFF + wave * 1024);
+        lds_dma_sv<16>(wsrc, voff2, slot + W_OFF + wave2 * 1024);
+      }
       if constexpr (TM == 1) {
-        if (piece_ok) {
-          lds_dma_sv<16>(wsrc, voff, slot + W_OFF + wave * 1024);
-          lds_dma_sv<16>(asrc, voff, slot + A_OFF + wave * 1024);
-        }
-      } else {                                             // 13 token pieces: wave w takes w and 7 + w (wave 6 repeats its piece 6)
-        if (piece_ok) lds_dma_sv<16>(wsrc, voff, slot + W_OFF + wave * 1024);
+        if (half_ok) lds_dma_sv<16>(asrc, voff, slot + A_OFF + wave * 1024);
+      } else {
         lds_dma_sv<16>(asrc, voff, slot + A_OFF + wave * 1024);
         lds_dma_sv<16>(asrc, voff2, slot + A_OFF + wave2 * 1024);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < C::PPW; ++i) lds_dma_sv<4>(sbsrc, sbvoff, slot + SB_OFF);
+      for (int i = 0; i < PPW; ++i)                        // (TN = 2: 128 floats = two dword pieces, then repeats)
+        lds_dma_sv<4>(sbsrc + (TN == 2 ? 64 * (i & 1) : 0), sbvoff, slot + SB_OFF + (TN == 2 ? 256 * (i & 1) : 0));
     }
   };
   auto issue = [&](int st, unsigned slot) {                // any stage (prologue and the last NS - 1 steps)
@@ -435,70 +446,86 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     } else {                                               // keeper half st - G: the wave's piece(s) of the packed kernel's stage + a scale piece
       lds_dma_sv<16>(kd.d8 + (st - G) * 64, kd.kvoff, slot + kd.dst);
       if constexpr (TM == 2) lds_dma_sv<16>(p.B8 + (st - G) * 64, kd.kvoff_w, slot + kd.dst_w);
-      if (wave & 1) lds_dma_sv<2>(kd.s8, kd.svoff, slot + kd.sdst);
-      else lds_dma_sv<4>(kd.s8, kd.svoff, slot + kd.sdst);
+#pragma unroll
+      for (int i = 0; i < PPW - TM; ++i) {                 // (the count per wave stays PPW)
+        if (wave & 1) lds_dma_sv<2>(kd.s8, kd.svoff, slot + kd.sdst);
+        else lds_dma_sv<4>(kd.s8, kd.svoff, slot + kd.sdst);
+      }
     }
   };
 #pragma unroll 1
   for (int s = 0; s < min(NS - 1, T); ++s) issue(s, lds0 + s * STAGE);
 
   const int l15 = lane & 15, kb = lane >> 4;
-  // fragment (h, k) row l15 = record 32 h + 2 l15 + k; token block b row l15 = record 32 (b >> 1) + (b & 1) + 2 l15; the wave's blocks are
-  // tb and (TM = 2) tb + 4 = the same rows 64 records further
-  constexpr int TB2 = 64 * PITCH;                          // byte distance of the second token block's records
-  const unsigned aw = lds0 + W_OFF + (32 * h + 2 * l15) * PITCH + kb * 24;                  // + PITCH: k = 1
-  const unsigned aa = lds0 + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + kb * 24;
-  const unsigned as_ = lds0 + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + 100;  // the token's float32 scale
-  const unsigned asb = lds0 + SB_OFF + (32 * h + 8 * kb) * (C::S16 ? 2 : 4);
+  // fragment (hh, k) row l15 = record 32 hh + 2 l15 + k; token block b row l15 = record 32 (b >> 1) + (b & 1) + 2 l15; a wave's second
+  // feature block (h + 2) and second token block (tb + 4) are the same rows 64 records further
+  constexpr int R64 = 64 * PITCH;                          // byte distance of 64 records
+  constexpr int SPB = C::SPB, NB = (NS + SPB - 1) / SPB;   // ring slots per address-register set, sets
+  unsigned aw[NB], aa[NB], as_[NB], asb[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const unsigned base = lds0 + b * SPB * STAGE;
+    aw[b] = base + W_OFF + (32 * h + 2 * l15) * PITCH + kb * 24;                            // + PITCH: k = 1
+    aa[b] = base + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + kb * 24;
+    as_[b] = base + A_OFF + (32 * (tb >> 1) + (tb & 1) + 2 * l15) * PITCH + 100;            // the token's float32 scale
+    asb[b] = base + SB_OFF + (32 * h + 8 * kb) * (C::S16 ? 2 : 4);
+  }
 
-  float c[TM][2][4];
+  float c[TM][TN][2][4];
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[t][k][r] = 0.f;
-  // what a step leaves for the next one to de-quantise, in two register sets used alternately (the loop below is unrolled by two: no
-  // copies, and a step's scales are requested ahead of the previous step's de-quantisation instead of behind it)
-  struct Pend { v4f acc[TM][2]; float sa[TM]; v4f sb0, sb1; };
-  Pend P[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    P[i].sb0 = P[i].sb1 = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      P[i].acc[t][0] = P[i].acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
-      P[i].sa[t] = 0.f;
-    }
-  }
-  // c[t][k][r] = fma(idot, sa * sb, c): token = the lane's of block t, feature 32 h + 8 kb + 2 r + k (the contract; PAIR: one product per
-  // channel pair)
-  auto dequant = [&](const Pend &q, auto pair) {
-    constexpr bool PR = decltype(pair)::value;
-    float sbv[8];
-    if constexpr (C::S16 && !decltype(pair)::keeper) {     // eight halves in sb0
-      const half_t *hv = reinterpret_cast<const half_t *>(&q.sb0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sbv[j] = (float)hv[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { sbv[j] = q.sb0[j]; sbv[4 + j] = q.sb1[j]; }
-    }
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      float s[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[2 * r] = q.sa[t] * sbv[2 * r];
-        s[2 * r + 1] = PR ? s[2 * r] : q.sa[t] * sbv[2 * r + 1];
-      }
+    for (int n = 0; n < TN; ++n)
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
+        for (int r = 0; r < 4; ++r) c[t][n][k][r] = 0.f;
+  // what a step leaves for the next one to de-quantise, in two register sets used alternately (the loop below is unrolled by two: no
+  // copies, and a step's scales are requested ahead of the previous step's de-quantisation instead of behind it)
+  struct Pend { v4f acc[TM][TN][2]; float sa[TM]; v4f sb[TN][2]; };
+  Pend P[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int n = 0; n < TN; ++n) P[i].sb[n][0] = P[i].sb[n][1] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n) P[i].acc[t][n][0] = P[i].acc[t][n][1] = v4f{0.f, 0.f, 0.f, 0.f};
+      P[i].sa[t] = 0.f;
+    }
+  }
+  // c[t][n][k][r] = fma(idot, sa * sb, c): token = the lane's of block t, feature 32 (h + 2 n) + 8 kb + 2 r + k (the contract; PAIR: one
+  // product per channel pair)
+  auto dequant = [&](const Pend &q, auto pair) {
+    constexpr bool PR = decltype(pair)::value;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      float sbv[8];
+      if constexpr (C::S16 && !decltype(pair)::keeper) {   // eight halves in sb[0][0]
+        const half_t *hv = reinterpret_cast<const half_t *>(&q.sb[n][0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sbv[j] = (float)hv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sbv[j] = q.sb[n][0][j]; sbv[4 + j] = q.sb[n][1][j]; }
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        float s[8];
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-          c[t][k][r] = __builtin_fmaf(q.acc[t][k][r], s[2 * r + k], c[t][k][r]);
-          asm volatile("" : "+v"(c[t][k][r]));
+          s[2 * r] = q.sa[t] * sbv[2 * r];
+          s[2 * r + 1] = PR ? s[2 * r] : q.sa[t] * sbv[2 * r + 1];
         }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c[t][n][k][r] = __builtin_fmaf(q.acc[t][n][k][r], s[2 * r + k], c[t][n][k][r]);
+            asm volatile("" : "+v"(c[t][n][k][r]));
+          }
+      }
     }
   };
   // One K step on the stage in ring slot SL (compile time: the slot's byte offset rides in the loads' immediate offsets -- no address
@@ -508,57 +535,82 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   // this step's MFMAs (consumed in the next step).
   auto compute = [&](auto slc, unsigned so, Pend &cur, const Pend &prv, auto dma) {
     constexpr int SL = decltype(slc)::value;
-    constexpr int O = SL < 0 ? 0 : SL * STAGE;
-    const unsigned xw = SL < 0 ? aw + so : aw, xa = SL < 0 ? aa + so : aa, xs = SL < 0 ? as_ + so : as_, xb = SL < 0 ? asb + so : asb;
-    v2u f[6 + 3 * TM];                                     // w0, w1, then a token fragment per block: three 8-byte pieces each
+    constexpr int SET = SL < 0 ? 0 : SL / SPB;
+    constexpr int O = SL < 0 ? 0 : (SL % SPB) * STAGE;
+    const unsigned xw = SL < 0 ? aw[0] + so : aw[SET], xa = SL < 0 ? aa[0] + so : aa[SET];
+    const unsigned xs = SL < 0 ? as_[0] + so : as_[SET], xb = SL < 0 ? asb[0] + so : asb[SET];
+    v2u fw[TN][6], fa[TM][3];                              // weight fragments k = 0, 1 per feature block, a token fragment per block: three 8-byte pieces each
     if constexpr (!(C::ABL & 8)) {
-      f[0] = lds64<O>(xw); f[1] = lds64<O + 8>(xw); f[2] = lds64<O + 16>(xw);
-      f[3] = lds64<O + PITCH>(xw); f[4] = lds64<O + PITCH + 8>(xw); f[5] = lds64<O + PITCH + 16>(xw);
-      f[6] = lds64<O>(xa); f[7] = lds64<O + 8>(xa); f[8] = lds64<O + 16>(xa);
+      fw[0][0] = lds64<O>(xw); fw[0][1] = lds64<O + 8>(xw); fw[0][2] = lds64<O + 16>(xw);
+      fw[0][3] = lds64<O + PITCH>(xw); fw[0][4] = lds64<O + PITCH + 8>(xw); fw[0][5] = lds64<O + PITCH + 16>(xw);
+      fa[0][0] = lds64<O>(xa); fa[0][1] = lds64<O + 8>(xa); fa[0][2] = lds64<O + 16>(xa);
       cur.sa[0] = lds32f<O>(xs);
-      if constexpr (TM == 2) {                             // (its own address registers: slot 3 + 6,656 bytes exceeds a 16-bit offset)
-        const unsigned xa2 = xa + TB2, xs2 = xs + TB2;
-        f[9] = lds64<O>(xa2); f[10] = lds64<O + 8>(xa2); f[11] = lds64<O + 16>(xa2);
+      if constexpr (TM == 2) {                             // (their own address registers: a slot offset + 6,656 bytes can exceed 16 bits)
+        const unsigned xa2 = xa + R64, xs2 = xs + R64;
+        fa[TM - 1][0] = lds64<O>(xa2); fa[TM - 1][1] = lds64<O + 8>(xa2); fa[TM - 1][2] = lds64<O + 16>(xa2);
         cur.sa[TM - 1] = lds32f<O>(xs2);
       }
-      cur.sb0 = lds128f<O>(xb);
-      if constexpr (!C::S16) cur.sb1 = lds128f<O + 16>(xb);
+      if constexpr (TN == 2) {
+        const unsigned xw2 = xw + R64;
+        fw[TN - 1][0] = lds64<O>(xw2); fw[TN - 1][1] = lds64<O + 8>(xw2); fw[TN - 1][2] = lds64<O + 16>(xw2);
+        fw[TN - 1][3] = lds64<O + PITCH>(xw2); fw[TN - 1][4] = lds64<O + PITCH + 8>(xw2); fw[TN - 1][5] = lds64<O + PITCH + 16>(xw2);
+      }
+      cur.sb[0][0] = lds128f<O>(xb);
+      if constexpr (!C::S16) cur.sb[0][1] = lds128f<O + 16>(xb);
+      if constexpr (TN == 2) {
+        cur.sb[TN - 1][0] = lds128f<O + 256>(xb);
+        cur.sb[TN - 1][1] = lds128f<O + 256 + 16>(xb);
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < 6 + 3 * TM; ++i) f[i] = v2u{so + i, so};
+      for (int n = 0; n < TN; ++n)
 #pragma unroll
-      for (int t = 0; t < TM; ++t) cur.sa[t] = 1.f;
-      cur.sb0 = cur.sb1 = v4f{1.f, 1.f, 1.f, 1.f};
+        for (int i = 0; i < 6; ++i) fw[n][i] = v2u{so + i, so};
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fa[t][i] = v2u{so + i, so + 7};
+        cur.sa[t] = 1.f;
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n) cur.sb[n][0] = cur.sb[n][1] = v4f{1.f, 1.f, 1.f, 1.f};
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(C::ABL & 1)) dma();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(C::ABL & 16)) dequant(prv, DeqTag<C::PAIR, false>());
-    else { c[0][0][0] += prv.acc[0][0][0] + prv.acc[TM - 1][1][3]; asm volatile("" : "+v"(c[0][0][0])); }
+    else { c[0][0][0][0] += prv.acc[0][0][0][0] + prv.acc[TM - 1][TN - 1][1][3]; asm volatile("" : "+v"(c[0][0][0][0])); }
     // The loads above are invisible to the compiler: until they have landed, their destination registers must stay allocated and
     // unread -- also the components nothing reads later (PAIR uses every other weight scale), which the register allocator would
     // otherwise hand to the de-quantisation's temporaries while the load is still in flight.  Every destination is an in/out operand
-    // of the wait itself: nothing is copied or re-used before it.
-    if constexpr (TM == 1)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(cur.sa[0]),
-                     "+v"(cur.sb0), "+v"(cur.sb1)::"memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(cur.sa[0]),
-                     "+v"(cur.sb0), "+v"(cur.sb1), "+v"(f[6 + 3 * (TM - 1)]), "+v"(f[7 + 3 * (TM - 1)]), "+v"(f[8 + 3 * (TM - 1)]), "+v"(cur.sa[TM - 1])::"memory");
+    // of the wait itself (or of the empty statements behind it, which the scheduling barrier keeps behind it): nothing is copied or
+    // re-used before it.
+#define ATOM_F6M_BASE "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[0][2]), "+v"(fw[0][3]), "+v"(fw[0][4]), "+v"(fw[0][5]), "+v"(fa[0][0]), "+v"(fa[0][1]), \
+                      "+v"(fa[0][2]), "+v"(cur.sa[0]), "+v"(cur.sb[0][0]), "+v"(cur.sb[0][1])
+#define ATOM_F6M_T2 "+v"(fa[TM - 1][0]), "+v"(fa[TM - 1][1]), "+v"(fa[TM - 1][2]), "+v"(cur.sa[TM - 1])
+#define ATOM_F6M_N2 "+v"(fw[TN - 1][0]), "+v"(fw[TN - 1][1]), "+v"(fw[TN - 1][2]), "+v"(fw[TN - 1][3]), "+v"(fw[TN - 1][4]), "+v"(fw[TN - 1][5]), \
+                    "+v"(cur.sb[TN - 1][0]), "+v"(cur.sb[TN - 1][1])
+    if constexpr (TM == 1 && TN == 1) asm volatile("s_waitcnt lgkmcnt(0)" : ATOM_F6M_BASE::"memory");
+    else if constexpr (TN == 1) asm volatile("s_waitcnt lgkmcnt(0)" : ATOM_F6M_BASE, ATOM_F6M_T2::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : ATOM_F6M_BASE, ATOM_F6M_T2, ATOM_F6M_N2::"memory");
+#undef ATOM_F6M_BASE
+#undef ATOM_F6M_T2
+#undef ATOM_F6M_N2
     __builtin_amdgcn_sched_barrier(0);
-    const v8i w0 = {(int)f[0].x, (int)f[0].y, (int)f[1].x, (int)f[1].y, (int)f[2].x, (int)f[2].y, 0, 0};
-    const v8i w1 = {(int)f[3].x, (int)f[3].y, (int)f[4].x, (int)f[4].y, (int)f[5].x, (int)f[5].y, 0, 0};
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const v8i bf = {(int)f[6 + 3 * t].x, (int)f[6 + 3 * t].y, (int)f[7 + 3 * t].x, (int)f[7 + 3 * t].y, (int)f[8 + 3 * t].x, (int)f[8 + 3 * t].y, 0, 0};
-      if constexpr (!(C::ABL & 4)) {
-        cur.acc[t][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w0, bf, v4f{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
-        cur.acc[t][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w1, bf, v4f{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
-      } else {
-        cur.acc[t][0] = v4f{(float)w0[0], (float)w0[5], (float)bf[1], (float)w1[2]};
-        cur.acc[t][1] = v4f{(float)w1[0], (float)w1[5], (float)bf[3], (float)bf[5]};
+    for (int n = 0; n < TN; ++n) {
+      const v8i w0 = {(int)fw[n][0].x, (int)fw[n][0].y, (int)fw[n][1].x, (int)fw[n][1].y, (int)fw[n][2].x, (int)fw[n][2].y, 0, 0};
+      const v8i w1 = {(int)fw[n][3].x, (int)fw[n][3].y, (int)fw[n][4].x, (int)fw[n][4].y, (int)fw[n][5].x, (int)fw[n][5].y, 0, 0};
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const v8i bf = {(int)fa[t][0].x, (int)fa[t][0].y, (int)fa[t][1].x, (int)fa[t][1].y, (int)fa[t][2].x, (int)fa[t][2].y, 0, 0};
+        if constexpr (!(C::ABL & 4)) {
+          cur.acc[t][n][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w0, bf, v4f{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+          cur.acc[t][n][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w1, bf, v4f{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
+        } else {
+          cur.acc[t][n][0] = v4f{(float)w0[0], (float)w0[5], (float)bf[1], (float)w1[2]};
+          cur.acc[t][n][1] = v4f{(float)w1[0], (float)w1[5], (float)bf[3], (float)bf[5]};
+        }
       }
     }
   };
@@ -567,10 +619,10 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   // wave's pieces of the step's stage are in LDS, and every wave is done reading the slot of the previous step
   auto sync = [&](int allowed) {
     if constexpr (!(C::ABL & 1)) {
-      if (allowed >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (NS - 2)) : "memory");
-      else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
-      else if (allowed == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * 2) : "memory");
-      else if (allowed == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * 3) : "memory");
+      if (allowed >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");
+      else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else if (allowed == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
+      else if (allowed == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 3) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if constexpr (!(C::ABL & 2)) __builtin_amdgcn_s_barrier();
@@ -621,35 +673,39 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
   {
     const char *s0 = lds + slot * STAGE, *s1 = lds + (slot + 1 == NS ? 0 : slot + 1) * STAGE;
     const int coff = l15 * 64 + ((kb ^ ((l15 >> 1) & 3)) << 4);
-    const int kw = K_W + 2 * h * 1024 + coff;
-    const v4u sbv = *reinterpret_cast<const v4u *>(s0 + K_SB + (32 * h + 8 * kb) * 2);
-    const half_t *hv = reinterpret_cast<const half_t *>(&sbv);
-    v4i x0[2], x1[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      x0[k] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s0 + kw + k * 1024));
-      x1[k] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s1 + kw + k * 1024));
-    }
     Pend kq;
+    v4i b0[TM], b1[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       const int b = tb + 4 * t;                            // the token block
       const int ka = K_A + b * 1024 + coff;
-      const v4i b0 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s0 + ka));
-      const v4i b1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s1 + ka));
+      b0[t] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s0 + ka));
+      b1[t] = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s1 + ka));
       // token scale: the lane's token is record row 32 (b >> 1) + (b & 1) + 2 l15 of the tile = index of its dword in the scale pieces
       const unsigned sah = *reinterpret_cast<const unsigned *>(s0 + K_SA + (32 * (b >> 1) + (b & 1) + 2 * l15) * 4);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        v4i a = __builtin_amdgcn_mfma_i32_16x16x64_i8(x0[k], b0, v4i{0, 0, 0, 0}, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_i32_16x16x64_i8(x1[k], b1, a, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kq.acc[t][k][r] = (float)a[r];
-      }
       kq.sa[t] = (float)__builtin_bit_cast(half_t, (unsigned short)sah);
     }
-    kq.sb0 = v4f{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-    kq.sb1 = v4f{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int hh = h + 2 * n;                            // the feature block: fragments 2 hh + k
+      const int kw = K_W + 2 * hh * 1024 + coff;
+      const v4u sbv = *reinterpret_cast<const v4u *>(s0 + K_SB + (32 * hh + 8 * kb) * 2);
+      const half_t *hv = reinterpret_cast<const half_t *>(&sbv);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const v4i x0 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s0 + kw + k * 1024));
+        const v4i x1 = __builtin_bit_cast(v4i, *reinterpret_cast<const v4u *>(s1 + kw + k * 1024));
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          v4i a = __builtin_amdgcn_mfma_i32_16x16x64_i8(x0, b0[t], v4i{0, 0, 0, 0}, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_i32_16x16x64_i8(x1, b1[t], a, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kq.acc[t][n][k][r] = (float)a[r];
+        }
+      }
+      kq.sb[n][0] = v4f{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+      kq.sb[n][1] = v4f{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+    }
     dequant(kq, DeqTag<false, true>());
   }
 #pragma unroll
@@ -657,14 +713,17 @@ __global__ __launch_bounds__(C::NT) void gemm_w4a4_f6m_kernel(GemmParams p) {
     const int b = tb + 4 * t;
     const int m = m0 + 32 * (b >> 1) + (b & 1) + 2 * l15;
     if (m < p.M) {
-      v4u o;
-      half_t *ov = reinterpret_cast<half_t *>(&o);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ov[2 * r] = f2h(c[t][0][r]);
-        ov[2 * r + 1] = f2h(c[t][1][r]);
+      for (int n = 0; n < TN; ++n) {
+        v4u o;
+        half_t *ov = reinterpret_cast<half_t *>(&o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ov[2 * r] = f2h(c[t][n][0][r]);
+          ov[2 * r + 1] = f2h(c[t][n][1][r]);
+        }
+        *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n0 + 32 * (h + 2 * n) + 8 * kb) = o;
       }
-      *reinterpret_cast<v4u *>(p.D + (int64_t)m * p.N + n0 + 32 * h + 8 * kb) = o;
     }
   }
 }
@@ -673,7 +732,7 @@ template <class C>
 static int launch(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_f6m_kernel<C>), C::LDS_BYTES, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
-  const int nbm = (p.M + C::BMT - 1) / C::BMT, nbn = p.N / BN;
+  const int nbm = (p.M + C::BMT - 1) / C::BMT, nbn = p.N / C::BNT;
   hipLaunchKernelGGL((gemm_w4a4_f6m_kernel<C>), dim3((unsigned)(nbm * nbn)), dim3(C::NT), C::LDS_BYTES, s, p);
   return check_launch();
 }
@@ -681,17 +740,32 @@ static int launch(const GemmParams &p, hipStream_t s) {
 }  // namespace f6m
 }  // namespace mid
 
+// The tile of the BF6 mid-size-batch kernel for a shape: 1 = 64 x 64 (up to 256 of them), 2 = 128 x 64 (257 .. 512 tiles of 64 x 64:
+// otherwise two workgroups per CU).  3 = 128 x 128 exists in the tuning build only (ATOM_MID_TM=3; float32 weight scales shared by
+// channel pairs, N % 128 == 0): on shapes with at most 256 such tiles it measures 2-7 % ahead of the two-wave-group 128 x 128 kernel
+// that serves them (768 x 4096 x 4096 20.8 -> 19.6 us, 1024 x .. 22.4 -> 22.0, 256 x 13824 x 5120 25.4 -> 24.5) and behind everywhere
+// else (profiles/r05/mid_tm3.txt) -- not worth a summation order that would depend on the weight's flavour.
+int f6_mid_tile(int64_t M, int64_t N, bool f32_scales) {
+  const int64_t t64 = ((M + 63) / 64) * (N / 64);
+  int t = t64 <= 256 ? 1 : 2;
+#ifdef ATOM_TOOLS
+  if (const int forced = ATOM_TUNE("ATOM_MID_TM", 0)) t = forced == 3 && (!f32_scales || (N % 128) != 0) ? 2 : forced;
+#endif
+  return t;
+}
+
 // BF6 operands (ATOM_AB_F6; with the appended float32 weight scales of ATOM_B_F6S or the dense fp16 array), fp16 output, N % 64 == 0
 int launch_gemm_f6_mid(const GemmParams &p, hipStream_t s) {
   if (!p.f6_rows_a || (p.N % mid::BN) != 0 || !p.D) return ATOM_ERR_SHAPE;
   using namespace mid::f6m;
-  // 257 .. 512 tiles of 64 x 64 (two workgroups per CU): 128 x 64 tiles, one per CU (see Cfg)
-  int tm = ((p.M + 63) / 64) * (p.N / mid::BN) > 256 ? 2 : 1;
+  // the tile: 64 x 64 up to 256 of them; 128 x 64 for 257 .. 512 tiles of 64 x 64 (otherwise two workgroups per CU); 128 x 128 beyond
+  // (f6_pick_cfg sends such shapes here only where that leaves at most one tile per CU)
+  const int tsel = f6_mid_tile(p.M, p.N, p.sB32 != nullptr);
+  if (!p.sB32) return tsel == 2 ? launch<Cfg<4, false, 0, true, 2>>(p, s) : launch<Cfg<4, false, 0, true>>(p, s);
 #ifdef ATOM_TOOLS
-  if (const int forced = ATOM_TUNE("ATOM_MID_TM", 0)) tm = forced;
+  if (tsel == 3 && p.b_pairs) return launch<Cfg<4, true, 0, false, 2, 2>>(p, s);   // (without shared scale products the 128 x 128 wave tile spills: 128 x 64 then)
 #endif
-  if (!p.sB32) return tm == 2 ? launch<Cfg<4, false, 0, true, 2>>(p, s) : launch<Cfg<4, false, 0, true>>(p, s);
-  if (tm == 2) return p.b_pairs ? launch<Cfg<4, true, 0, false, 2>>(p, s) : launch<Cfg<4, false, 0, false, 2>>(p, s);
+  if (tsel >= 2) return p.b_pairs ? launch<Cfg<4, true, 0, false, 2>>(p, s) : launch<Cfg<4, false, 0, false, 2>>(p, s);
 #ifdef ATOM_TOOLS
   switch (ATOM_TUNE("ATOM_MID_ABL", 0)) {
 #define ATOM_ABL(a) case a: return launch<Cfg<4, true, a>>(p, s);
