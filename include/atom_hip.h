@@ -151,8 +151,8 @@ int atom_gemm_w4a4_f16(const void *A4, const void *B4, const void *sA, const voi
  * the K loop over several workgroups: FP32 partial sums [splits, M, N] are written to `workspace` and reduced, in split
  * order, by a second launch on the same stream; (2) PACKED operands of prefill size (M > 256 -- or > 128 where the decode-batch kernel does not take the shape --,
  * N >= 2048, K >= 1024) are re-coded into the F6 format inside the workspace (one bandwidth-bound launch; the activation alone
- * with ATOM_WS_WEIGHT_CACHED) and multiplied by the block-scaled-MFMA kernels: 59-68 instead of 106 us at 4096^3, 21.6 (weight
- * cached; 29.1 not) instead of 29.6 us at 512x4096x4096, 26 (32) instead of 37 at 768x4096x4096; bit-identical to atom_gemm_w4a4_f16 where
+ * with ATOM_WS_WEIGHT_CACHED) and multiplied by the BF6-MFMA kernels: 55-60 instead of 89 us at 4096^3, 17.5 (weight cached;
+ * 24.3 not) at 512x4096x4096, 26.2 (33.4) at 1024x4096x4096 (round 5); bit-identical to atom_gemm_w4a4_f16 where
  * atom_gemm_w4a4_f6_order(M, N, K_total) == 1, the sum of two / four ordered ranges of the K steps where it is 2 / 4 (see ATOM_AB_F6).
  * atom_gemm_w4a4_workspace_bytes() returns the size that enables it
  * (0 = the shape does not benefit; then, or with a NULL / too small workspace, this is atom_gemm_w4a4_f16).
