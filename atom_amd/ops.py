@@ -610,14 +610,12 @@ def scale_pairs_shared(b_scale: torch.Tensor, n: int) -> bool:
 
 def _pairs_flag(b_scale: torch.Tensor, n: int) -> bool:
     """scale_pairs_shared() of a weight-scale tensor, remembered ON the tensor object together with its version counter: one device
-    round trip per weight (and per in-place rewrite), none for a model's parameters afterwards.  False during graph capture for a tensor
-    not seen before (the generic kernels are always right)."""
+    round trip per weight (and per in-place rewrite), none for a model's parameters afterwards -- pass the SAME tensor object every
+    time (a Parameter, not a fresh ``.data`` view: the tag would die with the view and every call would pay the round trip).  False
+    during graph capture for a tensor not seen before (the generic kernels are always right)."""
     tag = getattr(b_scale, "_atom_pairs", None)
-    try:
-        ver = b_scale._version
-    except RuntimeError:                      # inference tensors have no version counter: check every time
-        ver = None
-    if tag is not None and ver is not None and tag[0] == ver:
+    ver = _version_of(b_scale)                # (inference tensors: -1 -- they cannot be written in place)
+    if tag is not None and tag[0] == ver:
         return tag[1]
     if torch.cuda.is_current_stream_capturing():
         return False
