@@ -4,6 +4,10 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import os  # noqa: E402
+from atom_amd import _lib as L  # noqa: E402
+if os.environ.get("ATOM_LIB"):                            # a tuning build of the library (ATOM_* overrides are read by that build only)
+    L.LIB_PATH = os.path.abspath(os.environ["ATOM_LIB"])
 from atom_amd import ops  # noqa: E402
 from atom_amd.utils.kvcache import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4  # noqa: E402
 
