@@ -64,16 +64,16 @@ def one(M, N, K, iters):
     wsb = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     if M < 256:
-        t_packed = time_graph(lambda st: (lambda: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN,
+        t_packed = time_graph(lambda st: (lambda: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS,
                                                                             ws.data_ptr(), wsb, st)))
     else:
-        t_packed = time_call(lambda: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN, ws.data_ptr(), wsb, stream), iters)
+        t_packed = time_call(lambda: lib.atom_gemm_w4a4_f16_ws(*ptrs, D.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS, ws.data_ptr(), wsb, stream), iters)
     t_f6 = None
     if M >= 256:
         a6, b6 = bench.build_f6_operands(ops_, M, N, K, dev)
         p6 = [a6.data_ptr(), b6.data_ptr()] + ptrs[2:]
         D2 = torch.empty_like(D)
-        fl = L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S
+        fl = L.SCALE_LAYOUT_PLAIN | L.AB_F6 | L.B_F6S | L.B_SCALE_PAIRS     # (bench.make_operands: channel pairs share their scales)
         wsb6 = wsb if M < 2048 else 0
         t_f6 = time_call(lambda: lib.atom_gemm_w4a4_f16_ws(*p6, D2.data_ptr(), M, N, K, 128, 128, fl, ws.data_ptr(), wsb6, stream), iters)
         if M >= 2048:
