@@ -95,6 +95,34 @@ def test_packed_route_query():
     assert L.atom_gemm_w4a4_packed_order(64, 5120, 13824, 1) > 100 and wsb(64, 5120, 13824) >= 8 * 64 * 5120 * 4   # split K without the flag
 
 
+def test_dispatch_queries_are_consistent_over_random_shapes():
+    """The host-side dispatch queries agree with each other for any shape: a shape that re-codes without a cached weight re-codes with
+    one; a re-coding shape has room for both operands' BF6 forms in the workspace the library asks for; every summation order is one
+    the oracle restates (1, 2, 8, 63, 64, 100 + splits); unsupported shapes answer 0 everywhere."""
+    import random
+    from atom_amd import _lib
+    L = _lib.lib()
+    rnd = random.Random(5)
+    for _ in range(4000):
+        M = rnd.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 256, 257, 300, 512, 513, 700, 1024, 2048, 4096, rnd.randrange(1, 5000)])
+        N = 64 * rnd.randrange(1, 260)
+        K = 128 * rnd.randrange(2, 120)
+        rec, recc, wsb = L.atom_gemm_w4a4_ws_recodes(M, N, K), L.atom_gemm_w4a4_ws_recodes_cached(M, N, K), L.atom_gemm_w4a4_workspace_bytes(M, N, K)
+        assert rec in (0, 1) and recc in (0, 1) and recc >= rec, (M, N, K)
+        G = K // 128 - 1
+        f6 = G * (-(-M // 256) * 256) * 104 + G * (-(-N // 256) * 256) * 108
+        if recc:
+            assert wsb >= f6, (M, N, K, wsb, f6)
+        for w in (0, 1, 2):
+            o = L.atom_gemm_w4a4_packed_order(M, N, K, w)
+            assert o in (1, 2, 8, 63, 64) or 101 < o <= 108, (M, N, K, w, o)
+        if recc:
+            assert L.atom_gemm_w4a4_packed_order(M, N, K, 2) == L.atom_gemm_w4a4_f6_order(M, N, K) in (1, 2), (M, N, K)
+        assert L.atom_gemm_w4a4_f6_order(M, N, K) in (1, 2)
+    for bad in ((0, 4096, 4096), (16, 4096, 4000), (16, 32, 4096), (16, 4096, 128)):
+        assert L.atom_gemm_w4a4_ws_recodes_cached(*bad) == 0 and L.atom_gemm_w4a4_workspace_bytes(*bad) == 0 and L.atom_gemm_w4a4_f6_order(*bad) == 0
+
+
 def test_fused_quantiser_shape_query():
     """atom_gemm_w4a4_multi_q_fits(q_op, ...): one or two tokens, the shapes atom_gemm_w4a4_multi takes, and the launcher's own bounds
     per quantiser (gemm_w4a4_skinny.hip skinny_q_fits): per thread of the 512 at most two 16-channel slot tasks (SiLU x up: three), at
