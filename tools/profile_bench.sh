@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o bench -- $CMD > $OUT/sq1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM --output-format csv -d $OUT/sq2 -o bench -- $CMD > $OUT/sq2.log 2>&1
 tail -1 $OUT/stats.log
-# controls for the FETCH_SIZE / WRITE_SIZE corrections (tools/probes/fetch_control.cpp: 512 MiB streamed once per launch by LDS-DMA, by
+# controls for the FETCH_SIZE / WRITE_SIZE corrections (build/tools/fetch_control <- `make -C atom_amd/csrc tools probes`; tools/probes/fetch_control.cpp: 512 MiB streamed once per launch by LDS-DMA, by
 # 16-byte loads into registers, by 16-byte stores), in the same kind of pass
 CTL="$R/build/tools/fetch_control 512 5"
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ctl_fetch -o ctl -- $CTL > $OUT/ctl_fetch.log 2>&1
