@@ -754,6 +754,41 @@ def test_c_abi_ws_weight_cached_flag():
     assert torch.equal(outs[0], ops.dense_layer_gemm_i4_fp16(*dev, scale_layout="plain"))
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 13824, 5120), (200, 4096, 4224), (40, 5120, 13824), (512, 4096, 1152), (300, 2048, 1152)])
+def test_c_abi_one_workspace_per_weight_recipe(M, N, K):
+    """The recipe of INTEGRATION.md for a binding that owns its layers: the weight region of the workspace filled ONCE by
+    atom_repack_weight_f6s, ATOM_WS_WEIGHT_CACHED in every call -- the library then re-codes only the activation wherever
+    atom_gemm_w4a4_ws_recodes_cached says so (from 129 rows, and from 17 where the decode-batch kernel does not take the shape) and the
+    result is the plain entry point's in the order atom_gemm_w4a4_packed_order(.., 2) names -- here always the K steps in order, hence
+    bit-identical to the call without a workspace where that sums in order too."""
+    from atom_amd import ops
+    L = ops.L
+    lib = L.lib()
+    dev = to_device(rand_gemm_operands(M, N, K, seed=M + N + K), "plain")
+    a, b, sa, sb, a8, b8, sa8, sb8 = dev
+    need = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
+    assert lib.atom_gemm_w4a4_ws_recodes_cached(M, N, K) == 1 and need >= lib.atom_f6_weight_bytes(N, K)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    stream = L.current_stream(a.device)
+    L.check(lib.atom_repack_weight_f6s(b.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), stream), "atom_repack_weight_f6s")
+    pairs = L.B_SCALE_PAIRS if ops.scale_pairs_shared(sb, N) else 0
+    flags = L.SCALE_LAYOUT_PLAIN | pairs | L.WS_WEIGHT_CACHED
+    outs = []
+    for _ in range(2):
+        d = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        L.check(lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), a8.data_ptr(), b8.data_ptr(), sa8.data_ptr(),
+                                          sb8.data_ptr(), d.data_ptr(), M, N, K, 128, 128, flags, ws.data_ptr(), need, stream), "atom_gemm_w4a4_f16_ws")
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1])
+    assert lib.atom_gemm_w4a4_packed_order(M, N, K, 2) == 1
+    plain = torch.empty_like(outs[0])
+    L.check(lib.atom_gemm_w4a4_f16(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), a8.data_ptr(), b8.data_ptr(), sa8.data_ptr(),
+                                   sb8.data_ptr(), plain.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | pairs, stream), "atom_gemm_w4a4_f16")
+    if lib.atom_gemm_w4a4_packed_order(M, N, K, 0) == 1:
+        assert torch.equal(outs[0], plain)
+    assert_gemm_close(t2n(outs[0]), t2n(plain).astype(np.float64), f"cached-weight route {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 256, 256), (1, 4096, 4096), (1, 11008, 4096), (1, 1024, 11008), (1, 13824, 5120), (1, 640, 13824),
                                    (1, 8256, 640), (1, 8320, 384), (2, 1024, 11008), (2, 13824, 5120), (2, 640, 13824), (2, 8320, 4224)])
 @pytest.mark.parametrize("layout", ["plain", "ref"])
