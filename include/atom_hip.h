@@ -78,15 +78,15 @@ extern "C" {
  * de-quantisation registers (no fp16 -> fp32 conversions in the K loop); `sB` (fp16) is still required -- the other tile
  * geometries read it.
  * Activations: ATOM_QUANT_F6_CODES in `quant_mode` of the three activation ops (o_norms = that buffer; norm_scales is
- * still written).  Weights: atom_repack_weight_f6.  M, N >= 1 as usual; tile geometries picked by shape: 256x256 and
- * 128x128 (4 waves) -- results bit-identical to the INT8 kernels -- and, for shapes of at most 256 tiles (one per CU: mid-size
- * prefill batches, 256..1024 rows at Llama widths), 128x128 / 64x128 tiles shared by two groups of 4 waves that split the
- * G + 1 K steps (the G int4 groups, then the keeper) at (G + 1) / 2: each half is summed in order from 0 and
- * D = half(first + second) -- deterministic, same tolerance, 1.4x faster there (1024x4096x4096: 33 -> 23 us); with at most 256
- * tiles of 64x128 and K_total >= 2048, four groups and four ranges [(G + 1) k / 4, (G + 1) (k + 1) / 4), D = half(((p0 + p1) + p2)
- * + p3) (512x4096x4096: 16.7 us).  atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in order, 2 = two halves,
- * 4 = four ranges (0 = unsupported shape).
- * Ahead of the INT8 kernels from 256 rows up (1.5x at 512-1024 rows, 1.35x at 4096^3).
+ * still written).  Weights: atom_repack_weight_f6 / atom_repack_weight_f6s.  M, N >= 1 as usual; tile geometries picked by shape, all
+ * with the K steps summed in order -- results bit-identical to the INT8 kernels --: 64x64 / 128x64 tiles over the whole K range on a
+ * deep LDS ring while a shape has at most 512 tiles of 64x64 (round 5: 256x4096x4096 11.0 us, 512x4096x4096 14.7), 256x256 where
+ * those fill the chip (4096^3: 48.5-50 us), 256x128 and 128x128 (4 waves) between -- EXCEPT shapes beyond 512 tiles of 64x64 with at
+ * most 256 tiles of 128x128 (and >= 8 K steps; 1024x4096x4096: 23 us): their 128x128 tiles are shared by two groups of 4 waves that
+ * split the G + 1 K steps (the G int4 groups, then the keeper) at (G + 1) / 2: each half is summed in order from 0 and
+ * D = half(first + second) -- deterministic, same tolerance.  atom_gemm_w4a4_f6_order(M, N, K_total) tells which: 1 = K steps in
+ * order, 2 = two halves (4 = four ranges: tuning builds only; 0 = unsupported shape).
+ * Ahead of the INT8 kernels from 129 rows up (1.7x at 512-1024 rows, 1.8x at 4096^3).
  */
 #define ATOM_QUANT_F6_CODES 0x200
 #define ATOM_AB_F6 0x200
@@ -103,8 +103,9 @@ int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
  * weight of a layer is static) -- so only the activation is re-coded: 5 instead of 10 us of re-coding at 4096^3.  The library keeps no
  * state: the CALLER asserts it (atom_amd.ops tracks which weight its workspace holds).  Wrong flag = wrong results, never a fault
  * (the region is inside the workspace either way).  Ignored on every other route.
- * Round 5: with the flag the re-coding route starts at 129 rows (N >= 2048, K >= 1024) -- only the activation is re-coded, and the
- * mid-size-batch kernel behind it runs 129 .. 256 rows in ~10 us at 4096 x 4096 where the decode-batch kernel takes 9.4 .. 15.5 --, so a
+ * Round 5: with the flag the re-coding route starts at 129 rows (N >= 2048, K >= 1024; at 17 rows where the decode-batch kernel does
+ * not take the shape: atom_gemm_w4a4_ws_recodes_cached) -- only the activation is re-coded, and the mid-size-batch kernel behind it runs
+ * 129 .. 256 rows in ~11 us at 4096 x 4096 where the decode-batch kernel takes 9.4 .. 15.5, 64 x 13824 x 5120 in 12 us --, so a
  * caller that keeps ONE workspace per weight (a layer's weight is static) fills its weight region once, offline, with
  * atom_repack_weight_f6s(B4, sB, N, K_total, workspace, stream) -- the region's layout is exactly that function's output -- and passes
  * the flag on every call; atom_gemm_w4a4_workspace_bytes() covers those shapes, atom_gemm_w4a4_packed_order(.., 2) names their order. */
@@ -175,15 +176,17 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
 /* The FP32 summation order atom_gemm_w4a4_f16 (with_workspace = 0) / atom_gemm_w4a4_f16_ws with a workspace of
  * atom_gemm_w4a4_workspace_bytes() bytes (with_workspace = 1) applies to PACKED (reference-format) operands of this shape -- a host-side
  * function of the shape alone, what the parity tests restate the arithmetic for (oracle/atom_oracle.c):
- *   1        the K steps (int4 groups, then the keeper) in order: the tile kernels -- among them the mid-size-batch kernel
- *            (gemm_w4a4_mid.hip: 64 x 64 tiles on a deep LDS ring, M > 16 once the tiles fill a good part of the chip, up to 1024 rows)
- *   2, 4     two / four ordered ranges of the K steps (the BF6 K-group kernels behind the re-coding route; see ATOM_AB_F6)
+ *   1        the K steps (int4 groups, then the keeper) in order: the tile kernels -- among them the mid-size-batch kernels
+ *            (gemm_w4a4_mid.hip: 64 x 64 / 128 x 64 tiles on a deep LDS ring; the INT8 form for 17 .. 256 rows with 96 .. 256 tiles, the
+ *            BF6 form behind the re-coding routes up to 512 tiles of 64 x 64)
+ *   2        two ordered ranges of the K steps (the BF6 two-wave-group kernel behind the re-coding routes; see ATOM_AB_F6)
  *   8        the decode-batch kernel: the G + 1 steps dealt to 8 waves in consecutive slices, partial sums added in wave order
  *   64       the one- / two-token dot-product kernel: groups dealt to 16 quad leaders, 64-lane butterfly, keeper last
  *   63       the staged dot-product kernel (M <= 7 with a K too long for the decode-batch kernel): per-lane partial sums
  *   100 + s  split-K over s workgroups through the workspace, partial sums added in split order
  *   0        unsupported shape
- * with_workspace = 2: a workspace AND ATOM_WS_WEIGHT_CACHED (the re-coding route from 129 rows). */
+ * with_workspace = 2: a workspace AND ATOM_WS_WEIGHT_CACHED (the re-coding route from 129 rows, and from 17 rows for the shapes the
+ * decode-batch kernel does not take: atom_gemm_w4a4_ws_recodes_cached). */
 int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_workspace);
 
 /*
