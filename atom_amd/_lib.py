@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libatom_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
+ERR_INVALID_ARG, ERR_SHAPE, ERR_ALIGN, ERR_LAUNCH = -22, -33, -14, -5   # ATOM_ERR_*
 SCALE_LAYOUT_REF = 0
 SCALE_LAYOUT_PLAIN = 1
 QUANT_KERNEL = 0
@@ -26,6 +27,7 @@ O4_REF_EXTREMA = 0x800     # ATOM_O4_REF_EXTREMA
 B_F6S = 0x400              # ATOM_B_F6S: float32 weight scales appended to the F6 weight buffer
 WS_WEIGHT_CACHED = 0x1000  # ATOM_WS_WEIGHT_CACHED: the workspace already holds this weight's F6 form
 B_SCALE_PAIRS = 0x2000     # ATOM_B_SCALE_PAIRS: output channels 2j, 2j+1 share their weight scales (weight_channel_group = 2)
+WS_VERIFY = 0x4000         # ATOM_WS_VERIFY: debug call -- the two assertions above are checked on the device first (synchronises)
 Q_REORDER, Q_RMSNORM, Q_ADD_RMSNORM, Q_SILU_MUL = 1, 2, 3, 4     # atom_gemm_w4a4_multi_q: q_op
 F6_PITCH = 104
 
@@ -44,6 +46,8 @@ SIGNATURES = {
     "atom_gemm_w4a4_ws_recodes": (_int, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_ws_recodes_cached": (_int, [_i64, _i64, _i64]),
     "atom_gemm_w4a4_packed_order": (_int, [_i64, _i64, _i64, _int]),
+    "atom_check_scale_pairs": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "atom_verify_weight_f6s": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "atom_gemm_w4a4_f16_ws": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_gemm_w4a4_multi_fits": (_int, [_i64, _i64, _int, _i64]),
     "atom_gemm_w4a4_multi": (_int, [_vp] * 11 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _int, _vp]),

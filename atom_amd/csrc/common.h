@@ -131,6 +131,10 @@ int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_
                           const half_t *sB, float *sB32,   // weight scales fp16 [G, N] -> float32 [G][Npad] (both or neither)
                           const uint8_t *B4, int64_t N, uint8_t *outB, int K4h, int G, hipStream_t s);
 
+// ... checkers of the two caller assertions (ATOM_B_SCALE_PAIRS, ATOM_WS_WEIGHT_CACHED): violations are ADDED to *n_bad (device)
+int launch_check_scale_pairs(const half_t *sB, int64_t G, int64_t N, int32_t *n_bad, hipStream_t s);
+int launch_verify_weight_f6s(const uint8_t *B4, const half_t *sB, int64_t N, int K4h, int G, const uint8_t *have, int32_t *n_bad, hipStream_t s);
+
 // LDS-DMA (global_load_lds_*: global memory -> LDS at M0 + lane * size, no VGPR round trip), issued through inline asm and
 // NOT through __builtin_amdgcn_global_load_lds: with the builtin in a loop the compiler's wait-count pass treats the DMA as a
 // pending FLAT access and emits `s_waitcnt lgkmcnt(0)` -- a full drain -- in front of EVERY later LDS-read consumer instead of

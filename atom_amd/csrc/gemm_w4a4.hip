@@ -106,6 +106,32 @@ static int f6_pick_cfg(int64_t M, int64_t N, int64_t K_total) {
   return 3;
 }
 
+// ATOM_WS_VERIFY (debug calls of atom_gemm_w4a4_f16_ws): CHECK the caller's assertions before using them -- a wrong ATOM_B_SCALE_PAIRS or
+// ATOM_WS_WEIGHT_CACHED otherwise gives wrong numbers without any error.  Violations are counted on the device into the last 16 bytes of
+// the workspace (free until the GEMM's own use of it starts), copied back, and the stream is SYNCHRONISED: not for production calls,
+// not during graph capture.
+static bool f6_route(int64_t M, int64_t N, int64_t K_total);
+static bool f6_route_cached(int64_t M, int64_t N, int64_t K_total);
+static int verify_assertions(const GemmParams &p, int64_t M, int64_t N, int64_t K_total, int flags, void *workspace, size_t workspace_bytes,
+                             hipStream_t hs) {
+  if (!workspace || workspace_bytes < 16 || !aligned16(workspace)) return ATOM_ERR_INVALID_ARG;
+  int32_t *cnt = reinterpret_cast<int32_t *>((uint8_t *)workspace + ((workspace_bytes - 16) & ~(size_t)15));
+  if (hipMemsetAsync(cnt, 0, 16, hs) != hipSuccess) return ATOM_ERR_LAUNCH;
+  if (p.b_pairs && !p.f6_rows_a) {
+    const int r = launch_check_scale_pairs(p.sB, p.G, N, cnt, hs);
+    if (r != ATOM_OK) return r;
+  }
+  if ((flags & ATOM_WS_WEIGHT_CACHED) && !p.a_wide && !p.f6_rows_a && (f6_route(M, N, K_total) || f6_route_cached(M, N, K_total))) {
+    if (workspace_bytes < atom_gemm_w4a4_workspace_bytes(M, N, K_total)) return ATOM_ERR_INVALID_ARG;   // no weight region to speak of
+    const int r = launch_verify_weight_f6s(p.B4, p.sB, N, p.K4h, p.G, (const uint8_t *)workspace, cnt + 1, hs);
+    if (r != ATOM_OK) return r;
+  }
+  int32_t host[2] = {0, 0};
+  if (hipMemcpyAsync(host, cnt, sizeof(host), hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess)
+    return ATOM_ERR_LAUNCH;
+  return host[0] != 0 || host[1] != 0 ? ATOM_ERR_INVALID_ARG : ATOM_OK;
+}
+
 extern "C" {
 
 int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total) {
@@ -204,7 +230,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   const int f6 = (scale_layout & ATOM_AB_F6) != 0, f6s = (scale_layout & ATOM_B_F6S) != 0;
   p.o4_ref = (scale_layout & ATOM_O4_REF_EXTREMA) != 0;    // (only the _o4 entry points look at it)
   p.b_pairs = (scale_layout & ATOM_B_SCALE_PAIRS) != 0;
-  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA | ATOM_WS_WEIGHT_CACHED | ATOM_B_SCALE_PAIRS);
+  scale_layout &= ~(ATOM_A_WIDE | ATOM_AB_F6 | ATOM_B_F6S | ATOM_O4_REF_EXTREMA | ATOM_WS_WEIGHT_CACHED | ATOM_B_SCALE_PAIRS | ATOM_WS_VERIFY);
   if ((a_wide && f6) || (f6s && !f6)) return ATOM_ERR_INVALID_ARG;
   if (scale_layout != ATOM_SCALE_LAYOUT_REF && scale_layout != ATOM_SCALE_LAYOUT_PLAIN) return ATOM_ERR_INVALID_ARG;
   if (group != kGroup || keeper != kKeeper) return ATOM_ERR_SHAPE;
@@ -233,8 +259,10 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 
 // Split-K policy: shapes that yield fewer than 512 workgroups of the smallest tile are latency-bound (one pass over K per
 // workgroup at ~1 us per K-group); split the K loop over up to 8 workgroups and reduce FP32 partials in a second launch.
-static int choose_splits(int64_t M, int64_t N, int64_t K_total) {
-  if (M <= gemv_max_m() || skinny_fits(M, N, K_total) || mid_fits(M, N, K_total)) return 1;   // decode / mid-size kernels
+// `packed`: the operands are packed nibbles (pre-widened ATOM_A_WIDE activations do not reach the mid-size-batch kernel, so its shapes
+// keep their split-K route for those)
+static int choose_splits(int64_t M, int64_t N, int64_t K_total, bool packed = true) {
+  if (M <= gemv_max_m() || skinny_fits(M, N, K_total) || (packed && mid_fits(M, N, K_total))) return 1;   // decode / mid-size kernels
   const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
   const int64_t nsteps = (K_total - kKeeper) / kGroup + 2;
   const int force = ATOM_TUNE("ATOM_SPLITS", 0);
@@ -278,7 +306,9 @@ int atom_gemm_w4a4_packed_order(int64_t M, int64_t N, int64_t K_total, int with_
   if (with_workspace && atom_gemm_w4a4_workspace_bytes(M, N, K_total) != 0) {
     if (f6_route(M, N, K_total) || (with_workspace == 2 && f6_route_cached(M, N, K_total)))
       return atom_gemm_w4a4_f6_order(M, N, K_total);                                 // re-coded to BF6: 1 / 2
-    if (choose_splits(M, N, K_total) > 1) return 100 + choose_splits(M, N, K_total); // split-K through the workspace
+    // split-K through the workspace -- never with ATOM_WS_WEIGHT_CACHED: the workspace's head holds the weight's BF6 form then, and
+    // FP32 partial sums written there would destroy it (atom_gemm_w4a4_f16_ws runs such a call as the plain entry point does)
+    if (with_workspace != 2 && choose_splits(M, N, K_total) > 1) return 100 + choose_splits(M, N, K_total);
   }
   if (M <= gemv_tokens(K_total)) return 64;                                          // the dot-product kernel
   if (mid_fits(M, N, K_total)) return 1;
@@ -299,7 +329,7 @@ int atom_gemm_w4a4_ws_recodes_cached(int64_t M, int64_t N, int64_t K_total) {
 
 size_t atom_gemm_w4a4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {
   if (M < 1 || N < 64 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
-  const int s = choose_splits(M, N, K_total);
+  const int s = choose_splits(M, N, K_total, false);                           // (the larger of the two operand formats' needs)
   const size_t split = s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
   const size_t f6 = f6_bytes(M, K_total) + f6_bytes(N, K_total) / 104 * 108;     // B: + float32 scales
   if (f6_route(M, N, K_total)) return f6;
@@ -311,6 +341,13 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
                           const void *sA8, const void *sB8, void *D, int64_t M, int64_t N, int64_t K_total, int group,
                           int keeper, int scale_layout, void *workspace, size_t workspace_bytes, void *stream) {
   const size_t need = atom_gemm_w4a4_workspace_bytes(M, N, K_total);
+  if (scale_layout & ATOM_WS_VERIFY) {                       // debug call: the caller's assertions are checked first (synchronises)
+    GemmParams pv;
+    const int fv = fill_params(pv, A4, B4, sA, sB, A8, B8, sA8, sB8, M, N, K_total, group, keeper, scale_layout);
+    if (fv != ATOM_OK) return fv;
+    const int rv = verify_assertions(pv, M, N, K_total, scale_layout, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+    if (rv != ATOM_OK) return rv;
+  }
   if (need == 0 || !workspace || workspace_bytes < need)
     return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
   if (!D) return ATOM_ERR_INVALID_ARG;
@@ -320,6 +357,12 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
   if (!aligned16(D) || !aligned16(workspace) || (N % 8) != 0) return ATOM_ERR_ALIGN;
   p.D = (half_t *)D;
   const bool wcached = (scale_layout & ATOM_WS_WEIGHT_CACHED) != 0;
+  // ATOM_WS_WEIGHT_CACHED: the head of the workspace is the weight's BF6 form, valid across calls of ANY batch size -- a call that does
+  // not take the re-coding route must not use the workspace for anything else (round 5 wrote split-K partial sums over it: 8 .. 16 rows
+  // at K_total > 14464, e.g. Llama-70B down_proj; the next call from 17 rows then multiplied garbage).  Such a call runs as the plain
+  // entry point does: atom_gemm_w4a4_packed_order(.., 2) says so.
+  if (wcached && !p.a_wide && !p.f6_rows_a && !f6_route(M, N, K_total) && !f6_route_cached(M, N, K_total))
+    return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
   if (!p.a_wide && !p.f6_rows_a && !f6_route(M, N, K_total) && !(wcached && f6_route_cached(M, N, K_total)) && choose_splits(M, N, K_total) <= 1)
     return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);   // (129 .. 256 rows, nothing cached)
   if (!p.a_wide && !p.f6_rows_a && (f6_route(M, N, K_total) || (wcached && f6_route_cached(M, N, K_total)))) {   // packed operands -> F6 copies in the workspace
@@ -341,11 +384,11 @@ int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const 
     return launch_gemm_f6(p, f6_pick_cfg(M, N, K_total), hs);
   }
   if (p.a_wide || p.f6_rows_a) {                                      // native formats: no workspace route for these sizes
-    if (choose_splits(M, N, K_total) <= 1)
+    if (choose_splits(M, N, K_total, !p.a_wide) <= 1)
       return atom_gemm_w4a4_f16(A4, B4, sA, sB, A8, B8, sA8, sB8, D, M, N, K_total, group, keeper, scale_layout, stream);
   }
   p.ws = (float *)workspace;
-  p.splits = choose_splits(M, N, K_total);
+  p.splits = choose_splits(M, N, K_total, !p.a_wide);
   if (p.f6_rows_a) {                                                  // the F6 kernels need no workspace (tools: ATOM_F6_SPLITS3)
     const int cfg = f6_pick_cfg(M, N, K_total);
     const int sp = ATOM_TUNE("ATOM_F6_SPLITS3", 0);

@@ -1090,6 +1090,64 @@ int launch_repack_f6_pair(const uint8_t *A4, int64_t M, const half_t *sA, int64_
   return check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Checkers for the two caller ASSERTIONS of the GEMM entry points (ATOM_B_SCALE_PAIRS, ATOM_WS_WEIGHT_CACHED): a wrong assertion gives
+// wrong numbers, never a fault, so a binding that cannot prove them by construction asks these (offline with the weight, or through
+// ATOM_WS_VERIFY on a debug call).  Both add the number of violations to a device counter.
+__global__ __launch_bounds__(256) void check_scale_pairs_kernel(const half_t *sB, int64_t npairs_total, int32_t *n_bad) {
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npairs_total; i += (int64_t)gridDim.x * 256) {
+    const unsigned w = reinterpret_cast<const unsigned *>(sB)[i];           // channels 2 j, 2 j + 1 of one group: N is even, sB 4-byte aligned
+    bad += (w & 0xFFFFu) != (w >> 16);
+  }
+  if (bad) atomicAdd(n_bad, bad);
+}
+
+// the F6 weight form [G][rows_pad][104] (+ float32 scales [G][rows_pad] behind it) against what atom_repack_weight_f6s makes of the
+// packed weight: one thread per (row < N, group) re-codes its 128 codes and compares the record and the scale (pad rows: not compared)
+__global__ __launch_bounds__(256) void verify_weight_f6s_kernel(RepackF6Params p, const uint8_t *have, int32_t *n_bad) {
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  typedef unsigned v6u __attribute__((ext_vector_type(6)));
+  const int g = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.N) return;
+  const uint8_t *src = p.B4 + n * p.K4h + g * 64;
+  const unsigned *rec = reinterpret_cast<const unsigned *>(have + ((int64_t)g * p.rows_pad + n) * 104);
+  int bad = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const v4u raw = *reinterpret_cast<const v4u *>(src + 16 * q);
+    v16f ea, eb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const unsigned byte = (raw[i >> 2] >> (8 * (i & 3))) & 0xFF;
+      ea[i] = (float)((int)(byte << 28) >> 28);
+      eb[i] = (float)((int)(byte << 24) >> 28);
+    }
+    const v6u f = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(ea, eb, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bad |= rec[6 * q + k] != f[k];
+  }
+  const float *s32 = reinterpret_cast<const float *>(have + (size_t)p.G * p.rows_pad * 104);
+  const float want = (float)p.wscale[(int64_t)g * p.N + n];
+  bad |= __builtin_bit_cast(unsigned, s32[(int64_t)g * p.rows_pad + n]) != __builtin_bit_cast(unsigned, want);
+  if (bad) atomicAdd(n_bad, 1);
+}
+
+int launch_check_scale_pairs(const half_t *sB, int64_t G, int64_t N, int32_t *n_bad, hipStream_t s) {
+  const int64_t np = G * (N / 2);
+  const unsigned grid = (unsigned)(np / 256 + 1 < 1024 ? np / 256 + 1 : 1024);
+  hipLaunchKernelGGL(check_scale_pairs_kernel, dim3(grid), dim3(256), 0, s, sB, np, n_bad);
+  return check_launch();
+}
+
+int launch_verify_weight_f6s(const uint8_t *B4, const half_t *sB, int64_t N, int K4h, int G, const uint8_t *have, int32_t *n_bad, hipStream_t s) {
+  const int64_t Npad = (N + 255) / 256 * 256;
+  const RepackF6Params q{B4, nullptr, N, Npad, K4h, G, nullptr, 0, 0, sB, nullptr};
+  hipLaunchKernelGGL(verify_weight_f6s_kernel, dim3((unsigned)(Npad / 256), (unsigned)G), dim3(256), 0, s, q, have, n_bad);
+  return check_launch();
+}
+
 }  // namespace atom
 
 using namespace atom;
@@ -1224,6 +1282,25 @@ int atom_repack_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_
   pp.op[1] = pp.op[0];
   hipLaunchKernelGGL(repack_f6_kernel, dim3((unsigned)(Npad / 256), (unsigned)G, 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pp);
   return check_launch();
+}
+
+int atom_check_scale_pairs(const void *sB, int64_t G, int64_t N, int32_t *n_bad_dev, void *stream) {
+  if (!sB || !n_bad_dev) return ATOM_ERR_INVALID_ARG;
+  if (G < 1 || N < 2 || (N % 2) != 0 || G > (1 << 20) || N > (1 << 24)) return ATOM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(sB) & 3u) || (reinterpret_cast<uintptr_t>(n_bad_dev) & 3u)) return ATOM_ERR_ALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(n_bad_dev, 0, sizeof(int32_t), s) != hipSuccess) return ATOM_ERR_LAUNCH;
+  return launch_check_scale_pairs((const half_t *)sB, G, N, n_bad_dev, s);
+}
+
+int atom_verify_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_total, const void *B_f6s, int32_t *n_bad_dev, void *stream) {
+  if (!B4 || !sB || !B_f6s || !n_bad_dev) return ATOM_ERR_INVALID_ARG;
+  if (N < 1 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0 || K_total > (1 << 20)) return ATOM_ERR_SHAPE;
+  if (!aligned16(B4) || !aligned16(B_f6s) || (reinterpret_cast<uintptr_t>(n_bad_dev) & 3u)) return ATOM_ERR_ALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(n_bad_dev, 0, sizeof(int32_t), s) != hipSuccess) return ATOM_ERR_LAUNCH;
+  return launch_verify_weight_f6s((const uint8_t *)B4, (const half_t *)sB, N, (int)((K_total - kKeeper) / 2), (int)((K_total - kKeeper) / kGroup),
+                                  (const uint8_t *)B_f6s, n_bad_dev, s);
 }
 
 }  // extern "C"

@@ -216,6 +216,8 @@ def _drop_f6w(key):
     e = _F6W.pop(key, None)
     if e is not None:
         _F6W_STATE["bytes"] -= e[2]
+        for f in e[1]:                                       # (a no-op for the finalizer that is calling us)
+            f.detach()
 
 
 def set_weight_f6_cache_bytes(limit: int):
@@ -232,10 +234,18 @@ def clear_weight_f6_cache():
     _F6W_STATE.update(bytes=0, hits=0, misses=0)
 
 
-def forget_weight_f6(b: torch.Tensor):
-    """Drop the cached F6 form(s) of the packed weight ``b`` (after writing it through an alias that keeps the version counter)."""
+def forget_weight_f6(b: torch.Tensor, b_scale: torch.Tensor = None):
+    """Drop the cached F6 form(s) of the packed weight ``b`` (after writing it through an alias that keeps the version counter --
+    ``.data`` / ``.detach()`` writes, inference tensors).  Pass the weight's scale tensor as well after such a write to IT: the
+    channel-pair tag of ``_pairs_flag`` lives on that tensor object and is keyed by the same version counter."""
     for key in [k for k in _F6W if k[1] == b.data_ptr() and k[0] == b.device]:
         _drop_f6w(key)
+    for t in (b, b_scale):
+        if t is not None and getattr(t, "_atom_pairs", None) is not None:
+            try:
+                del t._atom_pairs
+            except AttributeError:
+                pass
 
 
 def _evict_f6w():
@@ -269,6 +279,12 @@ def _weight_f6s(b, b_scale, n, k):
         return f6
     torch.cuda.current_stream(b.device).synchronize()        # complete before any other stream (or a graph captured later) reads it
     fin = tuple(weakref.finalize(st, _drop_f6w, key) for st in (b.untyped_storage(), b_scale.untyped_storage()))
+    if not all(f.alive for f in fin):
+        # a torch whose untyped_storage() hands out a fresh wrapper per call: the finalizers have fired already and the entry could
+        # never be dropped -- a recycled address would then hit a stale weight.  Do not cache (the call re-codes in the workspace).
+        for f in fin:
+            f.detach()
+        return f6
     _F6W[key] = [f6, fin, nbytes, False]
     _F6W_STATE["bytes"] += nbytes
     _evict_f6w()

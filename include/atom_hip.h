@@ -118,6 +118,14 @@ int atom_gemm_w4a4_f6_order(int64_t M, int64_t N, int64_t K_total);
  * when it does not (never a fault).  sB8 -- the keeper's scales are per output channel, model/qLinearLayer.py:59 -- is not covered:
  * the keeper step always forms one product per channel.  Ignored by kernels that do not use it. */
 #define ATOM_B_SCALE_PAIRS 0x2000
+/* atom_gemm_w4a4_f16_ws only, DEBUG: verify the two assertions above on the device before relying on them -- ATOM_B_SCALE_PAIRS against
+ * the values of sB (packed operands), ATOM_WS_WEIGHT_CACHED by re-coding B4 / sB and comparing with the workspace's weight region --
+ * and return ATOM_ERR_INVALID_ARG instead of computing wrong numbers when one does not hold.  Needs a workspace of
+ * atom_gemm_w4a4_workspace_bytes() (its last 16 bytes serve as the counter before the GEMM uses them); SYNCHRONISES the stream (the one
+ * exception to "no synchronisation" in this ABI), so it is not for production calls nor for graph capture.  The reference guards
+ * its KV ops the same way at the binding (TORCH_CHECK in punica_ops.cc:18-47); a binding without a debug mode asks the two functions
+ * below once per weight instead. */
+#define ATOM_WS_VERIFY 0x4000
 #define ATOM_F6_PITCH 104
 
 const char *atom_version(void);
@@ -168,6 +176,15 @@ int atom_gemm_w4a4_ws_recodes(int64_t M, int64_t N, int64_t K_total);
  * activation is re-coded): additionally every shape of 129 rows and more, and from 17 rows the shapes the decode-batch kernel does not
  * take (N >= 2048, K >= 1024 throughout).  What a binding that keeps one workspace per weight asks. */
 int atom_gemm_w4a4_ws_recodes_cached(int64_t M, int64_t N, int64_t K_total);
+/* Checkers of the caller assertions (asynchronous on `stream`, no synchronisation; the count is a device int32 the caller reads):
+ *   atom_check_scale_pairs   *n_bad_dev = number of (group, channel pair) of sB fp16 [G][N] whose two scales differ -- 0 means
+ *                            ATOM_B_SCALE_PAIRS may be asserted for this weight (what atom_amd/ops.py:scale_pairs_shared computes in torch)
+ *   atom_verify_weight_f6s   *n_bad_dev = number of (row < N, group) whose F6 record or float32 scale in B_f6s (atom_f6_weight_bytes(N,
+ *                            K_total) bytes: a workspace's weight region) is not what atom_repack_weight_f6s makes of B4 / sB -- 0 means
+ *                            ATOM_WS_WEIGHT_CACHED may be asserted for this (workspace, weight)
+ * No reference counterpart (its launcher has neither flag; its bindings check what they can with TORCH_CHECK, punica_ops.cc:18-47). */
+int atom_check_scale_pairs(const void *sB, int64_t G, int64_t N, int32_t *n_bad_dev, void *stream);
+int atom_verify_weight_f6s(const void *B4, const void *sB, int64_t N, int64_t K_total, const void *B_f6s, int32_t *n_bad_dev, void *stream);
 int atom_gemm_w4a4_f16_ws(const void *A4, const void *B4, const void *sA, const void *sB,
                           const void *A8, const void *B8, const void *sA8, const void *sB8,
                           void *D, int64_t M, int64_t N, int64_t K_total,

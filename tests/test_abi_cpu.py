@@ -93,6 +93,9 @@ def test_packed_route_query():
     assert recc(64, 4096, 4096) == 0 and recc(128, 11008, 4096) == 0 and recc(16, 13824, 5120) == 0 and recc(64, 1024, 13824) == 0
     assert wsb(64, 13824, 5120) > 0 and L.atom_gemm_w4a4_packed_order(64, 13824, 5120, 2) == 1
     assert L.atom_gemm_w4a4_packed_order(64, 5120, 13824, 1) > 100 and wsb(64, 5120, 13824) >= 8 * 64 * 5120 * 4   # split K without the flag
+    # 8 .. 16 rows at K_total > 14464 (Llama-70B down_proj): split K through the workspace WITHOUT the flag, the plain entry point's
+    # kernel with it -- the partial sums would land on the cached weight otherwise (tests/test_gpu_gemm.py)
+    assert L.atom_gemm_w4a4_packed_order(12, 8192, 28672, 1) > 100 and L.atom_gemm_w4a4_packed_order(12, 8192, 28672, 2) == L.atom_gemm_w4a4_packed_order(12, 8192, 28672, 0)
 
 
 def test_dispatch_queries_are_consistent_over_random_shapes():
@@ -116,6 +119,8 @@ def test_dispatch_queries_are_consistent_over_random_shapes():
         for w in (0, 1, 2):
             o = L.atom_gemm_w4a4_packed_order(M, N, K, w)
             assert o in (1, 2, 8, 63, 64) or 101 < o <= 108, (M, N, K, w, o)
+            # a call that asserts ATOM_WS_WEIGHT_CACHED never splits K through the workspace: its head is the cached weight
+            assert not (w == 2 and o > 100), (M, N, K, o)
         if recc:
             assert L.atom_gemm_w4a4_packed_order(M, N, K, 2) == L.atom_gemm_w4a4_f6_order(M, N, K) in (1, 2), (M, N, K)
         assert L.atom_gemm_w4a4_f6_order(M, N, K) in (1, 2)

@@ -789,6 +789,114 @@ def test_c_abi_one_workspace_per_weight_recipe(M, N, K):
     assert_gemm_close(t2n(outs[0]), t2n(plain).astype(np.float64), f"cached-weight route {M}x{N}x{K}")
 
 
+def _ws_call(lib, L, dev, M, N, K, flags, ws, need):
+    a, b, sa, sb, a8, b8, sa8, sb8 = dev
+    d = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    st = lib.atom_gemm_w4a4_f16_ws(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), a8.data_ptr(), b8.data_ptr(), sa8.data_ptr(),
+                                   sb8.data_ptr(), d.data_ptr(), M, N, K, 128, 128, flags, ws.data_ptr(), need, L.current_stream(a.device))
+    return st, d
+
+
+def test_c_abi_cached_weight_survives_decode_size_calls():
+    """one workspace per weight, ATOM_WS_WEIGHT_CACHED on EVERY call, batch sizes alternating between 8 .. 16 rows
+    and >= 17 rows at K_total > 14464 (Llama-70B down_proj's K = 28672 at a reduced N): the decode-size call used to run split-K with
+    its FP32 partial sums at workspace offset 0 -- over the cached BF6 weight -- and the next call from 17 rows multiplied garbage.  A
+    call with the flag outside the re-coding route now runs as the plain entry point does (atom_gemm_w4a4_packed_order(.., 2))."""
+    from atom_amd import ops
+    L = ops.L
+    lib = L.lib()
+    N, K = 2048, 14464 + 128 * 4
+    need = max(lib.atom_gemm_w4a4_workspace_bytes(M, N, K) for M in (8, 12, 16, 24, 160))
+    assert need >= lib.atom_f6_weight_bytes(N, K)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    full = rand_gemm_operands(160, N, K, seed=77)
+    stream = L.current_stream(torch.device("cuda"))
+    devs = {}
+    for M in (8, 12, 16, 24, 160):
+        sub = dict(full)
+        for k in ("qa4", "qa8", "sA", "sA8"):
+            sub[k] = full[k][:M]
+        devs[M] = to_device(sub, "plain")
+    b, sb = devs[160][1], devs[160][3]
+    L.check(lib.atom_repack_weight_f6s(b.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), stream), "atom_repack_weight_f6s")
+    region = ws[: lib.atom_f6_weight_bytes(N, K)].clone()
+    flags = L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS | L.WS_WEIGHT_CACHED
+    # the workspace-less split-K shape the finding names: without the flag it does split (order 100 + s), with it it must not
+    assert lib.atom_gemm_w4a4_packed_order(12, N, K, 1) > 100 and lib.atom_gemm_w4a4_packed_order(12, N, K, 2) < 100
+    ref = {}
+    for M in (24, 8, 160, 12, 24, 16, 160):
+        st, d = _ws_call(lib, L, devs[M], M, N, K, flags, ws, need)
+        L.check(st, "atom_gemm_w4a4_f16_ws")
+        torch.cuda.synchronize()
+        assert torch.equal(ws[: region.numel()], region), f"M = {M} wrote into the cached weight region"
+        if M in ref:
+            assert torch.equal(d, ref[M]), f"M = {M}: result changed after decode-size calls on the same workspace"
+        ref[M] = d
+        want = torch.empty_like(d)
+        a, b_, sa, sb_, a8, b8, sa8, sb8 = devs[M]
+        L.check(lib.atom_gemm_w4a4_f16(a.data_ptr(), b_.data_ptr(), sa.data_ptr(), sb_.data_ptr(), a8.data_ptr(), b8.data_ptr(), sa8.data_ptr(),
+                                       sb8.data_ptr(), want.data_ptr(), M, N, K, 128, 128, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS, stream), "plain")
+        assert_gemm_close(t2n(d), t2n(want).astype(np.float64), f"cached-weight workspace, M = {M}")
+
+
+def test_c_abi_wrong_assertions_are_caught_in_verify_mode():
+    """ATOM_B_SCALE_PAIRS and ATOM_WS_WEIGHT_CACHED are caller assertions whose violation gives wrong numbers
+    silently.  atom_check_scale_pairs / atom_verify_weight_f6s count the violations on the device, and a debug call with ATOM_WS_VERIFY
+    returns ATOM_ERR_INVALID_ARG instead of computing with a wrong assertion (the reference checks at its binding too: TORCH_CHECK in
+    punica_ops.cc:18-47)."""
+    from atom_amd import ops
+    L = ops.L
+    lib = L.lib()
+    M, N, K = 300, 2048, 1152
+    ops_np = rand_gemm_operands(M, N, K, seed=5)
+    dev = to_device(ops_np, "plain")
+    a, b, sa, sb, a8, b8, sa8, sb8 = dev
+    stream = L.current_stream(a.device)
+    G = K // 128 - 1
+    cnt = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.atom_check_scale_pairs(sb.data_ptr(), G, N, cnt.data_ptr(), stream), "atom_check_scale_pairs")
+    assert int(cnt[0]) == 0
+    sb_bad = sb.clone()
+    sb_bad[3, 11] = sb_bad[3, 10] * 2                                    # one pair with two different scales
+    sb_bad[0, 1] = sb_bad[0, 0] + sb_bad[0, 0] * 0.5
+    L.check(lib.atom_check_scale_pairs(sb_bad.data_ptr(), G, N, cnt.data_ptr(), stream), "atom_check_scale_pairs")
+    assert int(cnt[0]) == 2
+    need = lib.atom_gemm_w4a4_workspace_bytes(M, N, K)
+    assert need > 0 and lib.atom_gemm_w4a4_ws_recodes_cached(M, N, K) == 1
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    L.check(lib.atom_repack_weight_f6s(b.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), stream), "atom_repack_weight_f6s")
+    L.check(lib.atom_verify_weight_f6s(b.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), cnt.data_ptr(), stream), "atom_verify_weight_f6s")
+    assert int(cnt[0]) == 0
+    base = L.SCALE_LAYOUT_PLAIN | L.WS_VERIFY
+    # right assertions: the verified call computes what the unverified one does
+    st, d_ok = _ws_call(lib, L, dev, M, N, K, base | L.B_SCALE_PAIRS | L.WS_WEIGHT_CACHED, ws, need)
+    L.check(st, "verified call")
+    st, d_plain = _ws_call(lib, L, dev, M, N, K, L.SCALE_LAYOUT_PLAIN | L.B_SCALE_PAIRS | L.WS_WEIGHT_CACHED, ws, need)
+    L.check(st, "unverified call")
+    assert torch.equal(d_ok, d_plain)
+    # wrong ATOM_B_SCALE_PAIRS: the scales do not pair up
+    dev_bad = (a, b, sa, sb_bad, a8, b8, sa8, sb8)
+    st, _ = _ws_call(lib, L, dev_bad, M, N, K, base | L.B_SCALE_PAIRS, ws, need)
+    assert st == L.ERR_INVALID_ARG, lib.atom_strerror(st).decode()
+    st, _ = _ws_call(lib, L, dev_bad, M, N, K, base, ws, need)            # without the assertion the same operands are fine
+    L.check(st, "unpaired scales, no assertion")
+    # wrong ATOM_WS_WEIGHT_CACHED: the workspace holds ANOTHER weight's BF6 form (one code changed) / a zeroed region
+    L.check(lib.atom_repack_weight_f6s(b.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), stream), "atom_repack_weight_f6s")
+    b2 = b.clone()
+    b2[17, 5] ^= 0x30
+    L.check(lib.atom_verify_weight_f6s(b2.data_ptr(), sb.data_ptr(), N, K, ws.data_ptr(), cnt.data_ptr(), stream), "atom_verify_weight_f6s")
+    assert int(cnt[0]) == 1
+    dev2 = (a, b2, sa, sb, a8, b8, sa8, sb8)
+    st, _ = _ws_call(lib, L, dev2, M, N, K, base | L.WS_WEIGHT_CACHED, ws, need)
+    assert st == L.ERR_INVALID_ARG, lib.atom_strerror(st).decode()
+    ws.zero_()
+    st, _ = _ws_call(lib, L, dev, M, N, K, base | L.WS_WEIGHT_CACHED, ws, need)
+    assert st == L.ERR_INVALID_ARG, lib.atom_strerror(st).decode()
+    st, d2 = _ws_call(lib, L, dev, M, N, K, base, ws, need)                # no assertion: both operands re-coded, right answer
+    L.check(st, "no assertion")
+    assert torch.equal(d2, d_ok)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 256, 256), (1, 4096, 4096), (1, 11008, 4096), (1, 1024, 11008), (1, 13824, 5120), (1, 640, 13824),
                                    (1, 8256, 640), (1, 8320, 384), (2, 1024, 11008), (2, 13824, 5120), (2, 640, 13824), (2, 8320, 4224)])
 @pytest.mark.parametrize("layout", ["plain", "ref"])
