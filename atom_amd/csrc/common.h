@@ -119,6 +119,8 @@ int launch_gemm_skinny_o4(const GemmParams &p, hipStream_t s);     // ... + the 
 int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmented outputs (p.seg_*): q/k/v, gate/up, down + residual
 bool skinny_q_fits(int q_op, int64_t M, int64_t K_total);             // ... the shapes its quantiser-in-front variant takes
 int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s);   // ... + the preceding quantiser inside the launch (p.q_*)
+bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t K_total);     // gemvq_w4a4.hip: one or two tokens, the quantiser in front of the dot-product kernel
+int launch_gemvq_multi_q(const GemmParams &p, hipStream_t s);         // ... (p.q_*, p.seg_*): one quantiser per CU, gemv1's summation order
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 int launch_gemm_f6_mid(const GemmParams &p, hipStream_t s);        // gemm_w4a4_mid.hip: the same for BF6 operands (ATOM_AB_F6 | ATOM_B_F6S)
 int launch_gemm_mid(const GemmParams &p, hipStream_t s);           // gemm_w4a4_mid.hip (packed operands, mid-size batches: 64x64 tiles, deep LDS ring)

@@ -31,13 +31,17 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 static int gemv_max_m() { return ATOM_TUNE("ATOM_GEMV_MAXM", 7); }
 // Up to this many tokens EVERY GEMM entry point (fp16, FP32 sums, segmented) runs the few-token dot-product kernel (gemv_w4a4.hip
 // gemv1_w4a4_kernel: the weights streamed once at full occupancy, each token's sum in the one-token kernel's order); above it the
-// MFMA decode-batch kernel.  One token always; two tokens where K is long (measured cold, us, dot-product | decode-batch kernel:
+// MFMA decode-batch kernel.  One or two tokens -- round 6: two tokens at every K (rounds 4-5: where K is long), so that a decode step
+// of two tokens runs its projections with the quantisers in front of this kernel (gemvq_w4a4.hip; the decode-batch kernel behind a
+// quantiser runs a Llama-7B layer at batch 2 in 77 us, this one in 6x us: profiles/r06/) at the price of 0.2 us where a lone
+// 2 x 4096 x 4096 GEMM is called (measured cold, us, dot-product | decode-batch kernel:
 // 2 x 5120 x 13824 12.5 | 17.5, 2 x 4096 x 11008 8.0 | 8.6, 2 x 5120 x 5120 6.6 | 7.0, 2 x 4096 x 4096 4.6 | 4.4; from three tokens
 // the per-token VALU work loses everywhere: 3 x 13824 x 5120 13.9 | 11.7; profiles/r04/decode_small_m.txt).  The rule depends on
 // (M, K) only, so the projections that share an activation take the same kernel through every entry point.
 static int gemv_tokens(int64_t K_total) {
   const int forced = ATOM_TUNE("ATOM_GEMV_TOKENS", 0);       // (tuning builds)
-  const int t = forced > 0 ? forced : (K_total > 4096 ? 2 : 1);
+  const int t = forced > 0 ? forced : 2;                     // (rounds 4-5: two tokens only where K > 4096)
+  (void)K_total;
   return t > kGemvMaxTokens ? kGemvMaxTokens : t;
 }
 
@@ -457,7 +461,15 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
   return launch_gemm_skinny_multi(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+// one or two tokens (the token counts of gemv_tokens(): the projections take the dot-product kernel through every entry point): the
+// quantiser in front of THAT kernel, once per CU (gemvq_w4a4.hip, round 6); otherwise in front of the decode-batch kernel
+static bool multi_q_dot(int q_op, int64_t M, int64_t N, int64_t K_total) {
+  return ATOM_TUNE("ATOM_GEMVQ", 1) && M <= gemv_tokens(K_total) && gemvq_fits(q_op, M, N, K_total);
+}
+
 int atom_gemm_w4a4_multi_q_fits(int q_op, int64_t M, int64_t N_seg, int nseg, int64_t K_total) {
+  if (M < 1 || nseg < 1 || nseg > 3 || N_seg < 16 || (N_seg % 16) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  if (multi_q_dot(q_op, M, N_seg * nseg, K_total)) return atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total);
   if (!skinny_q_fits(q_op, M, K_total)) return 0;                    // the launcher's own predicate (gemm_w4a4_skinny.hip)
   return atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total);
 }
@@ -493,6 +505,7 @@ int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *
   p.q_res = (const half_t *)residual; p.q_res_out = (half_t *)residual_out;
   p.q_idx = reorder_index;
   p.q_eps = eps; p.q_clip = clip;
+  if (multi_q_dot(q_op, M, N_seg * nseg, K_total)) return launch_gemvq_multi_q(p, reinterpret_cast<hipStream_t>(stream));
   return launch_gemm_skinny_multi_q(p, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -1330,12 +1330,34 @@ struct QC {
   static_assert(LDS_BYTES <= 160 * 1024 && STAGE + (32 * 3 + 1) * PITCH + 100 < 65536, "q kernel: stage layout / ds offsets");
 };
 
+// A token scale in registers.  It arrives as the 8-byte pair at byte 96 of the row's record (fp16 copy, fp32 copy; q_scale below) and
+// only the upper dword is used -- but the pair stays ONE live value until its first use: the register allocator otherwise hands the
+// dead lower half to the very next temporary, and the write-after-write on a register with a load in flight costs a full
+// `s_waitcnt lgkmcnt(0)` behind every scale read (48 of them in the K loop instead of 11; seen in the disassembly, round 6).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+#ifdef ATOM_SA_B32
+struct QSa {
+  float v;
+  __device__ __forceinline__ QSa() = default;
+  __device__ __forceinline__ QSa(float f) : v(f) {}
+  __device__ __forceinline__ operator float() const { return v; }
+};
+#else
+struct QSa {
+  v2f_t p;
+  __device__ __forceinline__ QSa() = default;
+  __device__ __forceinline__ QSa(float f) : p{0.f, f} {}
+  __device__ __forceinline__ QSa(v2f_t q) : p(q) {}
+  __device__ __forceinline__ operator float() const { asm volatile("" ::"v"(p)); return p.y; }
+};
+#endif
+
 template <class C, bool PAIR = false>
 struct QRegs {
   v8i af[4];            // feature fragments of the current stage
   v8i bf[3];            // token fragments: [2] block 0, [0] blocks 2,4,6, [1] odd blocks
   float sb[2][PAIR ? 4 : 8];   // weight scales of feature-block pair h: [h][2 r + (fb & 1)]; PAIR (channels 2 j, 2 j + 1 share theirs): [h][r]
-  float sa[4];          // token scales, ring by token block % 4
+  QSa sa[4];            // token scales, ring by token block % 4
   v4f_t acc[2][2];
   // lane byte addresses in LDS, [set][piece]: set 0 serves stage slots 0 and 1 (+ instruction offset), set 1 = + 2 stages for
   // slot 2.  All opaque to the compiler: it would otherwise re-derive one from another with a v_add per use, or merge two 8-byte
@@ -1363,12 +1385,13 @@ __device__ __forceinline__ v8i q_frag(const char *lds, const int (&a)[2][3], int
 // 64 a ds_read_b64 sees (52 l mod 64: 16 distinct values) at the same two LDS cycles per instruction.  -DATOM_SA_B32: the round-5 read
 // (A/B builds, tools/ab_build.sh).
 template <class C, int SL, class RG>
-__device__ __forceinline__ float q_scale(const char *lds, const RG &R, int off, int ro) {
+__device__ __forceinline__ QSa q_scale(const char *lds, const RG &R, int off, int ro) {
 #ifdef ATOM_SA_B32
   return *reinterpret_cast<const float *>(lds + (SL < 0 ? ro : q_imm<C, SL>()) + off + R.aS[q_set<SL>()] + 4);
 #else
-  const v2u w = *reinterpret_cast<const v2u *>(lds + (SL < 0 ? ro : q_imm<C, SL>()) + off + R.aS[q_set<SL>()]);
-  return __builtin_bit_cast(float, w.y);
+  // (a float pair, NOT `bit_cast<float>(v2u.y)`: hipcc of ROCm 7.2 folds the latter to element 0 -- load <2 x float>, extractelement 0 --
+  // i.e. the fp16 copy read as a float; found by tests/test_gpu_block.py, kept out by tests/test_abi_cpu.py's disassembly check)
+  return QSa(*reinterpret_cast<const v2f_t *>(lds + (SL < 0 ? ro : q_imm<C, SL>()) + off + R.aS[q_set<SL>()]));
 #endif
 }
 template <class C, int SL, class RG>
@@ -1896,7 +1919,8 @@ __device__ __forceinline__ void qk_piece(const QkDma &d, const uint8_t *wsrc, co
 template <class C>
 struct QkRegs {
   v8i af[4], bf[4];
-  float sb[2][8], sa[4];
+  float sb[2][8];
+  QSa sa[4];
   v4f_t acc[2][2];
   int aW[2][3], aA[2][3], aS[2], aB[2];       // as QRegs
 };

@@ -66,7 +66,7 @@ constexpr int kQLdsMax = 96 * 1024;
 // (ops 1-3) the fp16 rows of up to two tokens + the norm weights
 inline size_t q_lds_bytes(int q_op, int K4h, int G) {
   const int H = 2 * K4h + kKeeper;
-  return (size_t)kQWaves * 64 * 16 + q_red_offset(K4h, G) + 32 + (q_op <= 3 ? (size_t)H * 2 * 3 : 0);
+  return (size_t)2 * kQWaves * 64 * 16 + q_red_offset(K4h, G) + 32 + (q_op <= 3 ? (size_t)H * 2 * 3 : 0);
 }
 
 // NW waves per workgroup, MBLK token blocks of 16, CNT = register slots for the wave's items (>= ceil((G + 1) / NW))
@@ -88,15 +88,25 @@ inline size_t q_lds_bytes(int q_op, int K4h, int G) {
 template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false, int QOP = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p) {
   constexpr bool OUT32 = OUT == 1;
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4]; QOP: + the quantiser's buffers
-  float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw);
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // float part[NW][MBLK][64][4] (QOP: two of them); QOP: + the quantiser's buffers
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row = lane & 15, kb = lane >> 4;
   // XCD-aware feature map (round 4, as in gemv_w4a4.hip): workgroup b runs on XCD b % 8; a 64-byte line of weight scales holds 32
   // adjacent features of one group = two workgroups' worth -- dealt round-robin they sit in two L2s.  Bijective for any grid size.
   const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
-  const int n0 = (xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3)) * 16;
+  const int lw = xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3);      // workgroups in XCD-contiguous order
+  // QOP (round 6): the grid may be SMALLER than the N / 16 feature blocks -- workgroup lw then owns the consecutive blocks
+  // [lw NB / grid, (lw + 1) NB / grid) and runs its quantiser ONCE in front of all of them (one workgroup per block repeated it 768 times
+  // for q / k / v, 1,376 times for gate / up: ~1 us of a CU's issue time each, which is what made those fusions lose in rounds 3-5);
+  // the weight registers of block b + 1 are re-filled in place as block b consumes them.
+  // (LOOP: instances of up to 8 register slots per wave -- K <= 8,064; the 14-slot instance has no registers to spare for the
+  // refills and keeps one workgroup per block: launch_q1 sizes its grid accordingly)
+  constexpr bool LOOP = QOP != 0 && CNT <= 8;
+  const int NBLK = p.N >> 4;
+  const int blk0 = LOOP ? (int)((int64_t)lw * NBLK / (int)gridDim.x) : lw;
+  const int blk1 = LOOP ? (int)((int64_t)(lw + 1) * NBLK / (int)gridDim.x) : lw + 1;
+  int n0 = blk0 * 16;
   const int K4h = p.K4h, G = p.G;
 
   // this wave's items: int4 groups [i0, min(i1, G)), and the keeper if i1 == G + 1
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       if constexpr (QOP >= 2) asm volatile("" : "+v"(q_wr[0]), "+v"(q_wr[1]));
     }
   }
-  char *qbase = lds_raw + (size_t)NW * MBLK * 64 * 16;      // behind the partial-sum area
+  char *qbase = lds_raw + (size_t)(QOP != 0 ? 2 : 1) * NW * MBLK * 64 * 16;      // behind the partial-sum area(s)
   uint8_t *qa4 = reinterpret_cast<uint8_t *>(qbase);                                     // [MQ][K4h]
   uint8_t *qa8 = qa4 + MQ * K4h;                                                        // [MQ][128]
   half_t *qsa = reinterpret_cast<half_t *>(qa8 + MQ * kKeeper);                         // [G][MQ]
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
           h8 v = q_xr[i];
           if constexpr (QOP == 3) {
             v = v + q_rr[i];
-            if (n0 == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
+            if (lw == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
           }
           *reinterpret_cast<h8 *>(rowbuf + m * H * 2 + cc * 16) = v;
         }
@@ -330,9 +340,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
     asm volatile("" : "+v"(raw));
     return (float)__builtin_bit_cast(half_t, (unsigned short)raw);
   };
+  if constexpr (QOP == 0) {
 #pragma unroll
-  for (int j = 0; j < CNT; ++j)
-    if (j < ng) { load_act(0, j); load_sa(0, j); }
+    for (int j = 0; j < CNT; ++j)
+      if (j < ng) { load_act(0, j); load_sa(0, j); }
+  }
   v4u ak[2] = {};
   unsigned sak = 0;
   auto load_keeper_act = [&](int tb) {
@@ -348,8 +360,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
     ak[1] = *reinterpret_cast<const v4u *>(kp + 64);
     sak = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(p.sA8) + soff[tb]);
   };
-  if (keeper) load_keeper_act(0);
+  if constexpr (QOP == 0) {
+    if (keeper) load_keeper_act(0);
+  }
 
+  for (int blk = blk0; blk < blk1; ++blk, n0 += 16) {       // (one block unless QOP)
+  const bool more = LOOP && blk + 1 < blk1;                 // workgroup-uniform: the next block's weights are requested in place
+  if constexpr (QOP != 0) {
+    // the token rows' packed operand is read out of LDS again for every block: kept in registers across the block loop it would
+    // hold 4 CNT + CNT of them for the whole kernel (the 14-slot instance then spills 50 registers)
+#pragma unroll
+    for (int j = 0; j < CNT; ++j)
+      if (j < ng) { load_act(0, j); load_sa(0, j); }
+    if (keeper) load_keeper_act(0);
+  }
+  float (*part)[MBLK][64][4] = reinterpret_cast<float (*)[MBLK][64][4]>(lds_raw + (size_t)(QOP != 0 ? ((blk - blk0) & 1) : 0) * NW * MBLK * 64 * 16);
   float c[MBLK][4];
 #pragma unroll
   for (int tb = 0; tb < MBLK; ++tb)
@@ -365,10 +390,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
         const v4i be = even_codes(a[j]), bo = odd_codes(a[j]);
         if (tb + 1 < MBLK) load_act(tb + 1, j);            // in place: the next block's chunk is on its way during this block
         const v4i ae = even_codes(w[j]), ao = odd_codes(w[j]);
+        if constexpr (LOOP) {
+          if (more) {                                      // the next feature block: 16 rows further
+            const v4u *wp = reinterpret_cast<const v4u *>(wbase + (int64_t)(blk + 1 - blk0) * 16 * K4h + j * 64 + woff);
+            w[j] = NT ? __builtin_nontemporal_load(wp) : *wp;
+          }
+        }
         v4i acc = {0, 0, 0, 0};
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, be, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bo, acc, 0, 0, 0);
         dequant4(acc, opaque_half(sa[j]) * (1.0f / 256.0f), sb[j], c[tb]);
+        if constexpr (LOOP) {
+          if (more) sb[j] = *reinterpret_cast<const v2u *>(sbbase + (int64_t)(blk + 1 - blk0) * 32 + (int64_t)j * p.N * 2 + 8 * kb);
+        }
         if (tb + 1 < MBLK) load_sa(tb + 1, j);
       }
     }
@@ -379,11 +413,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       for (int hlf = 0; hlf < 2; ++hlf)
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(v4i, wk[hlf]), __builtin_bit_cast(v4i, ak[hlf]), acc, 0, 0, 0);
       dequant4(acc, sa8, sbk, c[tb]);
+      if constexpr (LOOP) {
+        if (more) {
+          const char *kp = reinterpret_cast<const char *>(p.B8) + (int64_t)(n0 + 16) * kKeeper + (unsigned)(row * kKeeper + kb * 16);
+          wk[0] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp)) : *reinterpret_cast<const v4u *>(kp);
+          wk[1] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(kp + 64)) : *reinterpret_cast<const v4u *>(kp + 64);
+          sbk = *reinterpret_cast<const v2u *>(reinterpret_cast<const char *>(p.sB8 + n0 + 16) + 8 * kb);
+        }
+      }
       if (tb + 1 < MBLK) load_keeper_act(tb + 1);
     }
   }
 
-  // ---- partial sums of the NW waves, added in wave order
+  // ---- partial sums of the NW waves, added in wave order (QOP: two areas in alternation -- wave 0 may still be adding block b's
+  // when the other waves write block b + 1's; it has passed this barrier again before anybody writes block b + 2's)
 #pragma unroll
   for (int tb = 0; tb < MBLK; ++tb)
     *reinterpret_cast<v4f *>(&part[wave][tb][lane][0]) = v4f{c[tb][0], c[tb][1], c[tb][2], c[tb][3]};
@@ -426,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_skinny_kernel(GemmParams p)
       *reinterpret_cast<v2u *>(p.D + (int64_t)m * p.N + n0 + 4 * kb) = o;
     }
   }
+  }   // feature blocks of this workgroup
 }
 
 template <int NW, int MBLK, int CNT, int OUT = 0, bool NT = false>
@@ -449,7 +493,10 @@ static int launch_q1(const GemmParams &p, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), kQLdsMax, attr_done) != ATOM_OK)
     return ATOM_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), dim3((unsigned)(p.N / 16)), dim3(NW * 64), lds, s, p);
+  // one workgroup per CU at most, each with the consecutive feature blocks of its share (round 6: one quantiser per workgroup,
+  // not per block; N = 4096 keeps its 256 single-block workgroups)
+  const int nblk = p.N / 16, cap = CNT <= 8 ? ATOM_TUNE("ATOM_SKINNY_Q_GRID", 256) : nblk;   // (the kernel's LOOP)
+  hipLaunchKernelGGL((gemm_w4a4_skinny_kernel<NW, 1, CNT, OUT, true, QOP>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NW * 64), lds, s, p);
   return check_launch();
 }
 template <int NW, int CNT, int OUT>

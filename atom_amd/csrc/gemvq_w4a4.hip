@@ -1,0 +1,413 @@
+// W4A4 GEMM, one or two tokens of a decode step, with the quantiser that feeds it INSIDE the launch (round 6).
+//
+// A decode layer at batch 1 is four (quantiser -> projection) pairs around the attention (reference call order
+// e2e/punica-atom/punica/models/llama.py:259-292, :85-87): RMSNorm -> q / k / v, reorder -> o_proj, residual add + RMSNorm -> gate / up,
+// SiLU x up -> down_proj.  As separate launches each quantiser costs 4.4-4.5 us of a 60 us layer for ONE row of work (a chain of cold
+// dependent loads on a single workgroup, then a launch boundary); inside the decode-batch kernel (gemm_w4a4_skinny.hip, rounds 3-5) every
+// one of its N / 16 workgroups repeated the quantiser and its one-block-deep weight prefetch ran the large projections at 1.8 TB/s
+// (profiles/r06/decode_prof_*.txt: gate / up 24.8 us fused against 4.5 + 11.1 separate).  This kernel is the dot-product kernel
+// (gemv_w4a4.hip gemv1_w4a4_kernel: one wave per output feature, lanes along K, v_dot8_i32_i4 on the packed dwords) restructured so
+// that the quantiser runs ONCE PER CU:
+//   * grid = one workgroup of 16 waves per CU (at most); a workgroup owns a contiguous range of the output features (XCD-contiguous:
+//     a 64-byte line of weight scales serves 32 adjacent features), wave w of it the features w, w + 16, ... of that range;
+//   * every wave requests the weight chunks of its FIRST TWO features before anything else, then the workgroup runs the quantiser
+//     (1024 threads: every load of the token rows, norm weights and reorder indices is issued in one batch, three LDS barriers) and
+//     leaves the packed operand -- INT4 codes, INT8 keeper, fp16 scales: the bytes the stand-alone quantiser kernels write -- in LDS;
+//   * the feature loop keeps two features' weights in flight per wave (32 waves x 2-8 KiB per CU), reads the token's codes out of LDS
+//     (one ds_read_b128 per weight chunk) and forms every sum exactly as gemv1_w4a4_kernel does: lane l owns chunks l, l + 64, ... in
+//     ascending order, a quad sums a group exactly, the quad leader applies c = fma(idot, sA * sB, c), 64-lane butterfly, keeper last.
+// Output: bit-identical to the stand-alone quantiser launch followed by atom_gemm_w4a4_multi (which runs gemv1_w4a4_kernel for these
+// token counts) -- atom_gemm_w4a4_packed_order() = 64 on both sides.
+// Quantiser arithmetic: the kernel-flavoured mode of quant_kernels.hip slot by slot (Reorder.cuh:137-178, RMSNorm.cuh:112-151,
+// Activate.cuh:112-167), the sum of squares as the same fixed-shape FP32 tree (256 threads per row).
+#include "common.h"
+#include "quant_math.h"
+
+namespace atom {
+namespace gemvq {
+
+constexpr int NTH = 1024, NWV = NTH / 64;
+constexpr int MQ = 2;                     // token rows at most
+constexpr int TPT = 2, XC = 2;            // slot tasks (16 channels) / 16-byte row chunks per thread at most (gemvq_fits)
+
+__device__ __forceinline__ int quad_sum(int d) {
+  d += __builtin_amdgcn_mov_dpp(d, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  d += __builtin_amdgcn_mov_dpp(d, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  return d;
+}
+
+// LDS: the packed operand [MQ][K4h] codes, [MQ][128] keeper, [G][MQ] + [MQ] fp16 scales; then (16-byte aligned) the reduction scratch,
+// and for ops 1-3 the fp16 rows [MQ][H] and the norm weights [H]
+__host__ __device__ inline int red_offset(int K4h, int G) { return (MQ * K4h + MQ * kKeeper + MQ * G * 2 + MQ * 2 + 15) & ~15; }
+__host__ __device__ inline int sb_offset(int q_op, int K4h, int G) {      // the staged weight scales: behind everything the quantiser uses
+  const int H = 2 * K4h + kKeeper;
+  return red_offset(K4h, G) + 32 + (q_op <= 3 ? H * 2 * (MQ + 1) : 0);
+}
+inline size_t lds_bytes(int q_op, int K4h, int G, int nf_max) { return (size_t)sb_offset(q_op, K4h, G) + (size_t)(G + 1) * (nf_max | 1) * 2 + 16; }
+
+// One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 4 chunks per lane, a half or a quarter of
+// one beyond: with 16 waves per workgroup a wave has 128 registers).  The ring below holds D steps.
+template <int PCH>
+struct PartW {
+  v4i w[PCH];              // chunks lane + 64 (part PCH + k), clamped to the row's last one
+};
+
+// (`w8`: the keeper chunk lane % 8 of the feature, requested with its last part -- `last` is a constant once the loops are unrolled)
+template <int PCH>
+__device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, bool last, int lane, int nchunks, PartW<PCH> &f, v4i &w8) {
+  const uint8_t *brow = p.B4 + (int64_t)n * p.K4h;
+#pragma unroll
+  for (int c = 0; c < PCH; ++c) {
+    const int cc = min(lane + 64 * (part * PCH + c), nchunks - 1);
+    f.w[c] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(brow + cc * 16));   // nt: read once, by this CU only
+  }
+  if (last) w8 = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
+}
+
+// Weight scales of a workgroup's features, staged ONCE in LDS as [G + 1][nfs] fp16 (row G: the keeper's): read per feature from memory
+// (gemv1_w4a4_kernel) a wave issues one 2-byte gather over 16 cache lines for every 1 KiB of weights -- as many line requests as the
+// weight stream itself; staged, a row segment of the [G][N] array is a few contiguous lines for the whole workgroup.
+constexpr int SBT = 4;                    // staging loads per thread at most (gemvq_fits)
+__host__ __device__ inline int sb_stride(int nf) { return nf | 1; }   // halves; odd: the 16 groups of a wave's read fall into distinct banks
+
+// QOP: 1 reorder, 2 RMSNorm + reorder, 3 residual add + RMSNorm + reorder, 4 SiLU(x) * x2.  NCH: 16-byte weight chunks per lane
+// (>= ceil(K4 / 2048)).  MT: token rows.
+template <int QOP, int NCH, int MT>
+__global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K4h = p.K4h, G = p.G;
+  const int H = 2 * K4h + kKeeper;
+  const int nchunks = K4h >> 4;
+  // workgroup b runs on XCD b % 8: XCD-contiguous order, then a contiguous share of the features
+  const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
+  const int lw = xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3);
+  const int f0 = (int)((int64_t)lw * p.N / (int)gridDim.x), f1 = (int)((int64_t)(lw + 1) * p.N / (int)gridDim.x);
+
+  // ---- everything the quantiser reads, requested first (one memory round trip for the whole prologue)
+  const int q_nchunks = H >> 3, q_nslots = H >> 4;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  v4u q_ri[TPT][2], q_rb[QOP == 4 ? TPT : 1][2];
+  h8 q_xr[QOP <= 3 ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[QOP == 2 || QOP == 3 ? XC : 1];
+  {
+    const int ntask = p.M * q_nslots;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      const int task = min(tid + t * NTH, ntask - 1), m = task / q_nslots, e0 = (task - m * q_nslots) * 16;
+      if constexpr (QOP == 4) {
+        const half_t *arow = p.q_x + (int64_t)m * H, *brow = p.q_x2 + (int64_t)m * H;
+        q_ri[t][0] = *reinterpret_cast<const v4u *>(arow + e0);
+        q_ri[t][1] = *reinterpret_cast<const v4u *>(arow + e0 + 8);
+        q_rb[t][0] = *reinterpret_cast<const v4u *>(brow + e0);
+        q_rb[t][1] = *reinterpret_cast<const v4u *>(brow + e0 + 8);
+      } else {
+        const int16_t *ip = p.q_idx ? p.q_idx + e0 : reinterpret_cast<const int16_t *>(p.q_x);   // (no index: any readable address)
+        q_ri[t][0] = *reinterpret_cast<const v4u *>(ip);
+        q_ri[t][1] = *reinterpret_cast<const v4u *>(ip + 8);
+      }
+    }
+    if constexpr (QOP <= 3) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        const int c = min(tid + i * NTH, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+        q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
+        if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
+      }
+      if constexpr (QOP >= 2) {
+#pragma unroll
+        for (int i = 0; i < XC; ++i)
+          q_wr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x2) + min(tid + i * NTH, q_nchunks - 1) * 16);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (the requests above are issued before the weight loads below)
+
+  // ---- the weights of this wave's first D steps (NCH <= 4: its first D features): in flight while the quantiser runs
+  constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1), PCH = NCH / PARTS;
+  constexpr int D = 4;                                            // ring slots; the unrolled loop below needs PARTS | D
+  static_assert(PCH * PARTS == NCH && D % PARTS == 0, "chunks per lane: 1, 2, 4, 6 or 8");
+  PartW<PCH> ring[D];
+  v4i ring8[D / PARTS];                                           // the keeper chunks of the features in the ring
+  const int n0w = f0 + wave;
+  const int nfeat = n0w < f1 ? (f1 - n0w + NWV - 1) / NWV : 0;    // features of this wave
+  const int nsteps = nfeat * PARTS;
+#pragma unroll
+  for (int u = 0; u < D; ++u) {                                   // (a wave with fewer steps re-reads its last one / a valid row: L2)
+    const int st = min(u, max(nsteps - 1, 0));
+    load_part<PCH>(p, min(n0w + (st / PARTS) * NWV, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS]);
+  }
+  // ... and the workgroup's weight scales (staged in LDS below)
+  const int nf = f1 - f0, nfs = sb_stride(nf);
+  unsigned short sbt[SBT];
+#pragma unroll
+  for (int i = 0; i < SBT; ++i) {
+    const int e = min(tid + i * NTH, (G + 1) * nf - 1), g = e / nf, j = e - g * nf;
+    sbt[i] = g < G ? reinterpret_cast<const unsigned short *>(p.sB)[(int64_t)g * p.N + f0 + j]
+                   : reinterpret_cast<const unsigned short *>(p.sB8)[f0 + j];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // nothing of the quantiser moves up between the loads above, and none of its requests sinks into a branch below
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) {
+    asm volatile("" : "+v"(q_ri[t][0]), "+v"(q_ri[t][1]));
+    if constexpr (QOP == 4) asm volatile("" : "+v"(q_rb[t][0]), "+v"(q_rb[t][1]));
+  }
+  if constexpr (QOP <= 3) {
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      asm volatile("" : "+v"(q_xr[i]));
+      if constexpr (QOP == 3) asm volatile("" : "+v"(q_rr[i]));
+      if constexpr (QOP >= 2) asm volatile("" : "+v"(q_wr[i]));
+    }
+  }
+
+  unsigned short *lsb = reinterpret_cast<unsigned short *>(lds + sb_offset(QOP, K4h, G));   // [G + 1][nfs]
+#pragma unroll
+  for (int i = 0; i < SBT; ++i) {
+    const int e = tid + i * NTH;
+    if (e < (G + 1) * nf) {
+      const int g = e / nf, j = e - g * nf;
+      lsb[g * nfs + j] = sbt[i];                              // (published by the quantiser's barriers below)
+    }
+  }
+  // ---- the quantiser: the token rows' packed operand, built in LDS (its barriers wait for LDS only)
+  uint8_t *qa4 = reinterpret_cast<uint8_t *>(lds);                                        // [MQ][K4h]
+  uint8_t *qa8 = qa4 + MQ * K4h;                                                          // [MQ][128]
+  half_t *qsa = reinterpret_cast<half_t *>(qa8 + MQ * kKeeper);                           // [G][MQ]
+  half_t *qsa8 = qsa + (size_t)G * MQ;                                                    // [MQ]
+  {
+    auto lds_barrier = [] {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    float *red = reinterpret_cast<float *>(lds + red_offset(K4h, G));                     // [MQ][4] partial sums of squares
+    char *rowbuf = reinterpret_cast<char *>(red + 8);                                     // [MQ][H] halves, then the norm weights [H]
+    char *wbuf = rowbuf + MQ * H * 2;
+    const int nslots = q_nslots, Gt = H >> 7;
+    const int ntask = p.M * nslots;                          // slot tasks: (row, slot), 16 channels each
+    if constexpr (QOP <= 3) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
+        const int c = tid + i * NTH;                         // the first workgroup writes the residual stream)
+        if (c < p.M * q_nchunks) {
+          const int m = c / q_nchunks, cc = c - m * q_nchunks;
+          h8 v = q_xr[i];
+          if constexpr (QOP == 3) {
+            v = v + q_rr[i];
+            if (lw == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
+          }
+          *reinterpret_cast<h8 *>(rowbuf + m * H * 2 + cc * 16) = v;
+        }
+      }
+      if constexpr (QOP >= 2) {
+#pragma unroll
+        for (int i = 0; i < XC; ++i)
+          if (tid + i * NTH < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NTH) * 16) = q_wr[i];
+      }
+      lds_barrier();
+    }
+    float rinv[MQ] = {0.f, 0.f};
+    if constexpr (QOP == 2 || QOP == 3) {
+      const int m = tid >> 8, t8 = tid & 255;               // the stand-alone kernel's 4-wave tree, one per row
+      if (m < p.M) {
+        float ss = 0.f;
+        for (int c = t8; c < q_nchunks; c += 256) {          // chunk (i * 4 + wave) * 64 + lane, i ascending
+          const h8 v = *reinterpret_cast<const h8 *>(rowbuf + m * H * 2 + c * 16);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)v[k], (float)v[k], ss);
+        }
+        ss = wave_sum_butterfly(ss);
+        if (lane == 0) red[m * 4 + (wave & 3)] = ss;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int m2 = 0; m2 < MQ; ++m2) {
+        const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
+        const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
+        rinv[m2] = rinv_sqrt_exact(var + p.q_eps);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      const int task = tid + t * NTH;
+      if (task < ntask) {                                    // (ntask is a multiple of 8: whole octets for max8)
+        const int m = task / nslots, slot = task - m * nslots;
+        const int e0 = slot * 16, g = slot >> 3, j = slot & 7;
+        const bool keeper = g == Gt - 1;
+        float v[16];
+        if constexpr (QOP == 4) {
+          const half_t *av = reinterpret_cast<const half_t *>(q_ri[t]), *bv = reinterpret_cast<const half_t *>(q_rb[t]);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = silu_mul<false>((float)av[k], (float)bv[k]);
+        } else {
+          const uint16_t *iv = reinterpret_cast<const uint16_t *>(q_ri[t]);
+          const float rv = m == 0 ? rinv[0] : rinv[1];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int off = p.q_idx ? (int)iv[k] : e0 + k;
+            const half_t xh = *reinterpret_cast<const half_t *>(rowbuf + m * H * 2 + off * 2);
+            if constexpr (QOP >= 2) {
+              const half_t wg = *reinterpret_cast<const half_t *>(wbuf + off * 2);
+              v[k] = (float)(half_t)(((float)xh * (float)wg) * rv);                    // RMSNorm.cuh:145-151
+            } else {
+              v[k] = (float)xh;
+            }
+          }
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+        amax = max8(amax);
+        const GroupScale gs = group_scale<false>(amax, keeper, p.q_clip);
+        float tr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tr[i] = group_code<false>(v[i], gs);
+        const v4u w = pack_codes16(tr, keeper);
+        if (keeper) *reinterpret_cast<v4u *>(qa8 + m * kKeeper + j * 16) = w;
+        else *reinterpret_cast<v2u *>(qa4 + m * K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
+        if (j == 0) {
+          if (keeper) qsa8[m] = f2h(gs.s_store);
+          else qsa[g * MQ + m] = f2h(gs.s_store);
+        }
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- the feature loop: gemv1_w4a4_kernel's arithmetic, feature by feature.  Step s = (feature s / PARTS, part s % PARTS) sits in
+  // ring slot s % D; a slot is re-filled with step s + D as soon as step s is computed (D - 1 steps of weights in flight per wave, no
+  // register copies: the loop is unrolled by D, and PARTS | D keeps a feature's parts inside one trip)
+  const bool leader = (lane & 3) == 0;
+  for (int base = 0; base < nsteps; base += D) {
+    float acc[MT];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int part = u % PARTS;
+      const int fi = base / PARTS + u / PARTS;              // this wave's fi-th feature
+      if (base + u < nsteps) {                              // (wave-uniform)
+        const int n = n0w + fi * NWV, jf = n - f0;          // the feature, and its column in the staged scales
+        PartW<PCH> &f = ring[u];
+        if (part == 0) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) {
+          const int ch = lane + 64 * (part * PCH + c);
+          const bool ok = ch < nchunks;
+          const int cc = min(ch, nchunks - 1);
+          const float sbf = (float)__builtin_bit_cast(half_t, lsb[(cc >> 2) * nfs + jf]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int mr = min(m, p.M - 1);
+            const v4i a = *reinterpret_cast<const v4i *>(qa4 + mr * K4h + cc * 16);
+            const float saf = (float)qsa[(cc >> 2) * MQ + mr];
+            int d = 0;
+            d = __builtin_amdgcn_sdot8(a[0], f.w[c][0], d, false);
+            d = __builtin_amdgcn_sdot8(a[1], f.w[c][1], d, false);
+            d = __builtin_amdgcn_sdot8(a[2], f.w[c][2], d, false);
+            d = __builtin_amdgcn_sdot8(a[3], f.w[c][3], d, false);
+            d = quad_sum(d);                                    // exact: the group's 128-element integer dot
+            const float next = __builtin_fmaf((float)d, saf * sbf, acc[m]);   // exact scale product
+            acc[m] = (leader && ok) ? next : acc[m];
+          }
+        }
+        if (part == PARTS - 1) {
+          const float sb8f = (float)__builtin_bit_cast(half_t, lsb[G * nfs + jf]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int mr = min(m, p.M - 1);
+            const v4i a8 = *reinterpret_cast<const v4i *>(qa8 + mr * kKeeper + (lane & 7) * 16);
+            const float sa8f = (float)qsa8[mr];
+            int d = 0;
+            d = __builtin_amdgcn_sdot4(a8[0], ring8[u / PARTS][0], d, false);
+            d = __builtin_amdgcn_sdot4(a8[1], ring8[u / PARTS][1], d, false);
+            d = __builtin_amdgcn_sdot4(a8[2], ring8[u / PARTS][2], d, false);
+            d = __builtin_amdgcn_sdot4(a8[3], ring8[u / PARTS][3], d, false);
+            d = quad_sum(d);
+            d += __builtin_amdgcn_update_dpp(0, d, 0x104, 0xF, 0xF, true);   // row_shl:4 -- lane 0 += lane 4 (the other lanes' values are not used)
+            float s = acc[m];
+            s = wave_sum_butterfly(s);
+            if (lane == 0 && m < p.M) {
+              const float c = __builtin_fmaf((float)d, sa8f * sb8f, s);
+              const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
+              void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+              const int64_t at = (int64_t)m * p.seg_n + nl;
+              if ((p.seg_f32 >> seg) & 1u) {
+                reinterpret_cast<float *>(out)[at] = c;
+              } else {
+                half_t h = f2h(c);
+                if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[at]);   // fp16 + fp16 as torch adds halves
+                reinterpret_cast<half_t *>(out)[at] = h;
+              }
+            }
+          }
+        }
+        if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
+          load_part<PCH>(p, n + (D / PARTS) * NWV, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS]);
+      }
+    }
+  }
+}
+
+template <int QOP, int NCH, int MT>
+static int launch1(const GemmParams &p, hipStream_t s) {
+  const int cap0 = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
+  int grid0 = p.N / NWV;
+  if (grid0 > cap0) grid0 = cap0;
+  if (grid0 < 1) grid0 = 1;
+  const size_t lds = lds_bytes(QOP, p.K4h, p.G, (p.N + grid0 - 1) / grid0);
+  static std::atomic<uint64_t> attr_done{0};
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  const int grid = grid0;                                  // one workgroup per CU at most; every wave of it at least one feature
+  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT>), dim3((unsigned)grid), dim3(NTH), lds, s, p);
+  return check_launch();
+}
+
+template <int QOP, int MT>
+static int launch_nch(const GemmParams &p, hipStream_t s) {
+  const int need = ((p.K4h >> 4) + 63) / 64;
+  if (need <= 2) return launch1<QOP, 2, MT>(p, s);
+  if (need <= 4) return launch1<QOP, 4, MT>(p, s);
+  // (5 .. 8 chunks per lane run the 8-chunk instance -- four parts of two: its ring is 40 registers where three-chunk parts need 56 and
+  // spill; the chunks past the row's end are one clamped address per wave)
+  if (need <= 8) return launch1<QOP, 8, MT>(p, s);
+  return ATOM_ERR_SHAPE;
+}
+
+template <int QOP>
+static int launch_mt(const GemmParams &p, hipStream_t s) {
+  return p.M <= 1 ? launch_nch<QOP, 1>(p, s) : launch_nch<QOP, 2>(p, s);
+}
+
+}  // namespace gemvq
+
+// THE shape predicate of this launch (atom_gemm_w4a4_multi_q routes one or two tokens here when it holds): per thread of the 1024 at
+// most two slot tasks of 16 channels and two 16-byte chunks of the token rows / the norm weight, at most 8 weight chunks per lane
+// (K_total <= 16,512), everything within 128 KiB of LDS.
+bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t H) {
+  if (q_op < 1 || q_op > 4 || M < 1 || M > gemvq::MQ || H < 2 * kKeeper || ((H - kKeeper) % kGroup) != 0 || N < gemvq::NWV) return false;
+  if (M * (H >> 4) > gemvq::TPT * gemvq::NTH) return false;
+  if (q_op <= 3 && (M * (H >> 3) > gemvq::XC * gemvq::NTH || (H >> 3) > gemvq::XC * gemvq::NTH)) return false;
+  const int K4h = (int)((H - kKeeper) / 2), G = (int)((H - kKeeper) / kGroup);
+  const int need = ((K4h >> 4) + 63) / 64;                 // weight chunks per lane
+  if (need > 8) return false;
+  const int64_t grid = N / gemvq::NWV < 256 ? N / gemvq::NWV : 256, nf = (N + grid - 1) / grid;
+  if ((int64_t)(G + 1) * nf > (int64_t)gemvq::SBT * gemvq::NTH) return false;   // the staged weight scales: 4 loads per thread at most
+  return gemvq::lds_bytes(q_op, K4h, G, (int)nf) <= (size_t)128 * 1024;
+}
+
+int launch_gemvq_multi_q(const GemmParams &p, hipStream_t s) {
+  if (p.seg_n < 1 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3 || !p.seg_out[0]) return ATOM_ERR_SHAPE;
+  if (!gemvq_fits(p.q_op, p.M, p.N, 2 * (int64_t)p.K4h + kKeeper)) return ATOM_ERR_SHAPE;
+  switch (p.q_op) {
+    case 1: return gemvq::launch_mt<1>(p, s);
+    case 2: return gemvq::launch_mt<2>(p, s);
+    case 3: return gemvq::launch_mt<3>(p, s);
+    case 4: return gemvq::launch_mt<4>(p, s);
+  }
+  return ATOM_ERR_INVALID_ARG;
+}
+
+}  // namespace atom

@@ -100,20 +100,9 @@ struct QuantAppendParams {
 
 // Half a wave per (sequence, K / V, head) vector; the grid covers them all at once.  (Round 2 ran one workgroup per SEQUENCE that
 // walked its 2 N head vectors eight at a time: 5.6 us at batch 1 -- a chain of 8 dependent round trips on one CU.)
-__global__ __launch_bounds__(256) void kv_quant_append_kernel(QuantAppendParams p) {
-  const int l = threadIdx.x & 31;
-  const int P = p.kv.P, N = p.kv.N;
-  const int64_t vec = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);   // (b, kv, h)
-  if (vec >= (int64_t)p.kv.batch * 2 * N) return;
-  const int b = (int)(vec / (2 * N)), gi = (int)(vec % (2 * N));
-  const int kv = gi / N, h = gi % N;
-  const v4f x = *reinterpret_cast<const v4f *>((kv ? p.v : p.k) + ((int64_t)b * N + h) * kHeadDim + 4 * l);   // (independent of the page walk)
-  const int seq_len = (p.kv.indptr[b + 1] - p.kv.indptr[b] - 1) * P + p.kv.last_page_offset[b];
-  const int pos = seq_len - 1;
-  if (pos < 0) return;
-  const int64_t page = p.kv.indices[p.kv.indptr[b] + pos / P];
-  const int e = pos % P;
-  const int64_t base = (page * p.kv.L + p.kv.layer) * 2;             // [.., 2, N, P, ..]
+// the u4 epilogue on one 128-value head vector held by 32 lanes (4 values each; both halves of a wave at once): returns the lane's four
+// codes as 16 bits and the vector's (scale, zero) as a half2 bit pattern -- what the cache stores
+__device__ __forceinline__ unsigned short quant_head_u4(const v4f &x, unsigned &sz) {
   float lo = fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), hi = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
 #pragma unroll
   for (int k = 16; k >= 1; k >>= 1) {
@@ -131,13 +120,29 @@ __global__ __launch_bounds__(256) void kv_quant_append_kernel(QuantAppendParams 
     if (scale == 0.f) tr = 0.f;
     w |= (unsigned)(int)tr << (4 * k);
   }
+  sz = (unsigned)__builtin_bit_cast(unsigned short, f2h(scale)) | ((unsigned)__builtin_bit_cast(unsigned short, f2h(zero)) << 16);
+  return (unsigned short)w;
+}
+
+__global__ __launch_bounds__(256) void kv_quant_append_kernel(QuantAppendParams p) {
+  const int l = threadIdx.x & 31;
+  const int P = p.kv.P, N = p.kv.N;
+  const int64_t vec = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);   // (b, kv, h)
+  if (vec >= (int64_t)p.kv.batch * 2 * N) return;
+  const int b = (int)(vec / (2 * N)), gi = (int)(vec % (2 * N));
+  const int kv = gi / N, h = gi % N;
+  const v4f x = *reinterpret_cast<const v4f *>((kv ? p.v : p.k) + ((int64_t)b * N + h) * kHeadDim + 4 * l);   // (independent of the page walk)
+  const int seq_len = (p.kv.indptr[b + 1] - p.kv.indptr[b] - 1) * P + p.kv.last_page_offset[b];
+  const int pos = seq_len - 1;
+  if (pos < 0) return;
+  const int64_t page = p.kv.indices[p.kv.indptr[b] + pos / P];
+  const int e = pos % P;
+  const int64_t base = (page * p.kv.L + p.kv.layer) * 2;             // [.., 2, N, P, ..]
+  unsigned sz;
+  const unsigned short w = quant_head_u4(x, sz);
   const int64_t slot = ((base + kv) * N + h) * P + e;
-  *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = (unsigned short)w;
-  if (l == 0) {
-    half_t *d = p.kv.param + slot * 2;
-    d[0] = f2h(scale);
-    d[1] = f2h(zero);
-  }
+  *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = w;
+  if (l == 0) *reinterpret_cast<unsigned *>(p.kv.param + slot * 2) = sz;
 }
 
 // ------------------------------------------------------------------------------------------------ decode
@@ -148,7 +153,8 @@ struct DecodeParams {
   float *ws;            // splits > 1: [B, N, splits, 130] = o[128] (not normalised), m, d
   int splits;
   float sm_scale, log2_theta, rope_inv_scale;
-};
+  const float *k32, *v32;   // optional (atom_batch_decode_append_i4): the step's k / v projections as FP32 sums [B, N * 128] -- quantised and
+};                          // appended as the last token by the wave that attends to it
 
 // 8 packed u4 (nibble e at bits 4e) -> 4 half2 registers holding 1024 + nibble: m[k] = {1024 + n_k, 1024 + n_(k+4)}.
 // (x >> 4k) & 0x000F000F | 0x64006400 is one v_and_or_b32 (plus one shift for k > 0): 7 instructions per 8 elements,
@@ -234,6 +240,27 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     tb.lq = t * 2;
   }
   auto page_of = [&](int tile) { return ntiles > 0 ? (int64_t)p.kv.indices[pg0 + min(tile, ntiles - 1) / tpp] : (int64_t)0; };
+  // Fused append (round 6; p.k32 != NULL): this step's k / v of head h arrive as FP32 sums.  The ONE wave whose tile range holds the
+  // last token quantises them (lanes 0-31 K, 32-63 V: kv_quant_append_kernel's arithmetic), writes the cache slot, and hands the 64 + 64
+  // code bytes and the two (scale, zero) pairs to the lane of that token through LDS -- the attention below never waits for the store
+  // to come back from memory, and the step saves a launch.  Same cache bytes, same output as append -> decode.
+  __shared__ unsigned short stash_q[2][32];
+  __shared__ unsigned stash_sz[2];
+  const int last_tile = (seq_len - 1) >> 4;
+  const bool appends = p.k32 != nullptr && seq_len > 0 && last_tile >= tile0 && last_tile < tile1;   // wave-uniform
+  if (appends) {
+    const int kvh = lane >> 5, l = lane & 31;
+    const v4f x = *reinterpret_cast<const v4f *>((kvh ? p.v32 : p.k32) + ((int64_t)b * N + h) * kHeadDim + 4 * l);
+    unsigned sz;
+    const unsigned short w = quant_head_u4(x, sz);
+    const int pos = seq_len - 1;
+    const int64_t slot = ((((int64_t)p.kv.indices[pg0 + pos / P] * p.kv.L + p.kv.layer) * 2 + kvh) * N + h) * P + pos % P;
+    *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = w;
+    if (l == 0) *reinterpret_cast<unsigned *>(p.kv.param + slot * 2) = sz;
+    stash_q[kvh][l] = w;
+    if (l == 0) stash_sz[kvh] = sz;
+  }
+  __syncthreads();
   TileRegs cur, nxt;
   if (tile0 < tile1) cur = load_tile(tb, page_of(tile0), tile0 % tpp);
   if (tile0 + 1 < tile1) nxt = load_tile(tb, page_of(tile0 + 1), (tile0 + 1) % tpp);
@@ -271,11 +298,19 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   const float qk_scale = p.sm_scale * kLog2e;           // decode.cuh:500: softmax in base 2
 
   for (int tile = tile0; tile < tile1; ++tile) {
-    const TileRegs r = cur;
+    TileRegs r = cur;
     cur = nxt;
     if (tile + 2 < tile1) nxt = load_tile(tb, page2, (tile + 2) % tpp);
     page2 = page_of(tile + 3);
     const bool valid = tile * 16 + t < seq_len;
+    if (appends && tile == last_tile && t == ((seq_len - 1) & 15)) {   // my token is the one appended above: its bytes come from LDS
+      const char *sk = reinterpret_cast<const char *>(&stash_q[0][0]), *sv = reinterpret_cast<const char *>(&stash_q[1][0]);
+      r.k1 = *reinterpret_cast<const v2u *>(sk + 8 * u);
+      r.k2 = *reinterpret_cast<const v2u *>(sk + 32 + 8 * u);
+      r.v = *reinterpret_cast<const v4u *>(sv + 16 * u);
+      r.kq = stash_sz[0];
+      r.vq = stash_sz[1];
+    }
 
     // score = sum over my 16 pairs of (u1*ks - kz) * A1 + (u2*ks - kz) * A2 = ks * sum((1024+u) . A) - (kz + 1024 ks) * sum(A)
     float acc = 0.f, sumA = 0.f;
@@ -479,10 +514,10 @@ size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_s
   return s > 1 ? (size_t)batch * num_heads * s * (kHeadDim + 2) * sizeof(float) : 0;
 }
 
-int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,
-                         const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
-                         int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
-                         int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream) {
+static int batch_decode_impl(void *o, const void *q, const float *k32, const float *v32, void *kv_data, void *kv_param,
+                             const int32_t *kv_indptr, const int32_t *kv_indices, const int32_t *last_page_offset, int batch,
+                             int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta,
+                             float rope_scale, int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream) {
   const int st = check_kv(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
                           num_heads, page_size, head_dim);
   if (st != ATOM_OK) return st;
@@ -494,13 +529,32 @@ int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void
   DecodeParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
                   layer_idx, num_heads, page_size},
                  (const half_t *)q, (half_t *)o, (float *)workspace, splits,
-                 1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale};
+                 1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale, k32, v32};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(batch_decode_kernel, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
   if (splits > 1)
     hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace,
                        (half_t *)o, splits);
   return check_launch();
+}
+
+int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,
+                         const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
+                         int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
+                         int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream) {
+  return batch_decode_impl(o, q, nullptr, nullptr, const_cast<void *>(kv_data), const_cast<void *>(kv_param), kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
+                           num_heads, page_size, head_dim, rope_theta, rope_scale, max_pages_per_seq, workspace, workspace_bytes, stream);
+}
+
+int atom_batch_decode_append_i4(void *o, const void *q, const void *k_f32, const void *v_f32, void *kv_data, void *kv_param,
+                                const int32_t *kv_indptr, const int32_t *kv_indices, const int32_t *last_page_offset, int batch,
+                                int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta,
+                                float rope_scale, int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!k_f32 || !v_f32) return ATOM_ERR_INVALID_ARG;
+  if (!aligned16(k_f32) || !aligned16(v_f32)) return ATOM_ERR_ALIGN;
+  return batch_decode_impl(o, q, (const float *)k_f32, (const float *)v_f32, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset,
+                           batch, num_layers, layer_idx, num_heads, page_size, head_dim, rope_theta, rope_scale, max_pages_per_seq,
+                           workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

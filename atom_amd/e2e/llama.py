@@ -25,16 +25,18 @@ class DecodeFusion:
       decode     the projections that share an activation in ONE launch (q / k / v, gate / up), the residual add inside down_proj's
                  (False: one launch per projection, the reference's call order llama.py:259-292)
       kv_append  k / v quantised into the paged cache from the FP32 sums (False: the reference's op sequence _o4 GEMM -> append)
+      kv_in_decode  ... by the attention launch itself (atom_batch_decode_append_i4, round 6; False: a launch of its own in front)
       q_decode   one or two tokens: quantisers inside the GEMM that consumes them (atom_gemm_w4a4_multi_q)
       q_mask     ... which of the four (LlamaDecoderLayer._decode_fused_q): 1 input_layernorm -> q / k / v, 2 reorder -> o_proj,
-                 4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 2: every workgroup of the GEMM repeats
-                 the quantiser, which pays while the projection has one workgroup per CU (N = 4096: 6.4 -> 5.3 us for the pair; the
-                 decode layer 66.4 -> 64.9 us cold at batch 1) and loses once it has several rounds of them (q / k / v: 11.3 -> 13.8 us,
-                 gate / up: 16.0 -> 23.3); SiLU x up -> down_proj measures even (profiles/r03_decode.txt item 7)"""
+                 4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 15 since round 6: the quantiser runs once per
+                 CU in front of the dot-product kernel (csrc/gemvq_w4a4.hip) and every one of the four pays -- a Llama-7B layer at batch 1,
+                 cold: 60.8 us with the four quantisers as launches of their own, 5x.x us with them inside (profiles/r06/decode_layer_hot_cold.txt).
+                 (Rounds 3-5 ran it in every 16-feature workgroup of the decode-batch kernel: only reorder -> o_proj paid, default 2.)"""
     decode: bool = True
     kv_append: bool = True
+    kv_in_decode: bool = True
     q_decode: bool = True
-    q_mask: int = 2
+    q_mask: int = 15
 
 
 FUSION = DecodeFusion()
@@ -217,6 +219,15 @@ def rope_llama(x: torch.Tensor, pos: torch.Tensor, theta: float = 1e4) -> torch.
     return x * cos + rot * sin
 
 
+def _append_and_decode(fusion, q, k32, v32, decode_kv, layer_idx, rope_theta):
+    """reference llama.py:168-196 for a pure decode step: this token's k / v into the INT4 paged cache, then attention over it -- one
+    launch (DecodeFusion.kv_in_decode) or two; the same cache bytes and the same output either way."""
+    if fusion.kv_in_decode:
+        return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta, append_kv=(k32, v32))
+    ops.quant_append_kv_i4(decode_kv, k32, v32, layer_idx)
+    return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta)
+
+
 class LlamaAttention(nn.Module):
     """reference llama.py:90-230: q/k/v projections (k, v with the u4 epilogue), KV written to the INT4 paged cache,
     decode requests through the RoPE-fused batch-decode kernel, output reordered + quantised + projected.
@@ -270,8 +281,7 @@ class LlamaAttention(nn.Module):
                                                                  f32_mask=0b110)
             else:
                 k32, v32 = self.k_proj.forward_f32(hidden_states), self.v_proj.forward_f32(hidden_states)
-            ops.quant_append_kv_i4(decode_kv, k32, v32, self.layer_idx)
-            o = ops.batch_decode_i4(q_proj.view(rows, nh, hd), decode_kv, self.layer_idx, rope_theta=self.rope_theta)
+            o = _append_and_decode(self.fusion, q_proj.view(rows, nh, hd), k32, v32, decode_kv, self.layer_idx, self.rope_theta)
             return self.o_proj(ops.reorder_fp16_i4(o.view(rows, self.hidden_size), self.reorder_index))
         k_u4, k_sz = self.k_proj(hidden_states)
         v_u4, v_sz = self.v_proj(hidden_states)
@@ -330,8 +340,7 @@ class LlamaDecoderLayer(nn.Module):
         else:
             outlier, norms, outlier_scales, norm_scales = il(hidden_states)
             q, k32, v32 = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, at._decode_qkv(), f32_mask=0b110)
-        ops.quant_append_kv_i4(decode_kv, k32, v32, at.layer_idx)
-        o = ops.batch_decode_i4(q.view(rows, at.num_heads, at.head_dim), decode_kv, at.layer_idx, rope_theta=at.rope_theta).view(rows, hs)
+        o = _append_and_decode(self.fusion, q.view(rows, at.num_heads, at.head_dim), k32, v32, decode_kv, at.layer_idx, at.rope_theta).view(rows, hs)
         if mask & 2:
             (attn,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o, at.o_proj.single(), reorder_index=at.reorder_index)
         else:

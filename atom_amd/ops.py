@@ -454,10 +454,11 @@ def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, 
     it in the reference's call order INSIDE the launch -- ``q_op`` "reorder" (reorder_fp16_i4), "rmsnorm" (rmsnorm_fp16_i4, ``x2`` = the
     norm weight), "add_rmsnorm" (add_rmsnorm_fp16_i4: returns x + residual as well) or "silu_mul" (activate_fp16_i4, ``x2`` = the second
     factor); kernel-flavoured quantiser arithmetic.  ``x`` fp16 [M, K].  Returns (outs, residual_out).  The quantised operand is
-    bit-identical to the quantiser op's; the GEMM behind it always runs the decode-batch kernel (summation order 8: eight wave slices,
-    atom_gemm_w4a4_packed_order), so the outputs are bit-identical to quantiser op + dense_layer_gemm_i4_multi wherever THAT runs the
-    decode-batch kernel too -- two tokens with K <= 4096 -- and within one fp16 ulp where it runs the dot-product kernel (order 64): one
-    token, and two tokens with K > 4096 (the rule of gemv_tokens() in csrc/gemm_w4a4.hip).  tests/test_gpu_e2e.py states both."""
+    bit-identical to the quantiser op's, and the GEMM behind it sums in the order the SEPARATE entry points use for the token count
+    (atom_gemm_w4a4_packed_order): the dot-product kernel's (64) for one token and for two with K > 4096 -- round 6, csrc/gemvq_w4a4.hip:
+    one quantiser per CU in front of that kernel -- and the decode-batch kernel's (8) for two tokens with K <= 4096.  The outputs are
+    therefore bit-identical to quantiser op + dense_layer_gemm_i4_multi throughout (tests/test_gpu_e2e.py); rounds 3-5 always ran the
+    decode-batch kernel and were one fp16 ulp off where the separate path took the dot-product kernel."""
     _require_cuda_half(x, "x")
     code = _Q_OPS[q_op]
     m = x.size(0)
@@ -580,9 +581,11 @@ def quant_append_kv_i4(kv, k_f32: torch.Tensor, v_f32: torch.Tensor, layer_idx: 
     L.check(st, "atom_kv_quant_append_f32")
 
 
-def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0):
+def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0, append_kv=None):
     """Decode attention over the INT4 paged cache, RoPE fused.  Reference: punica/ops/__init__.py:21-30 ->
-    FlashInferBatchDecodeKernel_i4 (rope_theta 1e4, rope_scale 1 hard-coded there).  q fp16 [batch, heads, 128]."""
+    FlashInferBatchDecodeKernel_i4 (rope_theta 1e4, rope_scale 1 hard-coded there).  q fp16 [batch, heads, 128].
+    ``append_kv=(k_f32, v_f32)`` (round 6): quant_append_kv_i4 of this step's FP32 k / v projections inside the same launch
+    (atom_batch_decode_append_i4) -- same cache contents, same output, one launch fewer."""
     _require_cuda_half(q, "q")
     num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
     batch = q.size(0)
@@ -592,6 +595,20 @@ def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 
     max_pages = int(getattr(kv, "max_pages", 0))
     ws_bytes = lib.atom_batch_decode_i4_workspace_bytes(batch, num_heads, page_size, max_pages)
     ws = _workspace(q.device, ws_bytes) if ws_bytes else None
+    if append_kv is not None:
+        k32, v32 = append_kv
+        for t in (k32, v32):
+            if not t.is_cuda:
+                raise L.AtomHipError("KV-cache operands must live on the GPU: no CPU fallback")
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (batch, num_heads * head_dim)
+        assert batch == kv.last_page_offset.numel()
+        st = lib.atom_batch_decode_append_i4(o.data_ptr(), q.data_ptr(), k32.data_ptr(), v32.data_ptr(), kv.data.data_ptr(),
+                                             kv.param.data_ptr(), kv.indptr.data_ptr(), kv.indicies.data_ptr(),
+                                             kv.last_page_offset.data_ptr(), batch, num_layers, int(layer_idx), num_heads, page_size,
+                                             head_dim, float(rope_theta), float(rope_scale), max_pages, L.ptr(ws), ws_bytes,
+                                             L.current_stream(q.device))
+        L.check(st, "atom_batch_decode_append_i4")
+        return o
     st = lib.atom_batch_decode_i4(o.data_ptr(), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
                                   kv.indptr.data_ptr(), kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), batch,
                                   num_layers, int(layer_idx), num_heads, page_size, head_dim, float(rope_theta),

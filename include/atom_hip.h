@@ -404,6 +404,15 @@ int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void
                          const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
                          int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,
                          int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream);
+/* atom_kv_quant_append_f32 + atom_batch_decode_i4 of a pure decode step in ONE launch (round 6): k_f32 / v_f32 (float [batch, heads*128])
+ * are this step's k / v projections; for every (sequence, head) the wave that attends to the last token quantises them (the same _o4
+ * arithmetic), writes codes + (scale, zero) into the last token's cache slot and attends to the values it has just written -- the
+ * reference's call order punica/models/llama.py:168-196 (append_kv, then batch_decode) with bit-identical cache contents and output,
+ * without the launch boundary between the two. */
+int atom_batch_decode_append_i4(void *o, const void *q, const void *k_f32, const void *v_f32, void *kv_data, void *kv_param,
+                                const int32_t *kv_indptr, const int32_t *kv_indices, const int32_t *last_page_offset, int batch,
+                                int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta,
+                                float rope_scale, int max_pages_per_seq, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * KV-cache fake quantisation of the simulated path: every 128-d head vector of x is quantised

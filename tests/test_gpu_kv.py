@@ -178,6 +178,42 @@ def test_fused_quant_append_equals_o4_gemm_plus_append(seqlens, heads, block):
     assert torch.equal(pools[0].buf, pools[1].buf) and torch.equal(pools[0].param, pools[1].param)
 
 
+@pytest.mark.parametrize("seqlens,heads,block", [([5, 17, 32, 1, 16], 4, 16), ([1041, 1024, 1025, 48], 8, 16), ([300] * 3 + [33], 32, 32),
+                                                  ([2000, 7], 4, 16)])
+def test_decode_with_the_append_inside_equals_append_then_decode(seqlens, heads, block):
+    """atom_batch_decode_append_i4 (round 6): quantising this step's FP32 k / v sums, writing them into the last token's cache slot and
+    attending over the cache in ONE launch leaves the cache bytes of atom_kv_quant_append_f32 and gives the output of the two launches,
+    bit for bit -- sequence lengths that end on the first / last slot of a 16-token tile and of a page, one-token sequences, KV ranges
+    split over several waves (the appending wave is the last split's) and unsplit."""
+    from atom_amd import ops
+    from atom_amd.utils import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    dev = torch.device("cuda")
+    B = len(seqlens)
+    g = torch.Generator(device="cuda").manual_seed(sum(seqlens))
+    k32 = torch.randn((B, heads * 128), device="cuda", generator=g) * 2
+    v32 = torch.randn((B, heads * 128), device="cuda", generator=g) * 3 + 0.5
+    k32[0, :128] = 0.25                                               # a constant head vector: scale 0, every code 0
+    q = torch.randn((B, heads, 128), device="cuda", generator=g).half()
+    outs, pools = [], []
+    cap = sum(-(-n // block) for n in seqlens) + 2
+    for fused in (False, True):
+        pool = KvPoolInt4(num_layers=2, num_heads=heads, head_dim=128, capacity=cap, block_len=block, device=dev)
+        gp = torch.Generator(device="cuda").manual_seed(11)
+        pool.buf.copy_(torch.randint(0, 256, pool.buf.shape, device="cuda", dtype=torch.uint8, generator=gp))
+        pool.param.copy_((torch.rand(pool.param.shape, device="cuda", generator=gp) * 0.05 + 0.01).half())
+        pool._free = set(range(cap))                                  # same page numbering in both runs
+        kv = BatchedKvCacheInt4([KvCacheInt4(pool, n) for n in seqlens])
+        if fused:
+            o = ops.batch_decode_i4(q, kv, 1, append_kv=(k32, v32))
+        else:
+            ops.quant_append_kv_i4(kv, k32, v32, 1)
+            o = ops.batch_decode_i4(q, kv, 1)
+        outs.append(o)
+        pools.append(pool)
+    assert torch.equal(pools[0].buf, pools[1].buf) and torch.equal(pools[0].param.view(torch.int16), pools[1].param.view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 @pytest.mark.parametrize("seqlens,heads,block", [([37, 5, 16], 4, 16), ([100, 33, 64, 2, 17], 8, 32)])
 def test_append_and_decode_vs_reference_cpu_implementation(seqlens, heads, block):
     """The HIP ops directly against the reference's CPU code: the cache after atom_kv_append_i4 equals the cache after

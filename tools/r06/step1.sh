@@ -11,7 +11,7 @@ python -m pytest tests -m gpu -x -q > $O/pytest_step1.txt 2>&1; echo "pytest rc 
 tail -5 $O/pytest_step1.txt
 {
   for r in 1 2 3; do
-    echo "== new f6 4096^3 (round $r)"; ATOM_F6=1 build/tools/gemm_bench 4096 4096 4096 400 0 | grep RESULT
+    echo "== new f6 4096^3 (round $r)"; ATOM_F6=1 build/tools/gemm_bench 4096 4096 4096 400 $((r==1?64:0)) | grep -E "RESULT|check"
     echo "== sa32 f6 4096^3 (round $r)"; ATOM_F6=1 build/ab/sa32/gemm_bench 4096 4096 4096 400 0 | grep RESULT
   done
   for r in 1 2; do
