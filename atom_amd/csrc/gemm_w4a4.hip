@@ -505,6 +505,9 @@ int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *
   p.q_res = (const half_t *)residual; p.q_res_out = (half_t *)residual_out;
   p.q_idx = reorder_index;
   p.q_eps = eps; p.q_clip = clip;
+#ifdef ATOM_TOOLS   // traced run (tools/r06/gemvq_trace.py): the stamp buffer arrives in ATOM_TRACE_PTR
+  if (const char *e = getenv("ATOM_TRACE_PTR")) p.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+#endif
   if (multi_q_dot(q_op, M, N_seg * nseg, K_total)) return launch_gemvq_multi_q(p, reinterpret_cast<hipStream_t>(stream));
   return launch_gemm_skinny_multi_q(p, reinterpret_cast<hipStream_t>(stream));
 }

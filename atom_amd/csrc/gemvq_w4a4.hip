@@ -28,7 +28,8 @@ namespace gemvq {
 
 constexpr int NTH = 1024, NWV = NTH / 64;
 constexpr int MQ = 2;                     // token rows at most
-constexpr int TPT = 2, XC = 2;            // slot tasks (16 channels) / 16-byte row chunks per thread at most (gemvq_fits)
+constexpr int CPT = 4;                    // channels per quantiser task: a 128-channel group = 32 adjacent lanes
+constexpr int TPT1 = 3, XC = 2;           // quantiser tasks per thread and token row / 16-byte row chunks per thread at most (gemvq_fits)
 
 __device__ __forceinline__ int quad_sum(int d) {
   d += __builtin_amdgcn_mov_dpp(d, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -36,39 +37,52 @@ __device__ __forceinline__ int quad_sum(int d) {
   return d;
 }
 
+// max over the aligned 32 lanes this lane belongs to (a quantisation group of 4-channel tasks): exact, order-free
+__device__ __forceinline__ float max32(float a) {
+  a = max8(a);
+  a = fmaxf(a, dpp_f<0x140>(a));                      // row_mirror: lanes 8-15 <-> 7-0 of the row
+  a = fmaxf(a, __shfl_xor(a, 16));
+  return a;
+}
+
 // LDS: the packed operand [MQ][K4h] codes, [MQ][128] keeper, [G][MQ] + [MQ] fp16 scales; then (16-byte aligned) the reduction scratch,
 // and for ops 1-3 the fp16 rows [MQ][H] and the norm weights [H]
 __host__ __device__ inline int red_offset(int K4h, int G) { return (MQ * K4h + MQ * kKeeper + MQ * G * 2 + MQ * 2 + 15) & ~15; }
-__host__ __device__ inline int sb_offset(int q_op, int K4h, int G) {      // the staged weight scales: behind everything the quantiser uses
+inline size_t lds_bytes(int q_op, int K4h, int G) {
   const int H = 2 * K4h + kKeeper;
-  return red_offset(K4h, G) + 32 + (q_op <= 3 ? H * 2 * (MQ + 1) : 0);
+  return (size_t)red_offset(K4h, G) + 32 + (q_op <= 3 ? (size_t)H * 2 * (MQ + 1) : 0);
 }
-inline size_t lds_bytes(int q_op, int K4h, int G, int nf_max) { return (size_t)sb_offset(q_op, K4h, G) + (size_t)(G + 1) * (nf_max | 1) * 2 + 16; }
 
-// One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 4 chunks per lane, a half or a quarter of
-// one beyond: with 16 waves per workgroup a wave has 128 registers).  The ring below holds D steps.
+// One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 2 chunks per lane, a half or a quarter of
+// one beyond: with 16 waves per workgroup a wave has 128 registers) and the scales of those chunks' groups.  The ring below holds D steps.
 template <int PCH>
 struct PartW {
   v4i w[PCH];              // chunks lane + 64 (part PCH + k), clamped to the row's last one
+  unsigned short sbu[PCH]; // the weight scale of each chunk's group
 };
 
-// (`w8`: the keeper chunk lane % 8 of the feature, requested with its last part -- `last` is a constant once the loops are unrolled)
+// (`w8`, `sb8u`: the keeper chunk lane % 8 of the feature and its scale, requested with the feature's last part -- `last` is a constant
+// once the loops are unrolled)
 template <int PCH>
-__device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, bool last, int lane, int nchunks, PartW<PCH> &f, v4i &w8) {
+__device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, bool last, int lane, int nchunks, PartW<PCH> &f, v4i &w8,
+                                          unsigned short &sb8u) {
   const uint8_t *brow = p.B4 + (int64_t)n * p.K4h;
+  const unsigned short *sBu = reinterpret_cast<const unsigned short *>(p.sB);
 #pragma unroll
   for (int c = 0; c < PCH; ++c) {
     const int cc = min(lane + 64 * (part * PCH + c), nchunks - 1);
     f.w[c] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(brow + cc * 16));   // nt: read once, by this CU only
   }
-  if (last) w8 = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
+#pragma unroll
+  for (int c = 0; c < PCH; ++c) {
+    const int cc = min(lane + 64 * (part * PCH + c), nchunks - 1);
+    f.sbu[c] = sBu[(int64_t)(cc >> 2) * p.N + n];
+  }
+  if (last) {
+    w8 = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
+    sb8u = reinterpret_cast<const unsigned short *>(p.sB8)[n];
+  }
 }
-
-// Weight scales of a workgroup's features, staged ONCE in LDS as [G + 1][nfs] fp16 (row G: the keeper's): read per feature from memory
-// (gemv1_w4a4_kernel) a wave issues one 2-byte gather over 16 cache lines for every 1 KiB of weights -- as many line requests as the
-// weight stream itself; staged, a row segment of the [G][N] array is a few contiguous lines for the whole workgroup.
-constexpr int SBT = 4;                    // staging loads per thread at most (gemvq_fits)
-__host__ __device__ inline int sb_stride(int nf) { return nf | 1; }   // halves; odd: the 16 groups of a wave's read fall into distinct banks
 
 // QOP: 1 reorder, 2 RMSNorm + reorder, 3 residual add + RMSNorm + reorder, 4 SiLU(x) * x2.  NCH: 16-byte weight chunks per lane
 // (>= ceil(K4 / 2048)).  MT: token rows.
@@ -84,74 +98,92 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
   const int lw = xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3);
   const int f0 = (int)((int64_t)lw * p.N / (int)gridDim.x), f1 = (int)((int64_t)(lw + 1) * p.N / (int)gridDim.x);
+#ifdef ATOM_TOOLS   // tools/r06/gemvq_trace.py: s_memtime stamps of the first and the last workgroup into p.Dsz as u32 [2][16 waves][16]
+  unsigned *trb = nullptr;
+  if (p.Dsz && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 16 : 0) + wave) * 16;
+#define GQ_STAMP(k) do { if (trb) { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) trb[k] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+  if (trb && lane == 0) trb[15] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#else
+#define GQ_STAMP(k) do { } while (0)
+#endif
+  GQ_STAMP(0);
 
-  // ---- everything the quantiser reads, requested first (one memory round trip for the whole prologue)
-  const int q_nchunks = H >> 3, q_nslots = H >> 4;
+  // ---- everything the quantiser reads, requested first: one memory round trip for the whole prologue.  Whole waves without work
+  // issue nothing (wave-uniform guards; a CU's vector-memory path takes ~20 cycles per wave instruction: the s_memtime trace of the
+  // first version, profiles/r06/gemvq_trace.txt, had 4-8 k cycles of request issue in front of the quantiser)
+  const int q_nchunks = H >> 3;                              // 16-byte chunks of a row
+  const int tpr = H / CPT;                                   // tasks per row: 4 channels each, 32 per quantisation group
+  const int ntask = p.M * tpr;
+  const int wbase = tid & ~63;                               // this wave's first thread
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  v4u q_ri[TPT][2], q_rb[QOP == 4 ? TPT : 1][2];
+  constexpr int TPT = TPT1 * MT;
+  v2u q_ri[TPT], q_rb[QOP == 4 ? TPT : 1];                  // per task: 4 reorder indices (ops 1-3) / 4 gate and 4 up values (op 4)
   h8 q_xr[QOP <= 3 ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[QOP == 2 || QOP == 3 ? XC : 1];
-  {
-    const int ntask = p.M * q_nslots;
 #pragma unroll
-    for (int t = 0; t < TPT; ++t) {
-      const int task = min(tid + t * NTH, ntask - 1), m = task / q_nslots, e0 = (task - m * q_nslots) * 16;
+  for (int t = 0; t < TPT; ++t) {
+    q_ri[t] = v2u{0u, 0u};
+    if constexpr (QOP == 4) q_rb[t] = v2u{0u, 0u};
+    if (wbase + t * NTH < ntask) {                           // (wave-uniform)
+      const int task = min(tid + t * NTH, ntask - 1), m = task / tpr, e0 = (task - m * tpr) * CPT;
       if constexpr (QOP == 4) {
-        const half_t *arow = p.q_x + (int64_t)m * H, *brow = p.q_x2 + (int64_t)m * H;
-        q_ri[t][0] = *reinterpret_cast<const v4u *>(arow + e0);
-        q_ri[t][1] = *reinterpret_cast<const v4u *>(arow + e0 + 8);
-        q_rb[t][0] = *reinterpret_cast<const v4u *>(brow + e0);
-        q_rb[t][1] = *reinterpret_cast<const v4u *>(brow + e0 + 8);
-      } else {
-        const int16_t *ip = p.q_idx ? p.q_idx + e0 : reinterpret_cast<const int16_t *>(p.q_x);   // (no index: any readable address)
-        q_ri[t][0] = *reinterpret_cast<const v4u *>(ip);
-        q_ri[t][1] = *reinterpret_cast<const v4u *>(ip + 8);
+        q_ri[t] = *reinterpret_cast<const v2u *>(p.q_x + (int64_t)m * H + e0);
+        q_rb[t] = *reinterpret_cast<const v2u *>(p.q_x2 + (int64_t)m * H + e0);
+      } else if (p.q_idx) {
+        q_ri[t] = *reinterpret_cast<const v2u *>(p.q_idx + e0);
       }
     }
-    if constexpr (QOP <= 3) {
+  }
+  if constexpr (QOP <= 3) {
 #pragma unroll
-      for (int i = 0; i < XC; ++i) {
+    for (int i = 0; i < XC; ++i) {
+      q_xr[i] = h8{};
+      if constexpr (QOP == 3) q_rr[i] = h8{};
+      if (wbase + i * NTH < p.M * q_nchunks) {
         const int c = min(tid + i * NTH, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
         q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
         if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
       }
-      if constexpr (QOP >= 2) {
+    }
+    if constexpr (QOP >= 2) {
 #pragma unroll
-        for (int i = 0; i < XC; ++i)
+      for (int i = 0; i < XC; ++i) {
+        q_wr[i] = h8{};
+        if (wbase + i * NTH < q_nchunks)
           q_wr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x2) + min(tid + i * NTH, q_nchunks - 1) * 16);
       }
     }
   }
-  __builtin_amdgcn_sched_barrier(0);   // (the requests above are issued before the weight loads below)
+  __builtin_amdgcn_sched_barrier(0);
+  // every wave's quantiser requests are in the memory pipeline before ANY weight request goes out (one s_barrier: the 128 weight
+  // requests of a workgroup would otherwise sit in front of the later waves' row chunks)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- the weights of this wave's first D steps (NCH <= 4: its first D features): in flight while the quantiser runs
+  // ---- the weights of this wave's first D steps (NCH <= 2: its first D features): in flight while the quantiser runs
   constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1), PCH = NCH / PARTS;
   constexpr int D = 4;                                            // ring slots; the unrolled loop below needs PARTS | D
   static_assert(PCH * PARTS == NCH && D % PARTS == 0, "chunks per lane: 1, 2, 4, 6 or 8");
   PartW<PCH> ring[D];
-  v4i ring8[D / PARTS];                                           // the keeper chunks of the features in the ring
+  v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
+  unsigned short ringsb8[D / PARTS];
   const int n0w = f0 + wave;
   const int nfeat = n0w < f1 ? (f1 - n0w + NWV - 1) / NWV : 0;    // features of this wave
   const int nsteps = nfeat * PARTS;
+  auto issue_ring = [&](int u0, int u1) {
 #pragma unroll
-  for (int u = 0; u < D; ++u) {                                   // (a wave with fewer steps re-reads its last one / a valid row: L2)
-    const int st = min(u, max(nsteps - 1, 0));
-    load_part<PCH>(p, min(n0w + (st / PARTS) * NWV, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS]);
+  for (int u = 0; u < D; ++u) {
+    if (u >= u0 && u < u1 && (u < nsteps || u < PARTS))                                  // (wave-uniform; a wave without features still reads one valid row)
+      load_part<PCH>(p, min(n0w + (u / PARTS) * NWV, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
+                     ringsb8[u / PARTS]);
   }
-  // ... and the workgroup's weight scales (staged in LDS below)
-  const int nf = f1 - f0, nfs = sb_stride(nf);
-  unsigned short sbt[SBT];
-#pragma unroll
-  for (int i = 0; i < SBT; ++i) {
-    const int e = min(tid + i * NTH, (G + 1) * nf - 1), g = e / nf, j = e - g * nf;
-    sbt[i] = g < G ? reinterpret_cast<const unsigned short *>(p.sB)[(int64_t)g * p.N + f0 + j]
-                   : reinterpret_cast<const unsigned short *>(p.sB8)[f0 + j];
-  }
+  };
+  GQ_STAMP(1);                                               // every request issued
   __builtin_amdgcn_sched_barrier(0);
   // nothing of the quantiser moves up between the loads above, and none of its requests sinks into a branch below
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
-    asm volatile("" : "+v"(q_ri[t][0]), "+v"(q_ri[t][1]));
-    if constexpr (QOP == 4) asm volatile("" : "+v"(q_rb[t][0]), "+v"(q_rb[t][1]));
+    asm volatile("" : "+v"(q_ri[t]));
+    if constexpr (QOP == 4) asm volatile("" : "+v"(q_rb[t]));
   }
   if constexpr (QOP <= 3) {
 #pragma unroll
@@ -162,15 +194,6 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
   }
 
-  unsigned short *lsb = reinterpret_cast<unsigned short *>(lds + sb_offset(QOP, K4h, G));   // [G + 1][nfs]
-#pragma unroll
-  for (int i = 0; i < SBT; ++i) {
-    const int e = tid + i * NTH;
-    if (e < (G + 1) * nf) {
-      const int g = e / nf, j = e - g * nf;
-      lsb[g * nfs + j] = sbt[i];                              // (published by the quantiser's barriers below)
-    }
-  }
   // ---- the quantiser: the token rows' packed operand, built in LDS (its barriers wait for LDS only)
   uint8_t *qa4 = reinterpret_cast<uint8_t *>(lds);                                        // [MQ][K4h]
   uint8_t *qa8 = qa4 + MQ * K4h;                                                          // [MQ][128]
@@ -184,8 +207,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     float *red = reinterpret_cast<float *>(lds + red_offset(K4h, G));                     // [MQ][4] partial sums of squares
     char *rowbuf = reinterpret_cast<char *>(red + 8);                                     // [MQ][H] halves, then the norm weights [H]
     char *wbuf = rowbuf + MQ * H * 2;
-    const int nslots = q_nslots, Gt = H >> 7;
-    const int ntask = p.M * nslots;                          // slot tasks: (row, slot), 16 channels each
+    const int Gt = H >> 7;
     if constexpr (QOP <= 3) {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
@@ -205,8 +227,16 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         for (int i = 0; i < XC; ++i)
           if (tid + i * NTH < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NTH) * 16) = q_wr[i];
       }
+      GQ_STAMP(2);                                             // the quantiser's inputs have arrived and sit in LDS
       lds_barrier();
+      GQ_STAMP(3);
     }
+    // the weights of this wave's first D steps go out HERE: in front of the quantiser's own requests they held every wave at the
+    // CU's vector-memory issue rate (~20 cycles per wave instruction: 4-12 k cycles before the first row chunk reached LDS,
+    // profiles/r06/gemvq_trace.txt); from here they overlap the sum of squares and the codes
+    // (half of the ring up front, half here: measured equal to worse -- a CU streams ~10 bytes per clock from HBM whatever the order.
+    // SiLU x up has no barrier in front of its codes and two 8-byte inputs per task in registers: its ring goes out behind the codes)
+    if constexpr (QOP != 4) issue_ring(0, D);
     float rinv[MQ] = {0.f, 0.f};
     if constexpr (QOP == 2 || QOP == 3) {
       const int m = tid >> 8, t8 = tid & 255;               // the stand-alone kernel's 4-wave tree, one per row
@@ -221,6 +251,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         if (lane == 0) red[m * 4 + (wave & 3)] = ss;
       }
       lds_barrier();
+      GQ_STAMP(4);                                             // sum of squares done
 #pragma unroll
       for (int m2 = 0; m2 < MQ; ++m2) {
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
@@ -228,23 +259,25 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         rinv[m2] = rinv_sqrt_exact(var + p.q_eps);
       }
     }
+    // the codes: 4 channels per thread, a 128-channel group = 32 adjacent lanes (the stand-alone kernels take 16 per thread: the same
+    // values, the same maximum, the same scale, the same codes -- spread over four times the threads)
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
-      const int task = tid + t * NTH;
-      if (task < ntask) {                                    // (ntask is a multiple of 8: whole octets for max8)
-        const int m = task / nslots, slot = task - m * nslots;
-        const int e0 = slot * 16, g = slot >> 3, j = slot & 7;
+      if (wbase + t * NTH < ntask) {                         // (wave-uniform; ntask is a multiple of 32: whole groups per wave half)
+        const int task = min(tid + t * NTH, ntask - 1);
+        const int m = task / tpr, e0 = (task - m * tpr) * CPT;
+        const int g = e0 >> 7, j = (e0 >> 2) & 31;
         const bool keeper = g == Gt - 1;
-        float v[16];
+        float v[CPT];
         if constexpr (QOP == 4) {
-          const half_t *av = reinterpret_cast<const half_t *>(q_ri[t]), *bv = reinterpret_cast<const half_t *>(q_rb[t]);
+          const half_t *av = reinterpret_cast<const half_t *>(&q_ri[t]), *bv = reinterpret_cast<const half_t *>(&q_rb[t]);
 #pragma unroll
-          for (int k = 0; k < 16; ++k) v[k] = silu_mul<false>((float)av[k], (float)bv[k]);
+          for (int k = 0; k < CPT; ++k) v[k] = silu_mul<false>((float)av[k], (float)bv[k]);
         } else {
-          const uint16_t *iv = reinterpret_cast<const uint16_t *>(q_ri[t]);
+          const uint16_t *iv = reinterpret_cast<const uint16_t *>(&q_ri[t]);
           const float rv = m == 0 ? rinv[0] : rinv[1];
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
+          for (int k = 0; k < CPT; ++k) {
             const int off = p.q_idx ? (int)iv[k] : e0 + k;
             const half_t xh = *reinterpret_cast<const half_t *>(rowbuf + m * H * 2 + off * 2);
             if constexpr (QOP >= 2) {
@@ -257,22 +290,35 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         }
         float amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-        amax = max8(amax);
+        for (int i = 0; i < CPT; ++i) amax = fmaxf(amax, fabsf(v[i]));
+        amax = max32(amax);
         const GroupScale gs = group_scale<false>(amax, keeper, p.q_clip);
-        float tr[16];
+        float tr[CPT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tr[i] = group_code<false>(v[i], gs);
-        const v4u w = pack_codes16(tr, keeper);
-        if (keeper) *reinterpret_cast<v4u *>(qa8 + m * kKeeper + j * 16) = w;
-        else *reinterpret_cast<v2u *>(qa4 + m * K4h + g * 64 + j * 8) = v2u{w[0], w[1]};
-        if (j == 0) {
-          if (keeper) qsa8[m] = f2h(gs.s_store);
-          else qsa[g * MQ + m] = f2h(gs.s_store);
+        for (int i = 0; i < CPT; ++i) tr[i] = group_code<false>(v[i], gs);
+        if (tid + t * NTH < ntask) {
+          if (keeper) {                                        // 4 INT8 codes: one word of pack_codes16's keeper form
+            const float lo = __builtin_fmaf(tr[1], 256.f, tr[0] + 32896.f), hi = __builtin_fmaf(tr[3], 256.f, tr[2] + 32896.f);
+            *reinterpret_cast<unsigned *>(qa8 + m * kKeeper + j * 4) = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
+          } else {                                             // 4 INT4 codes: half a word of its nibble form
+            float lo = 34952.f;
+            lo = __builtin_fmaf(tr[0], 1.f, lo);
+            lo = __builtin_fmaf(tr[1], 16.f, lo);
+            lo = __builtin_fmaf(tr[2], 256.f, lo);
+            lo = __builtin_fmaf(tr[3], 4096.f, lo);
+            *reinterpret_cast<unsigned short *>(qa4 + m * K4h + g * 64 + j * 2) = (unsigned short)((unsigned)lo ^ 0x8888u);
+          }
+          if (j == 0) {
+            if (keeper) qsa8[m] = f2h(gs.s_store);
+            else qsa[g * MQ + m] = f2h(gs.s_store);
+          }
         }
       }
     }
+    if constexpr (QOP == 4) issue_ring(0, D);
+    GQ_STAMP(5);                                               // codes written
     lds_barrier();
+    GQ_STAMP(6);                                               // the packed operand is published
   }
 
   // ---- the feature loop: gemv1_w4a4_kernel's arithmetic, feature by feature.  Step s = (feature s / PARTS, part s % PARTS) sits in
@@ -286,7 +332,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       const int part = u % PARTS;
       const int fi = base / PARTS + u / PARTS;              // this wave's fi-th feature
       if (base + u < nsteps) {                              // (wave-uniform)
-        const int n = n0w + fi * NWV, jf = n - f0;          // the feature, and its column in the staged scales
+        const int n = n0w + fi * NWV;
         PartW<PCH> &f = ring[u];
         if (part == 0) {
 #pragma unroll
@@ -297,7 +343,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           const int ch = lane + 64 * (part * PCH + c);
           const bool ok = ch < nchunks;
           const int cc = min(ch, nchunks - 1);
-          const float sbf = (float)__builtin_bit_cast(half_t, lsb[(cc >> 2) * nfs + jf]);
+          const float sbf = (float)__builtin_bit_cast(half_t, f.sbu[c]);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const int mr = min(m, p.M - 1);
@@ -314,7 +360,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           }
         }
         if (part == PARTS - 1) {
-          const float sb8f = (float)__builtin_bit_cast(half_t, lsb[G * nfs + jf]);
+          const float sb8f = (float)__builtin_bit_cast(half_t, ringsb8[u / PARTS]);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const int mr = min(m, p.M - 1);
@@ -344,23 +390,28 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
             }
           }
         }
+        if (base + u < 4) GQ_STAMP(7 + base + u);            // steps 0 .. 3 done
         if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
-          load_part<PCH>(p, n + (D / PARTS) * NWV, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS]);
+          load_part<PCH>(p, n + (D / PARTS) * NWV, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
       }
     }
   }
+  GQ_STAMP(11);                                              // all features of this wave done
+#ifdef ATOM_TOOLS
+  if (trb && lane == 0) trb[14] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int QOP, int NCH, int MT>
 static int launch1(const GemmParams &p, hipStream_t s) {
-  const int cap0 = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
-  int grid0 = p.N / NWV;
-  if (grid0 > cap0) grid0 = cap0;
-  if (grid0 < 1) grid0 = 1;
-  const size_t lds = lds_bytes(QOP, p.K4h, p.G, (p.N + grid0 - 1) / grid0);
+  const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
-  const int grid = grid0;                                  // one workgroup per CU at most; every wave of it at least one feature
+  // one workgroup per CU at most; every wave of it at least one feature
+  const int cap = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
+  int grid = p.N / NWV;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
   hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT>), dim3((unsigned)grid), dim3(NTH), lds, s, p);
   return check_launch();
 }
@@ -384,18 +435,16 @@ static int launch_mt(const GemmParams &p, hipStream_t s) {
 }  // namespace gemvq
 
 // THE shape predicate of this launch (atom_gemm_w4a4_multi_q routes one or two tokens here when it holds): per thread of the 1024 at
-// most two slot tasks of 16 channels and two 16-byte chunks of the token rows / the norm weight, at most 8 weight chunks per lane
-// (K_total <= 16,512), everything within 128 KiB of LDS.
+// most three quantiser tasks of 4 channels per token row (hidden <= 12,288) and two 16-byte chunks of the token rows / the norm weight (ops 1-3), at most 8 weight chunks
+// per lane (K_total <= 16,512), everything within 128 KiB of LDS.
 bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t H) {
   if (q_op < 1 || q_op > 4 || M < 1 || M > gemvq::MQ || H < 2 * kKeeper || ((H - kKeeper) % kGroup) != 0 || N < gemvq::NWV) return false;
-  if (M * (H >> 4) > gemvq::TPT * gemvq::NTH) return false;
+  if (H / gemvq::CPT > gemvq::TPT1 * gemvq::NTH) return false;
   if (q_op <= 3 && (M * (H >> 3) > gemvq::XC * gemvq::NTH || (H >> 3) > gemvq::XC * gemvq::NTH)) return false;
   const int K4h = (int)((H - kKeeper) / 2), G = (int)((H - kKeeper) / kGroup);
   const int need = ((K4h >> 4) + 63) / 64;                 // weight chunks per lane
   if (need > 8) return false;
-  const int64_t grid = N / gemvq::NWV < 256 ? N / gemvq::NWV : 256, nf = (N + grid - 1) / grid;
-  if ((int64_t)(G + 1) * nf > (int64_t)gemvq::SBT * gemvq::NTH) return false;   // the staged weight scales: 4 loads per thread at most
-  return gemvq::lds_bytes(q_op, K4h, G, (int)nf) <= (size_t)128 * 1024;
+  return gemvq::lds_bytes(q_op, K4h, G) <= (size_t)128 * 1024;
 }
 
 int launch_gemvq_multi_q(const GemmParams &p, hipStream_t s) {

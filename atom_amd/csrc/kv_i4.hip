@@ -423,18 +423,63 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
 }
 
 // out[b,h,:] = sum_s o_s * 2^(m_s - M) / sum_s d_s * 2^(m_s - M)
+// Round 6: every split's (value, m, d) is requested before the first one is used -- in batches of 8 splits with compile-time bounds.
+// The partial states were written by waves on other XCDs, so each request is a trip to memory (~1.5 us): the two run-time loops of
+// rounds 1-5 (one for the maximum, one for the sums, their loads inside) paid it 2 x splits times in sequence on a 130-thread kernel
+// (4.7 us per decode step for 133 KB).  Same operations in the same order: same bits.
 __global__ __launch_bounds__(128) void decode_merge_kernel(const float *ws, half_t *o, int splits) {
   const int64_t bh = blockIdx.x;
   const int dim = threadIdx.x;
   const float *wp = ws + bh * splits * (kHeadDim + 2);
+  constexpr int SB = 8;
   float M = -INFINITY;
-  for (int s = 0; s < splits; ++s) M = fmaxf(M, wp[s * (kHeadDim + 2) + kHeadDim]);
+  if (splits <= SB) {
+    float ov[SB], mv[SB], dv[SB];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      const int sc = min(s, splits - 1);
+      ov[s] = wp[sc * (kHeadDim + 2) + dim];
+      mv[s] = wp[sc * (kHeadDim + 2) + kHeadDim];
+      dv[s] = wp[sc * (kHeadDim + 2) + kHeadDim + 1];
+    }
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+      if (s < splits) M = fmaxf(M, mv[s]);
+    float acc = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+      if (s < splits) {
+        const float w = mv[s] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv[s] - M);
+        acc = __builtin_fmaf(ov[s], w, acc);
+        den = __builtin_fmaf(dv[s], w, den);
+      }
+    o[bh * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
+    return;
+  }
+  for (int s0 = 0; s0 < splits; s0 += SB) {
+    float mv[SB];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) mv[s] = wp[min(s0 + s, splits - 1) * (kHeadDim + 2) + kHeadDim];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) M = fmaxf(M, mv[s]);        // (a clamped repeat of the last split changes no maximum)
+  }
   float acc = 0.f, den = 0.f;
-  for (int s = 0; s < splits; ++s) {
-    const float ms = wp[s * (kHeadDim + 2) + kHeadDim];
-    const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - M);
-    acc = __builtin_fmaf(wp[s * (kHeadDim + 2) + dim], w, acc);
-    den = __builtin_fmaf(wp[s * (kHeadDim + 2) + kHeadDim + 1], w, den);
+  for (int s0 = 0; s0 < splits; s0 += SB) {
+    float ov[SB], mv[SB], dv[SB];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      const int sc = min(s0 + s, splits - 1);
+      ov[s] = wp[sc * (kHeadDim + 2) + dim];
+      mv[s] = wp[sc * (kHeadDim + 2) + kHeadDim];
+      dv[s] = wp[sc * (kHeadDim + 2) + kHeadDim + 1];
+    }
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+      if (s0 + s < splits) {
+        const float w = mv[s] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv[s] - M);
+        acc = __builtin_fmaf(ov[s], w, acc);
+        den = __builtin_fmaf(dv[s], w, den);
+      }
   }
   o[bh * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
 }
@@ -453,7 +498,7 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
 static int decode_splits(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
   const int64_t tiles = (int64_t)max_pages * (P / 16), pairs = (int64_t)batch * N;
-  const int min_tiles = ATOM_TUNE("ATOM_DECODE_MIN_TILES", 8);
+  const int min_tiles = ATOM_TUNE("ATOM_DECODE_MIN_TILES", 4);   // (round 6: 4 -- a wave alone on its SIMD issues one VALU per ~7 cycles, so at small batches twice the waves with half the tiles each win: 11.0 -> 9.0 us at batch 1, context 1024)
   int64_t smax = tiles / min_tiles;
   if (smax > 64) smax = 64;
   int best = 1;

@@ -240,25 +240,29 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
  * (atom_gemm_w4a4_multi_q_fits).  The reference runs the two as separate ops -- punica/models/llama.py:259-263 input_layernorm
  * (rmsnorm_fp16_i4) -> :110-119 q / k / v; :176 reorder_fp16_i4 -> o_proj; :266-282 residual add + post_attention_layernorm -> :85
  * gate / up; :86 activate_fp16_i4 -> :87 down_proj -- and so does this library from three tokens on; at one or two tokens a
- * quantiser launch costs more than its arithmetic (a launch boundary, its own round trip through HBM, 3-5 us against the GEMM's 5-9), so
- * every workgroup of the GEMM quantises its own copy of the token rows into LDS behind its weight loads instead.
+ * quantiser launch costs more than its arithmetic (a launch boundary, its own round trip through HBM, 4.4-4.7 us against the GEMM's 5-9), so
+ * the GEMM launch quantises the token rows itself: once per CU, in front of the dot-product kernel's feature loop (round 6,
+ * csrc/gemvq_w4a4.hip: one workgroup of 16 waves per CU; a Llama-7B decode layer at batch 1, cold, 60.8 -> 52 us with all four
+ * quantisers inside).  (Rounds 3-5: in every 16-feature workgroup of the decode-batch kernel -- still the form for shapes the
+ * dot-product form does not take.)
  *   q_op   ATOM_Q_REORDER      x [M, K_total] fp16, reorder_index (or NULL)           = atom_reorder_quant_f16
  *          ATOM_Q_RMSNORM      + x2 = the RMSNorm weight [K_total], eps               = atom_rmsnorm_reorder_quant_f16
  *          ATOM_Q_ADD_RMSNORM  + residual, residual_out [M, K_total] (x + residual)   = atom_add_rmsnorm_reorder_quant_f16
  *                              (NOT in place: every workgroup reads x and residual, workgroup 0 writes residual_out)
  *          ATOM_Q_SILU_MUL     x2 = the second factor [M, K_total]; no reorder index  = atom_silu_mul_quant_f16
  * in the kernel-flavoured arithmetic (quant_mode 0), clip as there.  Outputs, segments, f32_mask, add0_f16 as atom_gemm_w4a4_multi.
- * The quantised operand is bit-identical to the quantiser op's; the GEMM always runs the decode-batch kernel (summation order 8), so the
- * outputs are bit-identical to the quantiser op followed by atom_gemm_w4a4_multi wherever that call runs the decode-batch kernel too
- * (two tokens with K_total <= 4096), and within one fp16 ulp where it runs the dot-product kernel (order 64: one token; two tokens with
- * K_total > 4096) -- atom_gemm_w4a4_packed_order(M, N, K_total, 0) tells which (tests/test_gpu_gemm.py, tests/test_gpu_e2e.py).
+ * The quantised operand is bit-identical to the quantiser op's, and the sums are formed in the order atom_gemm_w4a4_multi uses for the
+ * token count (one and two tokens: the dot-product kernel's, atom_gemm_w4a4_packed_order = 64): the outputs are bit-identical to the
+ * quantiser op followed by atom_gemm_w4a4_multi (tests/test_gpu_e2e.py).  (Rounds 3-5 always summed in the decode-batch kernel's order
+ * and were one fp16 ulp off where the separate call took the dot-product kernel.)
  */
 #define ATOM_Q_REORDER 1
 #define ATOM_Q_RMSNORM 2
 #define ATOM_Q_ADD_RMSNORM 3
 #define ATOM_Q_SILU_MUL 4
-/* 1 when atom_gemm_w4a4_multi_q takes (q_op, M, N_seg, nseg, K_total): the launcher's own predicate.  ATOM_Q_SILU_MUL allows three
- * 16-channel slots per thread of the 512, the other three ops two (they also stage the fp16 rows and the norm weight in LDS). */
+/* 1 when atom_gemm_w4a4_multi_q takes (q_op, M, N_seg, nseg, K_total): the launcher's own predicate -- one or two tokens, K_total <=
+ * 12,288 (three 4-channel quantiser tasks per thread of the 1024 and token row), for the three ops that stage fp16 rows and the norm
+ * weight in LDS M x K_total <= 16,384, and a shape atom_gemm_w4a4_multi takes. */
 int atom_gemm_w4a4_multi_q_fits(int q_op, int64_t M, int64_t N_seg, int nseg, int64_t K_total);
 int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *residual, void *residual_out,
                            const int16_t *reorder_index, float eps, float clip, const void *B4, const void *sB, const void *B8,

@@ -356,7 +356,7 @@ def test_fused_quantiser_query_is_the_launchers_predicate_at_wide_hidden_sizes()
     assert ops.multi_q_gemm_fits("reorder", 1, 8192, 1, 8192) and ops.multi_q_gemm_fits("reorder", 2, 8192, 1, 8192)
     assert ops.multi_q_gemm_fits("rmsnorm", 2, 6656, 3, 6656) and ops.multi_q_gemm_fits("silu_mul", 2, 4096, 1, 8192)
     assert not ops.multi_q_gemm_fits("reorder", 2, 4096, 1, 11008) and ops.multi_q_gemm_fits("silu_mul", 2, 4096, 1, 11008)
-    assert ops.multi_q_gemm_fits("reorder", 1, 64, 1, 12416) and not ops.multi_q_gemm_fits("reorder", 2, 64, 1, 12416)
+    assert ops.multi_q_gemm_fits("reorder", 1, 64, 1, 12288) and not ops.multi_q_gemm_fits("reorder", 2, 64, 1, 12288)
     dev = torch.device("cuda")
     # what the query refuses raises: two tokens of 11008 channels through the reorder quantiser
     N, K = 64, 11008
