@@ -76,6 +76,9 @@ SIGNATURES = {
     "atom_gemm_w4a4_f32": (_int, [_vp] * 9 + [_i64, _i64, _i64, _int, _int, _int, _vp]),
     "atom_gemm_w4a4_silu_mul_quant_f6": (_int, [_vp] * 6 + [_i64, _i64, _i64, _int, _int, _int, _f32, _int] + [_vp] * 6),
     "atom_batch_decode_i4_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _int]),
+    "atom_batch_decode_i4_splits": (_int, [_int, _int, _int, _int]),
+    "atom_gemm_w4a4_multi_merge_q_fits": (_int, [_i64, _i64, _int, _i64, _int]),
+    "atom_gemm_w4a4_multi_merge_q": (_int, [_vp, _int, _vp, _f32] + [_vp] * 7 + [ctypes.c_uint, _vp, _i64, _i64, _int, _i64, _int, _int, _vp]),
     "atom_batch_decode_i4": (_int, [_vp] * 7 + [_int] * 6 + [_f32, _f32, _int, _vp, ctypes.c_size_t, _vp]),
     "atom_batch_decode_append_i4": (_int, [_vp] * 9 + [_int] * 6 + [_f32, _f32, _int, _vp, ctypes.c_size_t, _vp]),
 }

@@ -99,6 +99,8 @@ struct GemmParams {
   half_t *q_res_out;              // 3: x + residual [M, K_total] (written by workgroup 0; may alias q_res)
   const int16_t *q_idx;           // reorder index [K_total] or null (1, 2, 3)
   float q_eps, q_clip;
+  const float *q_part;            // 5 (gemvq_w4a4.hip): the decode attention's split partial states [M][heads][q_splits][130] instead of q_x
+  int q_splits;
 };
 
 int launch_gemm_v2(const GemmParams &p, int ns, hipStream_t s);   // gemm_w4a4_v2.hip
@@ -120,6 +122,7 @@ int launch_gemm_skinny_multi(const GemmParams &p, hipStream_t s);  // ... segmen
 bool skinny_q_fits(int q_op, int64_t M, int64_t K_total);             // ... the shapes its quantiser-in-front variant takes
 int launch_gemm_skinny_multi_q(const GemmParams &p, hipStream_t s);   // ... + the preceding quantiser inside the launch (p.q_*)
 bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t K_total);     // gemvq_w4a4.hip: one or two tokens, the quantiser in front of the dot-product kernel
+bool gemvq_merge_fits(int64_t M, int64_t N, int64_t K_total, int splits);   // ... its merge form (q_op 5)
 int launch_gemvq_multi_q(const GemmParams &p, hipStream_t s);         // ... (p.q_*, p.seg_*): one quantiser per CU, gemv1's summation order
 int launch_gemm_f6(const GemmParams &p, int cfg, hipStream_t s);   // gemm_w4a4_f6.hip (BF6 operands on the block-scaled MFMA)
 int launch_gemm_f6_mid(const GemmParams &p, hipStream_t s);        // gemm_w4a4_mid.hip: the same for BF6 operands (ATOM_AB_F6 | ATOM_B_F6S)

@@ -248,7 +248,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.sA = (const half_t *)sA;  p.sB = (const half_t *)sB;
   p.A8 = (const uint8_t *)A8; p.B8 = (const uint8_t *)B8;
   p.sA8 = (const half_t *)sA8; p.sB8 = (const half_t *)sB8;
-  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr; p.ws = nullptr; p.splits = 1; p.q_op = 0;
+  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr; p.ws = nullptr; p.splits = 1; p.q_op = 0; p.q_part = nullptr; p.q_splits = 0;
   p.M = (int)M; p.N = (int)N;
   p.K4h = (int)((K_total - kKeeper) / 2);
   p.G = (int)((K_total - kKeeper) / kGroup);
@@ -510,6 +510,42 @@ int atom_gemm_w4a4_multi_q(int q_op, const void *x, const void *x2, const void *
 #endif
   if (multi_q_dot(q_op, M, N_seg * nseg, K_total)) return launch_gemvq_multi_q(p, reinterpret_cast<hipStream_t>(stream));
   return launch_gemm_skinny_multi_q(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+int atom_gemm_w4a4_multi_merge_q_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total, int splits) {
+  if (M < 1 || nseg < 1 || nseg > 3 || N_seg < 16 || (N_seg % 16) != 0 || K_total < 256 || ((K_total - kKeeper) % kGroup) != 0) return 0;
+  if (!ATOM_TUNE("ATOM_GEMVQ_MERGE", 1) || M > gemv_tokens(K_total) || !gemvq_merge_fits(M, N_seg * nseg, K_total, splits)) return 0;
+  return atom_gemm_w4a4_multi_fits(M, N_seg, nseg, K_total);
+}
+
+int atom_gemm_w4a4_multi_merge_q(const void *partials_f32, int splits, const int16_t *reorder_index, float clip, const void *B4, const void *sB,
+                                 const void *B8, const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask,
+                                 const void *add0_f16, int64_t M, int64_t N_seg, int nseg, int64_t K_total, int group, int keeper,
+                                 void *stream) {
+  if (!partials_f32) return ATOM_ERR_INVALID_ARG;
+  if (nseg < 1 || nseg > 3 || !out0 || (nseg > 1 && !out1) || (nseg > 2 && !out2)) return ATOM_ERR_INVALID_ARG;
+  if (N_seg < 16 || (N_seg % 16) != 0) return ATOM_ERR_SHAPE;
+  if ((f32_mask & 1u) && add0_f16) return ATOM_ERR_INVALID_ARG;
+  if (!(clip > 0.f)) return ATOM_ERR_INVALID_ARG;
+  GemmParams p;
+  const int st = fill_params(p, partials_f32, B4, sB, sB, partials_f32, B8, sB, sB8, M, N_seg * nseg, K_total, group, keeper, ATOM_SCALE_LAYOUT_PLAIN);
+  if (st != ATOM_OK) return st;
+  if (!atom_gemm_w4a4_multi_merge_q_fits(M, N_seg, nseg, K_total, splits)) return ATOM_ERR_SHAPE;
+  if (!aligned16(out0) || (out1 && !aligned16(out1)) || (out2 && !aligned16(out2)) || (add0_f16 && !aligned16(add0_f16)) ||
+      (reorder_index && !aligned16(reorder_index)))
+    return ATOM_ERR_ALIGN;
+  p.A4 = nullptr; p.sA = nullptr; p.A8 = nullptr; p.sA8 = nullptr;
+  p.seg_out[0] = out0; p.seg_out[1] = out1; p.seg_out[2] = out2;
+  p.seg_add = (const half_t *)add0_f16;
+  p.seg_n = (int)N_seg;
+  p.seg_f32 = f32_mask;
+  p.q_op = 5;
+  p.q_x = nullptr; p.q_x2 = nullptr; p.q_res = nullptr; p.q_res_out = nullptr;
+  p.q_idx = reorder_index;
+  p.q_eps = 0.f; p.q_clip = clip;
+  p.q_part = (const float *)partials_f32;
+  p.q_splits = splits;
+  return launch_gemvq_multi_q(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 size_t atom_gemm_w4a4_o4_workspace_bytes(int64_t M, int64_t N, int64_t K_total) {

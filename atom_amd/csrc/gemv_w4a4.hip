@@ -171,6 +171,56 @@ __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
     w8[r] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)nr[r] * kKeeper + (lane & 7) * 16);
     sb8u[r] = reinterpret_cast<const unsigned short *>(p.sB8)[nr[r]];
   }
+  // Round 6: rows of at most two batches (K_total <= 4224: BASELINE config 2) request BOTH weight chunks -- the
+  // only HBM traffic of the wave -- before anything else, then both batches' activation chunks and scales (L2), and compute after:
+  // the run-time loop below issues batch 1's requests behind batch 0's arithmetic, i.e. two dependent trips to HBM per wave where
+  // the launch itself is 1.6 us of a 4 us kernel.  Same per-lane order (batch 0, then batch 1): same bits.
+  if (nchunks <= 128) {
+    const int cc0 = min(lane, nchunks - 1), cc1 = min(64 + lane, nchunks - 1);
+    v4i w0[R], w1[R], a0[MT], a1[MT];
+    unsigned short sb0[R], sb1[R], sa0[MT], sa1[MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w0[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)nr[r] * K4h + cc0 * 16));
+#pragma unroll
+    for (int r = 0; r < R; ++r) w1[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p.B4 + (int64_t)nr[r] * K4h + cc1 * 16));
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      a0[m] = *reinterpret_cast<const v4i *>(p.A4 + (int64_t)mr[m] * K4h + cc0 * 16);
+      a1[m] = *reinterpret_cast<const v4i *>(p.A4 + (int64_t)mr[m] * K4h + cc1 * 16);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      sb0[r] = sBu[(int64_t)(cc0 >> 2) * p.N + nr[r]];
+      sb1[r] = sBu[(int64_t)(cc1 >> 2) * p.N + nr[r]];
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      sa0[m] = sAu[(int64_t)(cc0 >> 2) * p.ldA + so[m]];
+      sa1[m] = sAu[(int64_t)(cc1 >> 2) * p.ldA + so[m]];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bool ok = b * 64 + lane < nchunks;
+      if (b == 1 && nchunks <= 64) break;                   // (wave-uniform: a single batch)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float saf = (float)__builtin_bit_cast(half_t, b ? sa1[m] : sa0[m]);
+        const v4i &am = b ? a1[m] : a0[m];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const v4i &wr = b ? w1[r] : w0[r];
+          int d = 0;
+          d = __builtin_amdgcn_sdot8(am[0], wr[0], d, false);
+          d = __builtin_amdgcn_sdot8(am[1], wr[1], d, false);
+          d = __builtin_amdgcn_sdot8(am[2], wr[2], d, false);
+          d = __builtin_amdgcn_sdot8(am[3], wr[3], d, false);
+          d = quad_sum(d);
+          const float next = __builtin_fmaf((float)d, saf * (float)__builtin_bit_cast(half_t, b ? sb1[r] : sb0[r]), acc[r][m]);
+          acc[r][m] = (leader && ok) ? next : acc[r][m];
+        }
+      }
+    }
+  } else
   for (int c0 = 0; c0 < nchunks; c0 += 64) {
     const int c = c0 + lane;
     const bool ok = c < nchunks;

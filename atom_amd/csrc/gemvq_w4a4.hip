@@ -50,7 +50,7 @@ __device__ __forceinline__ float max32(float a) {
 __host__ __device__ inline int red_offset(int K4h, int G) { return (MQ * K4h + MQ * kKeeper + MQ * G * 2 + MQ * 2 + 15) & ~15; }
 inline size_t lds_bytes(int q_op, int K4h, int G) {
   const int H = 2 * K4h + kKeeper;
-  return (size_t)red_offset(K4h, G) + 32 + (q_op <= 3 ? (size_t)H * 2 * (MQ + 1) : 0);
+  return (size_t)red_offset(K4h, G) + 32 + (q_op != 4 ? (size_t)H * 2 * (MQ + 1) : 0);
 }
 
 // One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 2 chunks per lane, a half or a quarter of
@@ -107,6 +107,11 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #define GQ_STAMP(k) do { } while (0)
 #endif
   GQ_STAMP(0);
+  // QOP 5 (round 6): the token rows are the decode attention's output still in KV-split form -- FP32 partial states [M][heads][splits]
+  // [128 values, m, d] (csrc/kv_i4.hip) -- merged here exactly as decode_merge_kernel merges them, then reordered and quantised as QOP 1
+  constexpr bool ROWS = QOP <= 3 || QOP == 5;               // ops that stage fp16 token rows in LDS (gathered through the reorder index)
+  constexpr bool NORM = QOP == 2 || QOP == 3;
+  constexpr int PS = 16, PH = 8;                            // QOP 5: KV splits at most (gemvq_merge_fits); their values in batches of PH
 
   // ---- everything the quantiser reads, requested first: one memory round trip for the whole prologue.  Whole waves without work
   // issue nothing (wave-uniform guards; a CU's vector-memory path takes ~20 cycles per wave instruction: the s_memtime trace of the
@@ -118,7 +123,12 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   constexpr int TPT = TPT1 * MT;
   v2u q_ri[TPT], q_rb[QOP == 4 ? TPT : 1];                  // per task: 4 reorder indices (ops 1-3) / 4 gate and 4 up values (op 4)
-  h8 q_xr[QOP <= 3 ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[QOP == 2 || QOP == 3 ? XC : 1];
+  h8 q_xr[ROWS ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[NORM ? XC : 1];
+  typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
+  v4f_u po[QOP == 5 ? PH : 1][2];                           // QOP 5: my chunk's 8 values of the first PH splits, and every split's (m, d)
+  v2f_u pmd[QOP == 5 ? PS : 1];
+  const float *pwp = nullptr;
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
     q_ri[t] = v2u{0u, 0u};
@@ -131,6 +141,21 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       } else if (p.q_idx) {
         q_ri[t] = *reinterpret_cast<const v2u *>(p.q_idx + e0);
       }
+    }
+  }
+  if constexpr (QOP == 5) {                                 // (one chunk per thread: M x K_total <= 8192, gemvq_merge_fits)
+    const int c = min(tid, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+    const float *wp = p.q_part + ((int64_t)(m * (H >> 7) + (cc >> 4)) * p.q_splits) * 130 + (cc & 15) * 8;
+    pwp = wp;
+#pragma unroll
+    for (int sp = 0; sp < PS; ++sp) {
+      const int sc = min(sp, p.q_splits - 1);
+      if (sp < PH) {
+        po[sp][0] = *reinterpret_cast<const v4f_u *>(wp + sc * 130);
+        po[sp][1] = *reinterpret_cast<const v4f_u *>(wp + sc * 130 + 4);
+      }
+      if (sp < PH || p.q_splits > PH) pmd[sp] = *reinterpret_cast<const v2f_u *>(wp + sc * 130 + 128 - (cc & 15) * 8);
+      else pmd[sp] = v2f_u{-INFINITY, 0.f};
     }
   }
   if constexpr (QOP <= 3) {
@@ -185,6 +210,12 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     asm volatile("" : "+v"(q_ri[t]));
     if constexpr (QOP == 4) asm volatile("" : "+v"(q_rb[t]));
   }
+  if constexpr (QOP == 5) {
+#pragma unroll
+    for (int sp = 0; sp < PH; ++sp) asm volatile("" : "+v"(po[sp][0]), "+v"(po[sp][1]));
+#pragma unroll
+    for (int sp = 0; sp < PS; ++sp) asm volatile("" : "+v"(pmd[sp]));
+  }
   if constexpr (QOP <= 3) {
 #pragma unroll
     for (int i = 0; i < XC; ++i) {
@@ -208,6 +239,43 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     char *rowbuf = reinterpret_cast<char *>(red + 8);                                     // [MQ][H] halves, then the norm weights [H]
     char *wbuf = rowbuf + MQ * H * 2;
     const int Gt = H >> 7;
+    if constexpr (QOP == 5) {
+      // out[dim] = sum_s o_s[dim] 2^(m_s - M) / sum_s d_s 2^(m_s - M), splits in order: decode_merge_kernel's operations, same bits
+      float M_ = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < PS; ++sp)
+        if (sp < p.q_splits) M_ = fmaxf(M_, pmd[sp][0]);
+      float acc[8], den = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int hb = 0; hb < PS / PH; ++hb) {
+        if (hb > 0) {
+          if (p.q_splits <= hb * PH) break;                  // (workgroup-uniform)
+#pragma unroll
+          for (int sp = 0; sp < PH; ++sp) {                  // the next batch of splits: one more trip to memory
+            const int sc = min(hb * PH + sp, p.q_splits - 1);
+            po[sp][0] = *reinterpret_cast<const v4f_u *>(pwp + sc * 130);
+            po[sp][1] = *reinterpret_cast<const v4f_u *>(pwp + sc * 130 + 4);
+          }
+        }
+#pragma unroll
+        for (int sp = 0; sp < PH; ++sp)
+          if (hb * PH + sp < p.q_splits) {
+            const v2f_u md = pmd[hb * PH + sp];
+            const float w = md[0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(md[0] - M_);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_fmaf(po[sp][k >> 2][k & 3], w, acc[k]);
+            den = __builtin_fmaf(md[1], w, den);
+          }
+      }
+      if (tid < p.M * q_nchunks) {
+        h8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (half_t)(den > 0.f ? acc[k] / den : 0.f);
+        *reinterpret_cast<h8 *>(rowbuf + tid * 16) = v;      // (chunk tid of the [M][H] rows: contiguous)
+      }
+    }
     if constexpr (QOP <= 3) {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
@@ -227,6 +295,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         for (int i = 0; i < XC; ++i)
           if (tid + i * NTH < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NTH) * 16) = q_wr[i];
       }
+    }
+    if constexpr (ROWS) {
       GQ_STAMP(2);                                             // the quantiser's inputs have arrived and sit in LDS
       lds_barrier();
       GQ_STAMP(3);
@@ -280,7 +350,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           for (int k = 0; k < CPT; ++k) {
             const int off = p.q_idx ? (int)iv[k] : e0 + k;
             const half_t xh = *reinterpret_cast<const half_t *>(rowbuf + m * H * 2 + off * 2);
-            if constexpr (QOP >= 2) {
+            if constexpr (NORM) {
               const half_t wg = *reinterpret_cast<const half_t *>(wbuf + off * 2);
               v[k] = (float)(half_t)(((float)xh * (float)wg) * rv);                    // RMSNorm.cuh:145-151
             } else {
@@ -447,8 +517,18 @@ bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t H) {
   return gemvq::lds_bytes(q_op, K4h, G) <= (size_t)128 * 1024;
 }
 
+// ... of the merge form (q_op 5): one 16-byte row chunk per thread (M x K_total <= 8192), at most 16 KV splits, K_total = heads x 128
+bool gemvq_merge_fits(int64_t M, int64_t N, int64_t H, int splits) {
+  if (splits < 2 || splits > 16 || M < 1 || M > gemvq::MQ || (H % 128) != 0 || M * (H >> 3) > gemvq::NTH) return false;
+  return gemvq_fits(1, M, N, H);
+}
+
 int launch_gemvq_multi_q(const GemmParams &p, hipStream_t s) {
   if (p.seg_n < 1 || (p.N % p.seg_n) != 0 || p.N / p.seg_n > 3 || !p.seg_out[0]) return ATOM_ERR_SHAPE;
+  if (p.q_op == 5) {
+    if (!gemvq_merge_fits(p.M, p.N, 2 * (int64_t)p.K4h + kKeeper, p.q_splits) || !p.q_part) return ATOM_ERR_SHAPE;
+    return gemvq::launch_mt<5>(p, s);
+  }
   if (!gemvq_fits(p.q_op, p.M, p.N, 2 * (int64_t)p.K4h + kKeeper)) return ATOM_ERR_SHAPE;
   switch (p.q_op) {
     case 1: return gemvq::launch_mt<1>(p, s);

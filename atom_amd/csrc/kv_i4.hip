@@ -566,21 +566,29 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   const int st = check_kv(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers, layer_idx,
                           num_heads, page_size, head_dim);
   if (st != ATOM_OK) return st;
-  if (!o || !q || !(rope_theta > 0.f) || !(rope_scale > 0.f)) return ATOM_ERR_INVALID_ARG;
-  if (!aligned16(o) || !aligned16(q)) return ATOM_ERR_ALIGN;
+  if (!q || !(rope_theta > 0.f) || !(rope_scale > 0.f)) return ATOM_ERR_INVALID_ARG;
+  if ((o && !aligned16(o)) || !aligned16(q)) return ATOM_ERR_ALIGN;
   int splits = decode_splits(batch, num_heads, max_pages_per_seq, page_size);
   const size_t need = (size_t)batch * num_heads * splits * (kHeadDim + 2) * sizeof(float);
   if (splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) splits = 1;
+  // o == NULL: the split partial states stay in the workspace un-merged (atom_batch_decode_i4_splits() of them; the consumer merges:
+  // atom_gemm_w4a4_multi_merge_q) -- only meaningful when the KV range IS split
+  if (!o && splits < 2) return ATOM_ERR_INVALID_ARG;
   DecodeParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
                   layer_idx, num_heads, page_size},
                  (const half_t *)q, (half_t *)o, (float *)workspace, splits,
                  1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale, k32, v32};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(batch_decode_kernel, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
-  if (splits > 1)
+  if (splits > 1 && o)
     hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace,
                        (half_t *)o, splits);
   return check_launch();
+}
+
+int atom_batch_decode_i4_splits(int batch, int num_heads, int page_size, int max_pages_per_seq) {
+  if (batch < 1 || num_heads < 1 || page_size < 16) return 0;
+  return decode_splits(batch, num_heads, max_pages_per_seq, page_size);
 }
 
 int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,

@@ -26,6 +26,11 @@ class DecodeFusion:
                  (False: one launch per projection, the reference's call order llama.py:259-292)
       kv_append  k / v quantised into the paged cache from the FP32 sums (False: the reference's op sequence _o4 GEMM -> append)
       kv_in_decode  ... by the attention launch itself (atom_batch_decode_append_i4, round 6; False: a launch of its own in front)
+      merge_in_o_proj  one or two tokens whose KV range is split over several waves: the split merge runs in front of o_proj's quantiser
+                 inside o_proj's launch (atom_gemm_w4a4_multi_merge_q, round 6) instead of the decode op's own merge launch.  Built,
+                 bit-identical, and SLOWER -- every one of o_proj's 256 workgroups re-reads the partial states of all heads from the other
+                 XCDs' memory side: the layer at batch 1 53.4 -> 57.2 us cold with 16 splits, 55.2 -> 56.6 with 8
+                 (profiles/r06/ab_merge_in_o_proj.txt) -- hence off by default.
       q_decode   one or two tokens: quantisers inside the GEMM that consumes them (atom_gemm_w4a4_multi_q)
       q_mask     ... which of the four (LlamaDecoderLayer._decode_fused_q): 1 input_layernorm -> q / k / v, 2 reorder -> o_proj,
                  4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 15 since round 6: the quantiser runs once per
@@ -35,6 +40,7 @@ class DecodeFusion:
     decode: bool = True
     kv_append: bool = True
     kv_in_decode: bool = True
+    merge_in_o_proj: bool = False
     q_decode: bool = True
     q_mask: int = 15
 
@@ -219,13 +225,14 @@ def rope_llama(x: torch.Tensor, pos: torch.Tensor, theta: float = 1e4) -> torch.
     return x * cos + rot * sin
 
 
-def _append_and_decode(fusion, q, k32, v32, decode_kv, layer_idx, rope_theta):
+def _append_and_decode(fusion, q, k32, v32, decode_kv, layer_idx, rope_theta, merge=True):
     """reference llama.py:168-196 for a pure decode step: this token's k / v into the INT4 paged cache, then attention over it -- one
-    launch (DecodeFusion.kv_in_decode) or two; the same cache bytes and the same output either way."""
+    launch (DecodeFusion.kv_in_decode) or two; the same cache bytes and the same output either way.  ``merge=False``: the KV-split
+    partial states instead of the output (ops.batch_decode_i4)."""
     if fusion.kv_in_decode:
-        return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta, append_kv=(k32, v32))
+        return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta, append_kv=(k32, v32), merge=merge)
     ops.quant_append_kv_i4(decode_kv, k32, v32, layer_idx)
-    return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta)
+    return ops.batch_decode_i4(q, decode_kv, layer_idx, rope_theta=rope_theta, merge=merge)
 
 
 class LlamaAttention(nn.Module):
@@ -340,11 +347,17 @@ class LlamaDecoderLayer(nn.Module):
         else:
             outlier, norms, outlier_scales, norm_scales = il(hidden_states)
             q, k32, v32 = ops.dense_layer_gemm_i4_multi(norms, norm_scales, outlier, outlier_scales, at._decode_qkv(), f32_mask=0b110)
-        o = _append_and_decode(self.fusion, q.view(rows, at.num_heads, at.head_dim), k32, v32, decode_kv, at.layer_idx, at.rope_theta).view(rows, hs)
-        if mask & 2:
-            (attn,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o, at.o_proj.single(), reorder_index=at.reorder_index)
+        splits = ops.decode_splits(rows, decode_kv) if (mask & 2) and self.fusion.merge_in_o_proj else 1
+        if splits >= 2 and ops.merge_q_gemm_fits(rows, hs, 1, hs, splits):
+            # the KV-split merge in front of o_proj's quantiser, inside o_proj's launch (round 6): same bits, a launch fewer
+            part = _append_and_decode(self.fusion, q.view(rows, at.num_heads, at.head_dim), k32, v32, decode_kv, at.layer_idx, at.rope_theta, merge=False)
+            (attn,) = ops.dense_layer_gemm_i4_merge_q(part, splits, at.o_proj.single(), reorder_index=at.reorder_index)
         else:
-            attn = at.o_proj(ops.reorder_fp16_i4(o, at.reorder_index))
+            o = _append_and_decode(self.fusion, q.view(rows, at.num_heads, at.head_dim), k32, v32, decode_kv, at.layer_idx, at.rope_theta).view(rows, hs)
+            if mask & 2:
+                (attn,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o, at.o_proj.single(), reorder_index=at.reorder_index)
+            else:
+                attn = at.o_proj(ops.reorder_fp16_i4(o, at.reorder_index))
         if mask & 4:
             (gate, up), residual = ops.dense_layer_gemm_i4_multi_q("add_rmsnorm", attn, mlp._decode_gate_up(), residual=hidden_states, x2=pl.weight,
                                                                    reorder_index=pl.reorder_index, eps=pl.variance_epsilon)

@@ -487,6 +487,36 @@ def dense_layer_gemm_i4_multi_q(q_op: str, x, fused, *, x2=None, residual=None, 
     return tuple(outs), res_out
 
 
+def merge_q_gemm_fits(m: int, n_seg: int, nseg: int, k: int, splits: int) -> bool:
+    """True when dense_layer_gemm_i4_merge_q takes the shape and the KV-split count (atom_gemm_w4a4_multi_merge_q_fits)."""
+    return bool(L.lib().atom_gemm_w4a4_multi_merge_q_fits(int(m), int(n_seg), int(nseg), int(k), int(splits)))
+
+
+def dense_layer_gemm_i4_merge_q(partials: torch.Tensor, splits: int, fused, *, reorder_index=None, clip=1.0, f32_mask=0, add=None):
+    """NEW (round 6; decode steps of one or two tokens, no reference counterpart): dense_layer_gemm_i4_multi_q("reorder", ...) on the
+    decode attention's output while that is still in KV-split form -- ``partials`` float32 [M, heads, splits, 130] as
+    ``batch_decode_i4(..., merge=False)`` returns it --, the split merge running in front of the reorder quantiser inside the
+    projection's launch.  Bit-identical to batch_decode_i4 (merged) -> dense_layer_gemm_i4_multi_q("reorder", ...).  Returns outs."""
+    if not partials.is_cuda:
+        raise L.AtomHipError("merge_q needs GPU tensors: no CPU fallback")
+    n, nseg, k = fused["n_seg"], fused["nseg"], fused["k"]
+    m = partials.size(0)
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape == (m, k // 128, splits, 130)
+    outs = [torch.empty((m, n), dtype=torch.float32 if (f32_mask >> i) & 1 else torch.float16, device=partials.device) for i in range(nseg)]
+    if reorder_index is not None:
+        assert reorder_index.dtype == torch.int16 and reorder_index.numel() == k and reorder_index.is_cuda
+    if add is not None:
+        _require_cuda_half(add, "add")
+        assert add.shape == (m, n) and add.is_contiguous()
+    st = L.lib().atom_gemm_w4a4_multi_merge_q(partials.data_ptr(), int(splits), L.ptr(reorder_index), float(clip), fused["b4"].data_ptr(),
+                                              fused["sb"].data_ptr(), fused["b8"].data_ptr(), fused["sb8"].data_ptr(), outs[0].data_ptr(),
+                                              outs[1].data_ptr() if nseg > 1 else None, outs[2].data_ptr() if nseg > 2 else None,
+                                              int(f32_mask), L.ptr(add), m, n, nseg, k, GROUP_SIZE, GROUP_SIZE,
+                                              L.current_stream(partials.device))
+    L.check(st, "atom_gemm_w4a4_multi_merge_q")
+    return tuple(outs)
+
+
 def quant_weight_w4(weight: torch.Tensor, w_clip: float = 0.85, channel_group: int = 2, return_fake_quant=False):
     """NEW (no reference counterpart): quantise + pack a (column-reordered) FP16 weight [N,K] the
     way QLinearLayer.quant does (qLinearLayer.py:42-78).  Returns (B4 u8[N,K4/2], B8 i8[N,128], sB f16[G,N],
@@ -581,20 +611,34 @@ def quant_append_kv_i4(kv, k_f32: torch.Tensor, v_f32: torch.Tensor, layer_idx: 
     L.check(st, "atom_kv_quant_append_f32")
 
 
-def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0, append_kv=None):
+def decode_splits(batch: int, kv) -> int:
+    """How many waves share a (sequence, head)'s KV range in batch_decode_i4 for this cache (1: no split)."""
+    num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
+    return int(L.lib().atom_batch_decode_i4_splits(int(batch), num_heads, page_size, int(getattr(kv, "max_pages", 0))))
+
+
+def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 1e4, rope_scale: float = 1.0, append_kv=None, merge=True):
     """Decode attention over the INT4 paged cache, RoPE fused.  Reference: punica/ops/__init__.py:21-30 ->
     FlashInferBatchDecodeKernel_i4 (rope_theta 1e4, rope_scale 1 hard-coded there).  q fp16 [batch, heads, 128].
     ``append_kv=(k_f32, v_f32)`` (round 6): quant_append_kv_i4 of this step's FP32 k / v projections inside the same launch
-    (atom_batch_decode_append_i4) -- same cache contents, same output, one launch fewer."""
+    (atom_batch_decode_append_i4) -- same cache contents, same output, one launch fewer.
+    ``merge=False`` (only where decode_splits(batch, kv) >= 2): no merge launch -- returns the split partial states float32
+    [batch, heads, splits, 130] (a tensor of their own, not the shared workspace) for dense_layer_gemm_i4_merge_q."""
     _require_cuda_half(q, "q")
     num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
     batch = q.size(0)
     assert q.shape == (batch, num_heads, head_dim)
-    o = torch.empty_like(q)
     lib = L.lib()
     max_pages = int(getattr(kv, "max_pages", 0))
     ws_bytes = lib.atom_batch_decode_i4_workspace_bytes(batch, num_heads, page_size, max_pages)
-    ws = _workspace(q.device, ws_bytes) if ws_bytes else None
+    if not merge:
+        splits = lib.atom_batch_decode_i4_splits(batch, num_heads, page_size, max_pages)
+        assert splits >= 2 and ws_bytes == batch * num_heads * splits * 130 * 4, "merge=False needs a split KV range (decode_splits)"
+        part = torch.empty((batch, num_heads, splits, 130), dtype=torch.float32, device=q.device)
+        o, ws = None, part
+    else:
+        o = torch.empty_like(q)
+        ws = _workspace(q.device, ws_bytes) if ws_bytes else None
     if append_kv is not None:
         k32, v32 = append_kv
         for t in (k32, v32):
@@ -602,19 +646,19 @@ def batch_decode_i4(q: torch.Tensor, kv, layer_idx: int, *, rope_theta: float = 
                 raise L.AtomHipError("KV-cache operands must live on the GPU: no CPU fallback")
             assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (batch, num_heads * head_dim)
         assert batch == kv.last_page_offset.numel()
-        st = lib.atom_batch_decode_append_i4(o.data_ptr(), q.data_ptr(), k32.data_ptr(), v32.data_ptr(), kv.data.data_ptr(),
+        st = lib.atom_batch_decode_append_i4(L.ptr(o), q.data_ptr(), k32.data_ptr(), v32.data_ptr(), kv.data.data_ptr(),
                                              kv.param.data_ptr(), kv.indptr.data_ptr(), kv.indicies.data_ptr(),
                                              kv.last_page_offset.data_ptr(), batch, num_layers, int(layer_idx), num_heads, page_size,
                                              head_dim, float(rope_theta), float(rope_scale), max_pages, L.ptr(ws), ws_bytes,
                                              L.current_stream(q.device))
         L.check(st, "atom_batch_decode_append_i4")
-        return o
-    st = lib.atom_batch_decode_i4(o.data_ptr(), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
+        return o if merge else part
+    st = lib.atom_batch_decode_i4(L.ptr(o), q.data_ptr(), kv.data.data_ptr(), kv.param.data_ptr(),
                                   kv.indptr.data_ptr(), kv.indicies.data_ptr(), kv.last_page_offset.data_ptr(), batch,
                                   num_layers, int(layer_idx), num_heads, page_size, head_dim, float(rope_theta),
                                   float(rope_scale), max_pages, L.ptr(ws), ws_bytes, L.current_stream(q.device))
     L.check(st, "atom_batch_decode_i4")
-    return o
+    return o if merge else part
 
 
 def kv_fake_quant(x: torch.Tensor, n_bits: int = 4, clip: float = 1.0) -> torch.Tensor:

@@ -260,6 +260,18 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
 #define ATOM_Q_RMSNORM 2
 #define ATOM_Q_ADD_RMSNORM 3
 #define ATOM_Q_SILU_MUL 4
+/* The same launch with the decode attention's KV-split merge in front of the reorder quantiser (round 6): `partials_f32` = the
+ * workspace atom_batch_decode_append_i4 / atom_batch_decode_i4 filled when called with o == NULL -- float [M][heads][splits][130] =
+ * 128 un-normalised values, the running maximum m (base 2) and the denominator d per (token, head, split), heads = K_total / 128 --
+ * merged as the decode op's own merge launch does (out = sum_s o_s 2^(m_s - M) / sum_s d_s 2^(m_s - M), splits in order), rounded to
+ * fp16, then reordered, quantised and multiplied as ATOM_Q_REORDER: bit-identical to batch_decode (merged) -> atom_gemm_w4a4_multi_q
+ * (ATOM_Q_REORDER), two launch boundaries of a decode step fewer (the reference: punica/models/llama.py:168-196 batch_decode ->
+ * reorder_fp16_i4 -> o_proj).  2 .. 16 splits, one or two tokens, M x K_total <= 8192: atom_gemm_w4a4_multi_merge_q_fits. */
+int atom_gemm_w4a4_multi_merge_q_fits(int64_t M, int64_t N_seg, int nseg, int64_t K_total, int splits);
+int atom_gemm_w4a4_multi_merge_q(const void *partials_f32, int splits, const int16_t *reorder_index, float clip, const void *B4, const void *sB,
+                                 const void *B8, const void *sB8, void *out0, void *out1, void *out2, unsigned f32_mask,
+                                 const void *add0_f16, int64_t M, int64_t N_seg, int nseg, int64_t K_total, int group, int keeper,
+                                 void *stream);
 /* 1 when atom_gemm_w4a4_multi_q takes (q_op, M, N_seg, nseg, K_total): the launcher's own predicate -- one or two tokens, K_total <=
  * 12,288 (three 4-channel quantiser tasks per thread of the 1024 and token row), for the three ops that stage fp16 rows and the norm
  * weight in LDS M x K_total <= 16,384, and a shape atom_gemm_w4a4_multi takes. */
@@ -404,6 +416,10 @@ int atom_kv_quant_append_f32(void *kv_data, void *kv_param, const int32_t *kv_in
  * unknown) lets long sequences at small batch split their KV range over several waves: FP32 partial states go to
  * `workspace` (atom_batch_decode_i4_workspace_bytes; NULL / too small = no split) and a second launch merges them. */
 size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_size, int max_pages_per_seq);
+/* ... how many waves share a (sequence, head)'s KV range for these arguments (1 = no split, no workspace use).  With o == NULL and a
+ * split count >= 2 the two decode entry points leave the partial states in the workspace UN-merged, as float [batch][heads][splits][130]
+ * (128 un-normalised values, running maximum, denominator), for a consumer that merges them itself: atom_gemm_w4a4_multi_merge_q. */
+int atom_batch_decode_i4_splits(int batch, int num_heads, int page_size, int max_pages_per_seq);
 int atom_batch_decode_i4(void *o, const void *q, const void *kv_data, const void *kv_param, const int32_t *kv_indptr,
                          const int32_t *kv_indices, const int32_t *last_page_offset, int batch, int num_layers,
                          int layer_idx, int num_heads, int page_size, int head_dim, float rope_theta, float rope_scale,

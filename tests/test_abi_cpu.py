@@ -129,23 +129,29 @@ def test_dispatch_queries_are_consistent_over_random_shapes():
 
 
 def test_fused_quantiser_shape_query():
-    """atom_gemm_w4a4_multi_q_fits(q_op, ...): one or two tokens, the shapes atom_gemm_w4a4_multi takes, and the launcher's own bounds
-    per quantiser (gemm_w4a4_skinny.hip skinny_q_fits): per thread of the 512 at most two 16-channel slot tasks (SiLU x up: three), at
-    most three 16-byte chunks of the fp16 rows and two of the norm weight (ops 1-3)."""
+    """atom_gemm_w4a4_multi_q_fits(q_op, ...): one or two tokens, the shapes atom_gemm_w4a4_multi takes, and the launcher's own bounds.
+    Round 6 (csrc/gemvq_w4a4.hip: 1024 threads per workgroup): per thread at most three 4-channel quantiser tasks per token row
+    (K_total <= 12,288) and, for the three ops that stage fp16 rows and the norm weight in LDS, two 16-byte row chunks (M x K_total <=
+    16,384); at most 8 weight chunks per lane.  The merge form (atom_gemm_w4a4_multi_merge_q_fits): 2 .. 16 KV splits, M x K_total <= 8192."""
     from atom_amd import _lib
     L = _lib.lib()
-    fq, fm = L.atom_gemm_w4a4_multi_q_fits, L.atom_gemm_w4a4_multi_fits
+    fq, fm, fmq = L.atom_gemm_w4a4_multi_q_fits, L.atom_gemm_w4a4_multi_fits, L.atom_gemm_w4a4_multi_merge_q_fits
     RE, RN, AR, SM = _lib.Q_REORDER, _lib.Q_RMSNORM, _lib.Q_ADD_RMSNORM, _lib.Q_SILU_MUL
     assert fq(RN, 1, 4096, 3, 4096) == 1 and fq(RE, 2, 4096, 1, 4096) == 1 and fq(AR, 1, 11008, 2, 4096) == 1 and fq(SM, 2, 4096, 1, 11008) == 1
     assert fq(RE, 3, 4096, 1, 4096) == 0 and fq(RE, 0, 4096, 1, 4096) == 0 and fm(3, 4096, 1, 4096) == 1
     assert fq(0, 1, 4096, 1, 4096) == 0 and fq(5, 1, 4096, 1, 4096) == 0
-    assert fq(SM, 2, 5120, 1, 13824) == 0 and fq(SM, 1, 5120, 1, 13824) == 1          # 2 x 864 slots > 3 x 512
+    # 13824 / 4 tasks per row > 3 x 1024: not the dot-product form; one token still fits the decode-batch form (864 slots <= 3 x 512)
+    assert fq(SM, 2, 5120, 1, 13824) == 0 and fq(SM, 1, 5120, 1, 13824) == 1
+    assert fq(SM, 1, 5120, 1, 12288) == 1 and fq(SM, 2, 5120, 1, 12288) == 1
     assert fq(RE, 1, 4096, 4, 4096) == 0 and fq(RE, 1, 24, 1, 4096) == 0 and fq(RE, 1, 4096, 1, 4000) == 0
-    # the round-3 advisor's cases: two tokens at hidden 6656 / 8192 / 11008 -- only SiLU x up fits (no rows staged in LDS)
+    # two tokens: the row-staging ops up to hidden 8192 (M x K / 8 <= 2048 chunks), SiLU x up beyond
     for h in (6656, 8192, 11008):
-        assert fq(RE, 2, 4096, 1, h) == 0 and fq(RN, 2, 4096, 1, h) == 0 and fq(AR, 2, 4096, 1, h) == 0 and fq(SM, 2, 4096, 1, h) == 1
-        assert fq(RE, 1, 4096, 1, h) == (1 if h <= 8192 else 0)                      # one row: h / 8 chunks <= 2 x 512
-    assert fq(RE, 2, 4096, 1, 6144) == 1 and fq(RE, 2, 4096, 1, 6272) == 0                # M * K / 8 <= 1536
+        ok = 1 if h <= 8192 else 0
+        assert fq(RE, 2, 4096, 1, h) == ok and fq(RN, 2, 4096, 1, h) == ok and fq(AR, 2, 4096, 1, h) == ok and fq(SM, 2, 4096, 1, h) == 1
+        assert fq(RE, 1, 4096, 1, h) == 1
+    assert fq(RE, 2, 4096, 1, 8192) == 1 and fq(RE, 2, 4096, 1, 8320) == 0
+    assert fmq(1, 4096, 1, 4096, 8) == 1 and fmq(1, 4096, 1, 4096, 16) == 1 and fmq(2, 4096, 1, 4096, 4) == 1 and fmq(1, 8192, 1, 8192, 2) == 1
+    assert fmq(1, 4096, 1, 4096, 1) == 0 and fmq(1, 4096, 1, 4096, 17) == 0 and fmq(2, 4096, 1, 8192, 8) == 0 and fmq(3, 4096, 1, 4096, 8) == 0
 
 
 def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):

@@ -340,6 +340,56 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     assert torch.equal(outs[0], outs[1])                      # (round 6: batch 1 included -- see csrc/gemvq_w4a4.hip)
 
 
+@pytest.mark.parametrize("bsz,ctx", [(1, 300), (2, 130), (1, 1030)])
+def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
+    """Round 6: with the KV range of a decode step split over several waves (long contexts at small batches), the decode op leaves its
+    partial states un-merged and o_proj's launch merges them in front of its reorder quantiser (atom_gemm_w4a4_multi_merge_q).  The op
+    against batch_decode_i4 (merge launch) -> dense_layer_gemm_i4_multi_q("reorder"), and a whole decode layer with and without it:
+    bit for bit (4 / 8 / 16 splits here; the second batch of eight splits is a second trip to memory inside the launch)."""
+    import atom_amd.e2e.llama as E
+    from atom_amd import ops
+    from atom_amd.e2e import LlamaDecoderLayer
+    from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    torch.manual_seed(11)
+    cfg = _attn_cfg()
+    dev = torch.device("cuda")
+    layer = LlamaDecoderLayer(cfg, layer_idx=0).cuda()
+    _load_layer(layer, 13)
+    x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
+    outs, caches = [], []
+    nblk = bsz * (ctx // 16 + 2)
+    for fused in (False, True):
+        E.FUSION.merge_in_o_proj = fused
+        try:
+            pool = KvPoolInt4(num_layers=1, num_heads=4, head_dim=128, capacity=nblk, block_len=16, device=dev)
+            g = torch.Generator(device="cuda").manual_seed(9)
+            pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
+            pool.param.copy_((torch.rand(pool.param.shape, device=dev, generator=g) * 0.05 + 0.01).half())
+            pool._free = set(range(nblk))
+            cs = [KvCacheInt4(pool, ctx) for _ in range(bsz)]
+            for c in cs:
+                c.acquire_one()
+            kv = BatchedKvCacheInt4(cs)
+            if fused:
+                splits = ops.decode_splits(bsz, kv)
+                assert splits >= 2 and ops.merge_q_gemm_fits(bsz, cfg.hidden_size, 1, cfg.hidden_size, splits), splits
+            outs.append(layer(x, BatchLenInfo([], bsz, dev), None, kv))
+            caches.append((pool.buf.clone(), pool.param.clone()))
+        finally:
+            E.FUSION.merge_in_o_proj = False
+    assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
+    assert torch.equal(outs[0], outs[1])
+    # the op itself, on the partial states of a decode over the cache just written
+    at = layer.self_attn
+    q = (torch.randn(bsz, 4, 128, device=dev)).half()
+    part = ops.batch_decode_i4(q, kv, 0, merge=False)
+    o = ops.batch_decode_i4(q, kv, 0)
+    add = (torch.randn(bsz, cfg.hidden_size, device=dev) * 2).half()
+    (want,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o.view(bsz, -1), at.o_proj.single(), reorder_index=at.reorder_index, add=add)
+    (got,) = ops.dense_layer_gemm_i4_merge_q(part, ops.decode_splits(bsz, kv), at.o_proj.single(), reorder_index=at.reorder_index, add=add)
+    assert torch.equal(got, want)
+
+
 def test_fused_quantiser_query_is_the_launchers_predicate_at_wide_hidden_sizes():
     """Round-3 advisor item: the shape query of atom_gemm_w4a4_multi_q and its launchers share ONE predicate -- what the query accepts
     launches, what it refuses raises (it used to say yes to shapes the launch then failed on), and a decode layer asks it per batch size.
