@@ -31,17 +31,16 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
 static int gemv_max_m() { return ATOM_TUNE("ATOM_GEMV_MAXM", 7); }
 // Up to this many tokens EVERY GEMM entry point (fp16, FP32 sums, segmented) runs the few-token dot-product kernel (gemv_w4a4.hip
 // gemv1_w4a4_kernel: the weights streamed once at full occupancy, each token's sum in the one-token kernel's order); above it the
-// MFMA decode-batch kernel.  One or two tokens -- round 6: two tokens at every K (rounds 4-5: where K is long), so that a decode step
-// of two tokens runs its projections with the quantisers in front of this kernel (gemvq_w4a4.hip; the decode-batch kernel behind a
-// quantiser runs a Llama-7B layer at batch 2 in 77 us, this one in 6x us: profiles/r06/) at the price of 0.2 us where a lone
-// 2 x 4096 x 4096 GEMM is called (measured cold, us, dot-product | decode-batch kernel:
+// MFMA decode-batch kernel.  One token always; two tokens where K is long (measured cold, us, dot-product | decode-batch kernel:
 // 2 x 5120 x 13824 12.5 | 17.5, 2 x 4096 x 11008 8.0 | 8.6, 2 x 5120 x 5120 6.6 | 7.0, 2 x 4096 x 4096 4.6 | 4.4; from three tokens
 // the per-token VALU work loses everywhere: 3 x 13824 x 5120 13.9 | 11.7; profiles/r04/decode_small_m.txt).  The rule depends on
-// (M, K) only, so the projections that share an activation take the same kernel through every entry point.
+// (M, K) only, so the projections that share an activation take the same kernel through every entry point.  (Round 6 tried two tokens
+// on the dot-product kernel at every K, for the sake of the quantiser-in-front launch of gemvq_w4a4.hip: a Llama-7B layer at batch 2
+// then takes 69-71 us cold against 66.6 with this rule and separate quantiser launches -- two tokens double the kernel's VALU work per
+// weight chunk -- so the rule stayed and the decode layer fuses its quantisers at ONE token only.)
 static int gemv_tokens(int64_t K_total) {
   const int forced = ATOM_TUNE("ATOM_GEMV_TOKENS", 0);       // (tuning builds)
-  const int t = forced > 0 ? forced : 2;                     // (rounds 4-5: two tokens only where K > 4096)
-  (void)K_total;
+  const int t = forced > 0 ? forced : (K_total > 4096 ? 2 : 1);
   return t > kGemvMaxTokens ? kGemvMaxTokens : t;
 }
 

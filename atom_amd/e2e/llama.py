@@ -36,13 +36,17 @@ class DecodeFusion:
                  4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 15 since round 6: the quantiser runs once per
                  CU in front of the dot-product kernel (csrc/gemvq_w4a4.hip) and every one of the four pays -- a Llama-7B layer at batch 1,
                  cold: 60.8 us with the four quantisers as launches of their own, 5x.x us with them inside (profiles/r06/decode_layer_hot_cold.txt).
-                 (Rounds 3-5 ran it in every 16-feature workgroup of the decode-batch kernel: only reorder -> o_proj paid, default 2.)"""
+                 (Rounds 3-5 ran it in every 16-feature workgroup of the decode-batch kernel: only reorder -> o_proj paid, default 2.)
+      q_mask2    the same choice for a step of TWO tokens: their projections with K <= 4096 run the decode-batch kernel (two tokens double
+                 the dot-product kernel's arithmetic per weight chunk), where only reorder -> o_proj pays: default 2 (66-67 us per layer
+                 cold; 15 measures 69-71)"""
     decode: bool = True
     kv_append: bool = True
     kv_in_decode: bool = True
     merge_in_o_proj: bool = False
     q_decode: bool = True
     q_mask: int = 15
+    q_mask2: int = 2
 
 
 FUSION = DecodeFusion()
@@ -369,6 +373,9 @@ class LlamaDecoderLayer(nn.Module):
             return out
         return mlp.down_proj.forward_add(ops.activate_fp16_i4(gate, up), residual)
 
+    def _q_mask_for(self, rows):
+        return self.fusion.q_mask if rows <= 1 else self.fusion.q_mask2
+
     def _fused_q_fits(self, rows):
         """every projection of the layer is a shape atom_gemm_w4a4_multi_q takes at this batch size (asked once per batch size)"""
         ok = getattr(self, "_fq_ok", None)
@@ -378,7 +385,7 @@ class LlamaDecoderLayer(nn.Module):
             hs, inter = self.hidden_size, self.mlp.intermediate_size
             # only the ops the mask selects have to fit (each with ITS quantiser's bounds); the others run as separate launches
             need = (("rmsnorm", hs, 3, hs), ("reorder", hs, 1, hs), ("add_rmsnorm", inter, 2, hs), ("silu_mul", hs, 1, inter))
-            ok[rows] = all(ops.multi_q_gemm_fits(q, rows, n, nseg, k) for bit, (q, n, nseg, k) in enumerate(need) if (self.fusion.q_mask >> bit) & 1)
+            ok[rows] = all(ops.multi_q_gemm_fits(q, rows, n, nseg, k) for bit, (q, n, nseg, k) in enumerate(need) if (self._q_mask_for(rows) >> bit) & 1)
             # the launches that take the un-fused operands in _decode_fused_q
             ok[rows] = ok[rows] and ops.multi_gemm_fits(rows, hs, 3, hs) and ops.multi_gemm_fits(rows, inter, 2, hs) and ops.multi_gemm_fits(rows, hs, 1, inter)
         return ok[rows]
@@ -386,9 +393,9 @@ class LlamaDecoderLayer(nn.Module):
     def forward(self, hidden_states, blen: BatchLenInfo, prefill_kv, decode_kv) -> torch.Tensor:
         rows = hidden_states.size(0) if torch.is_tensor(hidden_states) else 0
         fu = self.fusion
-        if (fu.q_decode and fu.q_mask and fu.decode and fu.kv_append and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
+        if (fu.q_decode and self._q_mask_for(rows) and fu.decode and fu.kv_append and 0 < rows <= 2 and hidden_states.dim() == 2 and hidden_states.is_contiguous()
                 and len(blen.prefills) == 0 and blen.decode == rows and decode_kv is not None and self._fused_q_fits(rows)):
-            return self._decode_fused_q(hidden_states, decode_kv, fu.q_mask)
+            return self._decode_fused_q(hidden_states, decode_kv, self._q_mask_for(rows))
         attn = self.self_attn(self.input_layernorm(hidden_states), blen, prefill_kv, decode_kv)
         residual, normed = self.post_attention_layernorm.forward_add(attn, hidden_states)   # fused residual add
         return self.mlp(normed, residual=residual)                                           # ... and the second one (decode: in down_proj's launch)

@@ -6,7 +6,7 @@ One "step" = one launch of atom_gemm_w4a4_f16 (through the C ABI) on the headlin
 int4/int8 codes and U(0.005,0.05) fp16 scales (never zeros: zero data clocks ~19 % higher).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--M 4096 --N 4096 --K 4096] [--format f6|packed|wide] [--no-cpu-baseline]
-                    [--no-configs] [--no-block] [--workload gemm|block]
+                    [--no-configs] [--no-block] [--no-decode] [--workload gemm|block]
                     [--ramp 1500]   (untimed set-up launches ahead of the W warm-up steps: power-state ramp after idle;
                                      reported as "ramp" in the JSON line)
 
@@ -312,7 +312,7 @@ def block_workload(args, rank, world, dev):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    r = block_bench.run(bsz=32, seq=2048, iters=steps, warmup=max(1, min(args.warmup, 3)), verbose=False)
+    r = block_bench.run(bsz=32, seq=2048, iters=steps, warmup=max(1, min(args.warmup, 3)), verbose=False, check=True)
     torch.cuda.synchronize(dev)
     # beside it: the same block with the attention opt-in of the configuration namespace (args.attn_sdpa: torch's fused attention
     # instead of the reference's materialised 32 x 32 x 2048 x 2048 score tensor -- same mathematics, not part of the W4A4 hot path)
@@ -334,6 +334,13 @@ def block_workload(args, rank, world, dev):
                           "parallelism": f"replicas x{world}"},
                "block_ms": round(block_ms, 3), "gemm_ms": round(gemm_ms, 3), "gemm_share": round(gemm_ms / block_ms, 4),
                "module_ms": r["spans"],
+               # the timed model is the model of tests/golden/llama_block_7b_wide.npz: its seven projections on the unmodified reference's
+               # own inputs (256 token rows) against the reference's own outputs (256 features each) -- tools/block_bench.py golden_check
+               "golden_check": {"rows": 256, "features_per_projection": 256,
+                                "rel_frobenius": {k: float(f"{v[0]:.3e}") for k, v in r.get("golden", {}).items()},
+                                "worst_element": {k: float(f"{v[1]:.3e}") for k, v in r.get("golden", {}).items()},
+                                "bounds": {"rel_frobenius": 1e-3, "worst_element": 1e-2},
+                                "ok": bool(r.get("golden")) and all(v[0] <= 1e-3 and v[1] <= 1e-2 for v in r["golden"].values())},
                "block_ms_attn_sdpa": round(r2["block_ms"], 3), "gemm_ms_attn_sdpa": round(r2["gemm_ms"], 3),
                "roofline": {"bound": "mfma", "achieved": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12, 2), "peak": PEAK_I8_TOPS,
                             "unit": "TFLOP/s", "frac": round(r["gemm_ops"] / (gemm_ms * 1e-3) / 1e12 / PEAK_I8_TOPS, 4),
@@ -371,6 +378,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the side sweep over the other BASELINE configs (N=1 only)")
     ap.add_argument("--with-block", action="store_true", help="(the default since round 5; kept so that older command lines parse)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode-layer key (tools/cold_bench.py layer 1,16 in its own process, ~20 s)")
     ap.add_argument("--no-block", action="store_true", help="skip --workload block (BASELINE configs[3]: one Llama-7B block at batch 32 x "
                                                               "seq 2048, its own process; ~1 minute), whose numbers otherwise go into "
                                                               "the line's `block` key (N=1 only)")
@@ -597,6 +605,7 @@ def main():
                                 "attention_and_rest_ms": round(b["block_ms"] - b["gemm_ms"] - quant_ms, 3),
                                 "gemm_share": b["gemm_share"], "module_ms": mm,
                                 "block_ms_attn_sdpa": b.get("block_ms_attn_sdpa"), "gemm_ms_attn_sdpa": b.get("gemm_ms_attn_sdpa"),
+                                "golden_check": b.get("golden_check"),
                                 "note": "one QLlamaDecoderLayer forward (model/qLlamaLayer.py:86-127 mirrored) at batch 32 x seq 2048; gemm_ms = "
                                         "q/k/v/o projections + the MLP module (gate / up / SiLU x up / its quantiser in one launch, then down_proj); "
                                         "quantiser_ms = the two RMSNorm -> reorder -> quantise launches (the o_proj and down_proj quantisers run "
@@ -605,6 +614,28 @@ def main():
                                         "*_attn_sdpa = the same block with the opt-in args.attn_sdpa (torch's fused attention)"}
             except Exception as e:                               # pragma: no cover
                 out["block"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
+        if world == 1 and not args.no_decode:                    # the decode step of a Llama-7B layer (reference punica/models/llama.py:259-292):
+            import subprocess                                    # its own process too (tools/cold_bench.py: HIP-graph replay, hot / cold)
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_bench.py"), "layer", "1,16"], capture_output=True, text=True)
+            try:
+                rows = {}
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("batch"):
+                        f = ln.split()
+                        rows[f"batch_{int(f[1].rstrip(':'))}"] = {"hot_us": float(f[3]), "cold_us": float(f[6]),
+                                                                  "cold_frac_hbm": round(12.6 / float(f[6]), 3)}
+                assert rows
+                out["decode_layer"] = {"config": "Llama-7B decoder layer (atom_amd.e2e.LlamaDecoderLayer), one decode step, context 1024, INT4 "
+                                                 "paged KV, HIP-graph replay, us per layer", **rows,
+                                       "weight_stream_us_at_8TBps": 12.6,
+                                       "note": "hot = one layer replayed (its 101 MB of weights stay in the Infinity Cache); cold = 8 distinct "
+                                               "layers per replay, every launch streams its weights from HBM; cold_frac_hbm = 12.6 us (the "
+                                               "layer's weight bytes at 8 TB/s) / cold_us.  Batch 1: six launches since round 6 (the four "
+                                               "activation quantisers inside their projections' launches, csrc/gemvq_w4a4.hip; KV quant + "
+                                               "append inside the attention launch) -- round 5: ten, 55.3 / 59.7 us"}
+            except Exception as e:                               # pragma: no cover
+                out["decode_layer"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N, K)
         print(json.dumps(out), flush=True)

@@ -252,7 +252,8 @@ int atom_gemm_w4a4_multi(const void *A4, const void *B4, const void *sA, const v
  *          ATOM_Q_SILU_MUL     x2 = the second factor [M, K_total]; no reorder index  = atom_silu_mul_quant_f16
  * in the kernel-flavoured arithmetic (quant_mode 0), clip as there.  Outputs, segments, f32_mask, add0_f16 as atom_gemm_w4a4_multi.
  * The quantised operand is bit-identical to the quantiser op's, and the sums are formed in the order atom_gemm_w4a4_multi uses for the
- * token count (one and two tokens: the dot-product kernel's, atom_gemm_w4a4_packed_order = 64): the outputs are bit-identical to the
+ * shape (atom_gemm_w4a4_packed_order: 64, the dot-product kernel's, for one token and for two with K_total > 4096 -- the quantiser then
+ * sits in front of that kernel; 8, the decode-batch kernel's, for two tokens with K_total <= 4096): the outputs are bit-identical to the
  * quantiser op followed by atom_gemm_w4a4_multi (tests/test_gpu_e2e.py).  (Rounds 3-5 always summed in the decode-batch kernel's order
  * and were one fp16 ulp off where the separate call took the dot-product kernel.)
  */

@@ -421,9 +421,12 @@ def gemm_w4a4_exact(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
 
 
 def gemm_w4a4_ref(qa4, qb4, sA, sB, qa8, qb8, sA8, sB8) -> np.ndarray:
-    """The reference kernel's rounding order: scale product in FP16 (__hmul2, :417), widened to
-    FP32, c_fp32 += float(int_acc) * s per group in group order then keeper (:404-434, :680-691),
-    D = half(c) (:240-243).  Returns float16 [M,N]."""
+    """The reference kernel's rounding order UP TO FMA CONTRACTION: scale product in FP16 (__hmul2, :417), widened to
+    FP32, c_fp32 += float(int_acc) * s per group in group order then keeper (:404-434, :680-691), D = half(c) (:240-243).
+    This restatement rounds the product int_acc * s to FP32 and then adds; nvcc contracts `accu += c_frag * rs_scale`
+    (:420-431) into one FMA by default, i.e. the compiled reference rounds once per group where this rounds twice --
+    immaterial at the 1e-2 this function is used for (the tests' tolerance), and neither is the contract of
+    include/atom_hip.h (gemm_w4a4_contract below: exact FP32 scale product, one FMA).  Returns float16 [M,N]."""
     M, K4 = qa4.shape
     G = K4 // GROUP
     c = np.zeros((M, qb4.shape[0]), dtype=f32)

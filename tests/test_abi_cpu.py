@@ -150,7 +150,8 @@ def test_fused_quantiser_shape_query():
         assert fq(RE, 2, 4096, 1, h) == ok and fq(RN, 2, 4096, 1, h) == ok and fq(AR, 2, 4096, 1, h) == ok and fq(SM, 2, 4096, 1, h) == 1
         assert fq(RE, 1, 4096, 1, h) == 1
     assert fq(RE, 2, 4096, 1, 8192) == 1 and fq(RE, 2, 4096, 1, 8320) == 0
-    assert fmq(1, 4096, 1, 4096, 8) == 1 and fmq(1, 4096, 1, 4096, 16) == 1 and fmq(2, 4096, 1, 4096, 4) == 1 and fmq(1, 8192, 1, 8192, 2) == 1
+    assert fmq(1, 4096, 1, 4096, 8) == 1 and fmq(1, 4096, 1, 4096, 16) == 1 and fmq(1, 8192, 1, 8192, 2) == 1
+    assert fmq(2, 4096, 1, 4096, 4) == 0                     # two tokens with K <= 4096 run the decode-batch kernel, not the dot-product form
     assert fmq(1, 4096, 1, 4096, 1) == 0 and fmq(1, 4096, 1, 4096, 17) == 0 and fmq(2, 4096, 1, 8192, 8) == 0 and fmq(3, 4096, 1, 4096, 8) == 0
 
 

@@ -918,19 +918,17 @@ def test_gemv_bit_exact_vs_c_contract(M, N, K, layout):
     assert torch.equal(f32.half(), out)
 
 
-def test_two_tokens_take_the_dot_product_kernel_and_three_the_decode_batch_kernel():
-    """The routing rule is the token count only (round 6; rounds 4-5: two tokens took the dot-product kernel where K > 4096): one and two
-    tokens run the dot-product kernel -- through every entry point, so that a decode step's projections and the quantiser-in-front launch
-    (csrc/gemvq_w4a4.hip) agree bit for bit --, three and more the MFMA decode-batch kernel (its order: nsplit = 8)."""
+def test_two_tokens_take_the_decode_batch_kernel_up_to_k_4096():
+    """The routing rule is (M, K) only: two tokens with K <= 4096 keep the MFMA decode-batch kernel (its order: nsplit = 8); beyond, and
+    for one token, the dot-product kernel (round 6 measured two tokens on it at every K: slower, see csrc/gemm_w4a4.hip gemv_tokens)."""
     from tests import c_oracle as C
     ops = _ops()
     lib = ops.L.lib()
-    for M, order in ((2, "lanes"), (3, 8)):
-        assert lib.atom_gemm_w4a4_packed_order(M, 1024, 4096, 0) == (64 if order == "lanes" else 8)
-        d = rand_gemm_operands(M, 1024, 4096, seed=77)
-        out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
-        want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=order)
-        assert np.array_equal(bits16(t2n(out)), bits16(want))
+    assert lib.atom_gemm_w4a4_packed_order(2, 1024, 4096, 0) == 8 and lib.atom_gemm_w4a4_packed_order(2, 1024, 4224, 0) == 64
+    d = rand_gemm_operands(2, 1024, 4096, seed=77)
+    out = ops.dense_layer_gemm_i4_fp16(*to_device(d, "plain"), scale_layout="plain")
+    want = C.gemm(O.pack_int4(d["qa4"]), O.pack_int4(d["qb4"]), d["sA"].T, d["sB"], d["qa8"], d["qb8"], d["sA8"], d["sB8"], nsplit=8)
+    assert np.array_equal(bits16(t2n(out)), bits16(want))
 
 
 # mid-size batches in the packed format: gemm_w4a4_mid.hip, INT8 form (64 x 64 tiles over the whole K range on a deep LDS ring).  The

@@ -15,15 +15,56 @@ from atom_amd.model import qLlamaLayer, quant  # noqa: E402
 from atom_amd.model.qLinearLayer import QLinearLayer  # noqa: E402
 
 
-def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True, attn_sdpa=False):
+WIDE_PROJ = {   # projection -> (fixture key of its input, module path): tests/golden/llama_block_7b_wide.npz
+    "q": ("xq1", "self_attn.q_proj"), "k": ("xq1", "self_attn.k_proj"), "v": ("xq1", "self_attn.v_proj"), "o": ("attn_q", "self_attn.o_proj"),
+    "gate": ("xq2", "mlp.gate_proj"), "up": ("xq2", "mlp.up_proj"), "down": ("act_q", "mlp.down_proj"),
+}
+
+
+def golden_check(m):
+    """the 65,536-token number carries a check.  The timed block IS the model of tests/golden/llama_block_7b_wide.npz
+    (same seeds, gen_golden_block7b.py), so its seven W4A4 projections are fed the unmodified REFERENCE's own inputs on the fixture's
+    256 token rows and compared with the reference's own outputs on its 256 sampled features (what tests/test_gpu_block.py asserts
+    with bounds 1e-3 / 1e-2).  Returns {projection: (relative Frobenius error, worst element / max(|ref|, rms))}."""
+    import numpy as np
+    from atom_amd import ops
+    from atom_amd.model.qLinearLayer import find_qlinear_layers
+    z = np.load(os.path.join(ROOT, "tests", "golden", "llama_block_7b_wide.npz"))
+    layers = find_qlinear_layers(m)
+    out = {}
+    for name, (key, path) in WIDE_PROJ.items():
+        v = torch.from_numpy(z[key]).cuda().float()
+        s4 = torch.from_numpy(z["s4_" + key]).cuda()
+        s8 = torch.from_numpy(z["s8_" + key]).cuda()
+        M, H = v.shape
+        c4 = torch.round(v[:, :-128].reshape(M, -1, 128) / s4.float()[..., None]).reshape(M, H - 128).to(torch.int32)
+        c8 = torch.round(v[:, -128:] / s8.float()[:, None]).to(torch.int8)
+        o4 = ((c4[:, 0::2] & 0xF) | ((c4[:, 1::2] & 0xF) << 4)).to(torch.uint8).view(torch.int8).contiguous()
+        b4, b8, sb, sb8 = layers[path].packed_weight()
+        D = ops.dense_layer_gemm_i4_fp16(o4, b4, s4.t().contiguous(), sb, c8.contiguous(), b8, s8, sb8, scale_layout="plain")
+        got = D[:, torch.from_numpy(z["cols_" + name]).cuda()].double()
+        ref = torch.from_numpy(z["out_" + name]).cuda().double()
+        out[name] = (((got - ref).norm() / ref.norm()).item(),
+                     ((got - ref).abs() / ref.abs().clamp_min(ref.pow(2).mean().sqrt())).max().item())
+    return out
+
+
+def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True, attn_sdpa=False, check=False):
     """Returns dict(block_ms, gemm_ms, gemm_tops, spans={module: ms}) -- also what `bench.py --workload block` reports.
-    attn_sdpa: the configuration opt-in args.attn_sdpa (torch's fused attention instead of the reference's materialised score matrix)."""
+    attn_sdpa: the configuration opt-in args.attn_sdpa (torch's fused attention instead of the reference's materialised score matrix).
+    check (Llama-7B width only): + "golden" = golden_check() of the very model that was timed."""
     args = types.SimpleNamespace(wbits=4, abits=4, a_sym=True, w_sym=True, act_group_size=128, weight_group_size=128,
                                  weight_channel_group=2, keeper=128, keeper_precision=3, a_clip_ratio=0.9,
                                  w_clip_ratio=0.85, kv_clip_ratio=1.0, tiling=0, exponential=False, quant_type="int",
                                  static=False, reorder=True, kv_cache=True, attn_sdpa=bool(attn_sdpa))
-    orig = G.build_original(hidden, heads, inter, seed=7)
-    idx, _, _, _ = G.make_inputs(hidden, inter, 1, 8, seed=8)
+    if (hidden, heads, inter) == (4096, 32, 11008):           # the model of the 7B-width goldens (weights seed 17, reorder indices seed 18)
+        import gen_golden_block7b as G7
+        orig = G7.build_original()
+        idx = G.make_inputs(hidden, inter, 1, 8, seed=G7.SEED_X)[0]
+    else:
+        check = False
+        orig = G.build_original(hidden, heads, inter, seed=7)
+        idx, _, _, _ = G.make_inputs(hidden, inter, 1, 8, seed=8)
     m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
     G.prepare(m, args, {k: v.cuda() for k, v in idx.items()}, quant)
     x = torch.randn(bsz, seq, hidden, device="cuda").half()
@@ -77,9 +118,16 @@ def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1,
     if verbose:
         print(f"  seven W4A4 GEMMs (the MLP's three incl. its fused SiLU x up quantiser): {gemm:.2f} ms = {ops / gemm / 1e9:.0f} TOPS; "
               f"rest (attention in torch, KV fake-quant, RoPE, residuals): {total - gemm:.2f} ms")
-    return {"block_ms": total, "gemm_ms": gemm, "gemm_ops": ops, "gemm_tops": ops / gemm / 1e9, "spans": per, "tokens": M}
+    res = {"block_ms": total, "gemm_ms": gemm, "gemm_ops": ops, "gemm_tops": ops / gemm / 1e9, "spans": per, "tokens": M}
+    if check:
+        with torch.no_grad():
+            res["golden"] = golden_check(m)
+        if verbose:
+            print("  the timed model's projections on the reference's inputs vs the reference's outputs (256 rows x 256 features: relative "
+                  "Frobenius, worst element): " + ", ".join(f"{k} {a:.1e} {b:.1e}" for k, (a, b) in res["golden"].items()))
+    return res
 
 
 if __name__ == "__main__":
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    run(bsz=b)
+    run(bsz=b, check=True)

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=/tmp/atom_prof_raw          # (raw rocprofv3 output stays on the box: gpurun copies at most 64 MiB of gpurun_out/ back)
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $R/bench.py --no-cpu-baseline --no-configs --no-block --steps 500 --warmup 100"   # 500 timed + 100 warm-up launches per operand format (+ the 1500-launch ramp)
+CMD="python $R/bench.py --no-cpu-baseline --no-configs --no-block --no-decode --steps 500 --warmup 100"   # 500 timed + 100 warm-up launches per operand format (+ the 1500-launch ramp)
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
