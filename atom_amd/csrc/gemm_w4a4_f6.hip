@@ -1441,18 +1441,26 @@ struct QNoEarly { __device__ __forceinline__ void operator()(int) const {} };
 // `early(i)`, i = 0..7: behind the MFMAs of slots 0..7 (step 0 issues the LDS-DMA of stage 1 there; published by the same mid-step barrier)
 template <class C, int SL, bool PAIR, class FS, class FD, class FE = QNoEarly>
 __device__ __forceinline__ void q_step(QRegs<C, PAIR> &R, const char *lds, float (&c)[4][8][4], FS sync, FD mid, int ro = 0, int rn = 0,
-                                       bool LAST = false, FE early = FE()) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
+                                       bool LAST = false, FE early = FE(), unsigned *tp = nullptr) {   // LAST (only with SL < 0): no next int4 stage to prefetch from
+  // tp (traced tools build, ONE step of two workgroups): s_memtime at the head of every pair slot [i], in front of / behind the mid-step
+  // wait + barrier [16], [17], behind the step [18], and around every slot's loads-and-DMA section [32 + 2 i], [33 + 2 i] -- with an
+  // s_waitcnt lgkmcnt(0) in front of the second one, so that [33 + 2 i] - [32 + 2 i] is the slot's fragment-read issue + wait + DMA issue
   constexpr int NX = SL < 0 ? -1 : (SL + 1) % 3;
+  auto stamp = [&](int k) {
+    if (tp) { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) tp[k] = t_; __builtin_amdgcn_sched_barrier(0); }
+  };
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int tb = p_tb(i), h = p_h(i);
     __builtin_amdgcn_sched_barrier(0);
-    if (i == 8) sync();
+    stamp(i);
+    if (i == 8) { stamp(16); sync(); stamp(17); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       R.acc[i & 1][k] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(R.af[2 * h + k], R.bf[p_buf(tb)], v4f_t{0.f, 0.f, 0.f, 0.f}, 3, 3, 0, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(32 + 2 * i);
     // ---- loads behind this slot's MFMAs, into registers whose last reader has just issued
     if (h == 1 && i < 12 && tb + 2 < 8) {
       R.bf[p_buf(tb + 2)] = q_frag<C, SL>(lds, R.aA, p_row(tb + 2) * PITCH, ro);
@@ -1476,6 +1484,8 @@ __device__ __forceinline__ void q_step(QRegs<C, PAIR> &R, const char *lds, float
     }
     if (i >= 8) mid(i - 8);
     else early(i);
+    if (tp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(33 + 2 * i);
     __builtin_amdgcn_sched_barrier(0);
     // ---- de-quantisation of the previous slot's pair (slot 15 of the previous step for i == 0)
     {
@@ -1488,6 +1498,7 @@ __device__ __forceinline__ void q_step(QRegs<C, PAIR> &R, const char *lds, float
     if (!LAST && i == 14) q_load_sb<C, NX>(lds, R, 0, rn);
     if (i == 0) q_load_sb<C, SL>(lds, R, 1, ro);
   }
+  stamp(18);
 }
 
 // The keeper step of the q kernel (round 3): both 64-column halves (two stage slots) in ONE step, pipelined like q_step.  Round 2 ran
@@ -1599,7 +1610,8 @@ __device__ __forceinline__ void q_keeper(const GemmParams &p, const char *slot, 
 // Activate.cuh:67-180) -- writing the F6 activation operand of down_proj directly (GU = 1: simulated-path arithmetic, 2: the CUDA
 // kernels').  Bit-identical to fp16 GEMMs + atom_silu_mul_quant_f16; saves writing and re-reading 2 x M x N_inter fp16.
 // TR (tools build only, tools/trace_f6q.cpp): s_memtime stamps of workgroups 0 and gridDim.x - 1 into p.Dsz as u32 [2][8 waves][64]:
-// [0..15] kernel phases, [16 + s] start of K step s, [62], [63] s_memrealtime (100 MHz) at entry and exit
+// [0..15] kernel phases, [16 + s] start of K step s, [62], [63] s_memrealtime (100 MHz) at entry and exit, [64 ..] the in-step stamps of K step 9 (q_step's tp);
+// 128 dwords per wave
 // PAIR: the caller asserts that output channels 2 j, 2 j + 1 share their weight scales (ATOM_B_SCALE_PAIRS: weight_channel_group = 2,
 // the only form the reference kernel accepts): 6 instead of 8 de-quantisation VALU per MFMA (deq_pair), half the scale registers.
 template <class C, int GU = 0, bool TR = false, bool PAIR = false>
@@ -1615,7 +1627,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
   };
   if constexpr (TR) {
     if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
-      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 64;
+      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 128;
       if ((threadIdx.x & 63) == 0) trb[62] = (unsigned)__builtin_amdgcn_s_memrealtime();
     }
     kstamp(0);
@@ -1711,6 +1723,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
 #pragma unroll
     for (int k = 0; k < 2; ++k) R.acc[1][k] = v4f_t{0.f, 0.f, 0.f, 0.f};
   }
+  if constexpr (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); kstamp(3); }   // the first fragments have arrived
   auto sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1722,7 +1735,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
     const int g = s + 2;
     const uint8_t *wsrc = wsrc0 + g * wstep, *asrc = asrc0 + g * astep;
     const float *sbsrc = sbsrc0 + (int64_t)g * p.f6_rows_b;
-    q_step<C, SL, PAIR>(R, lds, c, sync, [&](int i) { q_piece<C, (SL + 2) % 3>(d, wsrc, asrc, sbsrc, i); });
+    unsigned *tp = nullptr;
+    if constexpr (TR) { if (trb && s == 9) tp = trb + 64; }   // the in-step stamps of K step 9 (a slot-0 body in the middle of the loop)
+    q_step<C, SL, PAIR>(R, lds, c, sync, [&](int i) { q_piece<C, (SL + 2) % 3>(d, wsrc, asrc, sbsrc, i); }, 0, 0, false, QNoEarly(), tp);
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -1988,7 +2003,7 @@ __global__ __launch_bounds__(C::NT * 2, 2) void gemm_w4a4_f6qk_kernel(GemmParams
   };
   if constexpr (TR) {
     if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) {
-      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 64;
+      trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 128;
       if ((threadIdx.x & 63) == 0) trb[62] = (unsigned)__builtin_amdgcn_s_memrealtime();
     }
     kstamp(0);

@@ -48,6 +48,13 @@ class QLinearLayer(nn.Module):
     # INT4 codes once the F6 form exists (a layer that only sees prefill batches then holds 6.75 bit per weight instead of 10.9);
     # a later decode-size batch re-packs them from `weight` (one atom_pack_weight_w4 launch).
     keep_packed_with_f6 = True
+    # keep_f6 = False (round 6): the weight stays at 4 bits in HBM on the prefill path too -- the reference's weight_int4 layout, 0.52 B
+    # per weight incl. scales (punica/models/llama.py:35-59) -- and a prefill batch re-codes it to the BF6 form into a TRANSIENT buffer
+    # (one bandwidth-bound launch, freed after the GEMM) instead of keeping 0.84 B per weight beside it.  Same kernels, same bits;
+    # the price is the re-coding per call (and, in the MLP, re-building the interleaved gate / up operand): the seven GEMMs of a
+    # Llama-7B block take +3.4 % at the 65,536 tokens of BASELINE config 4 (the block +0.7 %), +14 % at 16,384 tokens, +60 % at 4,096
+    # (profiles/r06/ab_nibble_weights.txt).  Default True (speed at every batch size); False for deployments that count the bytes.
+    keep_f6 = True
     # Forwards that arrived with INT4 activation codes and a hot-path configuration but were served by F.linear because the weight is
     # not on the INT4-g128 / INT8 grid (pack_weight_w4 found off-grid blocks): the reference's own arithmetic, but not the HIP path.
     # Expected while GPTQ collects Hessians on still-unquantised weights; anywhere else it means the layer was never quantised.
@@ -131,7 +138,12 @@ class QLinearLayer(nn.Module):
                 # packed codes of a batch the BF6 kernels serve faster with the weight's BF6 form at hand (large N x K below 129 rows):
                 # re-code the activation and use this layer's BF6 weight, instead of a second copy in the GEMM op's per-weight cache
                 o4, wide = _ops.repack_act_f6(o4.view(torch.uint8), codes.s4, scale_layout=codes.layout), "f6"
-            if wide == "f6":                              # BF6 operands: the weight is repacked once per packed form
+            if wide == "f6" and not self.keep_f6:         # 4-bit weights only: the BF6 form is made per call and dropped
+                if b4 is None:
+                    b4 = self.packed_weight(need_codes=True)[0]
+                self._f6 = None
+                b4 = _ops.repack_weight_f6(b4, sb)
+            elif wide == "f6":                            # BF6 operands: the weight is repacked once per packed form
                 if self._f6 is None or self._f6[0] != self._packed_key:
                     if b4 is None:
                         b4 = self.packed_weight(need_codes=True)[0]

@@ -279,6 +279,9 @@ class QLlamaMLP(nn.Module):
         if self.gate_proj.packed_weight(need_codes=False) is None or self.up_proj.packed_weight(need_codes=False) is None:
             return None
         key = (self.gate_proj._packed_key, self.up_proj._packed_key)
+        if not (self.gate_proj.keep_f6 and self.up_proj.keep_f6):    # 4-bit weights only (QLinearLayer.keep_f6): built per call, not kept
+            self._fused = None
+            return _ops.fuse_gate_up_weights(self.gate_proj.packed_weight(), self.up_proj.packed_weight())
         if getattr(self, "_fused", None) is None or self._fused[0] != key:
             pg, pu = self.gate_proj.packed_weight(), self.up_proj.packed_weight()
             self._fused = (key, _ops.fuse_gate_up_weights(pg, pu))

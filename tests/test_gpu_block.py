@@ -286,6 +286,13 @@ def test_qlinear_weight_memory_policy():
     assert wb["f6"] == wa["f6"] == (K // 128 - 1) * N * 108
     assert 8.0 * (wb["f6"] + wb["keeper_and_scales"]) / (N * K) < 7.8      # bits per weight without the packed codes (keeper incl.)
     assert torch.equal(a(small), b(small))                                  # re-packed on demand
+    # keep_f6 = False (round 6): 4-bit weights only -- the BF6 form is transient; same bits, no F6 bytes held
+    n4 = mk()
+    n4.weight = w0.clone()
+    n4.keep_f6 = False
+    n4.quant()
+    assert torch.equal(n4(big), a(big)) and torch.equal(n4(small), a(small)) and torch.equal(n4(big), a(big))
+    assert n4.weight_bytes()["f6"] == 0 and n4.weight_bytes()["packed_int4"] == wa["packed_int4"]
     assert b.weight_bytes()["packed_int4"] == wa["packed_int4"]
     assert torch.equal(a(big), b(big))
     # a .to() round trip with released codes (None entries in the packed tuple) and a cached F6 form

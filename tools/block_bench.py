@@ -49,7 +49,7 @@ def golden_check(m):
     return out
 
 
-def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True, attn_sdpa=False, check=False):
+def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1, verbose=True, attn_sdpa=False, check=False, keep_f6=True):
     """Returns dict(block_ms, gemm_ms, gemm_tops, spans={module: ms}) -- also what `bench.py --workload block` reports.
     attn_sdpa: the configuration opt-in args.attn_sdpa (torch's fused attention instead of the reference's materialised score matrix).
     check (Llama-7B width only): + "golden" = golden_check() of the very model that was timed."""
@@ -67,6 +67,10 @@ def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1,
         idx, _, _, _ = G.make_inputs(hidden, inter, 1, 8, seed=8)
     m = qLlamaLayer.QLlamaDecoderLayer(orig, args).to("cuda")
     G.prepare(m, args, {k: v.cuda() for k, v in idx.items()}, quant)
+    if not keep_f6:                                           # 4-bit weights only in HBM: the BF6 form re-made by every call (QLinearLayer.keep_f6)
+        for mod in m.modules():
+            if type(mod) is QLinearLayer:
+                mod.keep_f6 = False
     x = torch.randn(bsz, seq, hidden, device="cuda").half()
     pos = torch.arange(seq, device="cuda")[None, :].expand(bsz, seq).contiguous()
     mask = torch.full((seq, seq), torch.finfo(torch.float16).min, device="cuda").triu(1)[None, None].expand(bsz, 1, seq, seq).half().contiguous()
@@ -130,4 +134,4 @@ def run(bsz=32, seq=2048, hidden=4096, heads=32, inter=11008, iters=3, warmup=1,
 
 if __name__ == "__main__":
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    run(bsz=b, check=True)
+    run(bsz=b, check=True, keep_f6=not (len(sys.argv) > 2 and sys.argv[2] == "nibble"))

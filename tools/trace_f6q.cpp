@@ -27,7 +27,8 @@ int main(int argc, char **argv) {
   void *B6; (void)hipMalloc(&B6, atom_f6_weight_bytes(N, K));
   if (int st = atom_repack_weight_f6s(B4, sB, N, K, B6, nullptr)) { printf("repack err %d\n", st); return 1; }
   void *D; (void)hipMalloc(&D, (size_t)M * N * 2);
-  const size_t TR = 2 * 8 * 64;
+  const size_t WS = qk ? 64 : 128;                          // dwords per wave (the q kernel: + the in-step stamps of K step 9)
+  const size_t TR = 2 * 8 * WS;
   unsigned *tr; (void)hipMalloc(&tr, TR * 4); (void)hipMemset(tr, 0, TR * 4);
   char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)tr); setenv("ATOM_TRACE_PTR", buf, 1); setenv("ATOM_F6_CFG", qk ? "2017" : "2016", 1);
   const int layout = ATOM_AB_F6 | ATOM_B_F6S | ATOM_SCALE_LAYOUT_PLAIN;
@@ -62,22 +63,37 @@ int main(int argc, char **argv) {
     return 0;
   }
   for (int wg = 0; wg < 2; ++wg) {
-    const unsigned t00 = h[wg * 8 * 64];
+    const unsigned t00 = h[wg * 8 * WS];
     printf("workgroup %s\n", wg ? "last" : "0");
     for (int w = 0; w < 8; ++w) {
-      unsigned *e = &h[(wg * 8 + w) * 64];
+      unsigned *e = &h[(wg * 8 + w) * WS];
       const double mhz = 100.0 * d(e[8], e[0]) / (double)d(e[63], e[62]);
       printf(" wave %d: entry %+d | dma issued +%d | stages 0,1 landed +%d | first fragments +%d | int4 loop +%d | keeper0 +%d | barrier +%d | keeper1 + stores issued +%d | "
              "stores done +%d | total %d cycles = %.2f us, %.0f MHz\n", w, d(e[0], t00), d(e[1], e[0]), d(e[2], e[1]), d(e[3], e[2]), d(e[4], e[3]),
              d(e[5], e[4]), d(e[6], e[5]), d(e[7], e[6]), d(e[8], e[7]), d(e[8], e[0]), d(e[63], e[62]) / 100.0, mhz);
     }
-    unsigned *e = &h[wg * 8 * 64];
+    unsigned *e = &h[wg * 8 * WS];
     printf(" wave 0, K steps (cycles):");
     for (int s2 = 0; s2 + 1 < G && s2 < 43; ++s2) printf(" %d", d(e[16 + s2 + 1], e[16 + s2]));
     printf("\n wave 4, K steps (cycles):");
-    e = &h[(wg * 8 + 4) * 64];
+    e = &h[(wg * 8 + 4) * WS];
     for (int s2 = 0; s2 + 1 < G && s2 < 43; ++s2) printf(" %d", d(e[16 + s2 + 1], e[16 + s2]));
     printf("\n");
+    // inside K step 9 (stamped: the stamps and the lgkmcnt(0) in front of each slot's second one lengthen this step): per pair slot
+    // [MFMA pair issue | loads + DMA issue + read wait | de-quantisation of the previous pair], and the mid-step wait + barrier
+    for (int w = 0; w < 8; w += 4) {
+      unsigned *t = &h[(wg * 8 + w) * WS + 64];
+      if (!t[0]) continue;
+      int mf = 0, ld = 0, dq = 0;
+      printf(" wave %d, K step 9 by pair slot: mfma | loads+dma+wait | dequant (cycles):", w);
+      for (int i = 0; i < 16; ++i) {
+        const int a = d(t[32 + 2 * i], i == 8 ? t[17] : t[i]), b = d(t[33 + 2 * i], t[32 + 2 * i]), c2 = d(i < 15 ? t[i + 1] : t[18], t[33 + 2 * i]);
+        mf += a; ld += b; dq += c2;
+        printf(" %d|%d|%d", a, b, c2);
+      }
+      printf("\n   = MFMA pair issue %d + fragment / scale reads, their wait and the LDS-DMA issue %d + de-quantisation %d + vmcnt wait and barrier %d "
+             "= %d cycles (the step: %d)\n", mf, ld, dq, d(t[17], t[16]), mf + ld + dq + d(t[17], t[16]), d(t[18], t[0]));
+    }
   }
   return 0;
 }
