@@ -48,9 +48,14 @@ __device__ __forceinline__ float max32(float a) {
 // LDS: the packed operand [MQ][K4h] codes, [MQ][128] keeper, [G][MQ] + [MQ] fp16 scales; then (16-byte aligned) the reduction scratch,
 // and for ops 1-3 the fp16 rows [MQ][H] and the norm weights [H]
 __host__ __device__ inline int red_offset(int K4h, int G) { return (MQ * K4h + MQ * kKeeper + MQ * G * 2 + MQ * 2 + 15) & ~15; }
-inline size_t lds_bytes(int q_op, int K4h, int G) {
+constexpr int RED_BYTES = 48;             // [MQ][4] partial sums of squares, then the staging counter (+ padding)
+__host__ __device__ inline int quant_lds_bytes(int q_op, int K4h, int G) {   // everything the quantiser uses
   const int H = 2 * K4h + kKeeper;
-  return (size_t)red_offset(K4h, G) + 32 + (q_op != 4 ? (size_t)H * 2 * (MQ + 1) : 0);
+  return (red_offset(K4h, G) + RED_BYTES + (q_op != 4 ? H * 2 * (MQ + 1) : 0) + 15) & ~15;
+}
+// behind it: the weight chunks the loader waves fetch by LDS-DMA while the quantiser runs -- [16 waves][lf features][NCH chunks][1 KiB]
+inline size_t lds_bytes(int q_op, int K4h, int G, int lf = 0, int nch = 0) {
+  return (size_t)quant_lds_bytes(q_op, K4h, G) + (size_t)NWV * lf * nch * 1024;
 }
 
 // One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 2 chunks per lane, a half or a quarter of
@@ -179,6 +184,19 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // LDS prefetch (round 6, p.q_lf > 0: RMSNorm forms at one token): the waves WITHOUT a row chunk to stage -- waves nstage .. 15 -- are
+  // the workgroup's loaders: behind their own (late-needed) task inputs they request the first q_lf features of EVERY wave by LDS-DMA,
+  // into LDS, while waves 0 .. nstage - 1 stage the rows and run the sum of squares.  The stream then starts ~1 k cycles into the
+  // kernel instead of behind the quantiser's first barrier, occupies no registers, and blocks (at the CU's ~10 B per clock from HBM)
+  // only waves that have nothing else to do; the staging waves synchronise among themselves through an LDS counter instead of an
+  // s_barrier the loaders would arrive late at.
+  const int nstage = (p.M * q_nchunks + 63) >> 6;            // waves with a row chunk to stage
+  const int lf = (NORM && MT == 1) ? p.q_lf : 0;             // (workgroup-uniform)
+  const bool loader = lf > 0 && wave >= nstage;
+  unsigned *stage_cnt = reinterpret_cast<unsigned *>(lds + red_offset(K4h, G) + 32);
+  const unsigned wl0 = lds_addr(lds) + (unsigned)quant_lds_bytes(QOP, K4h, G);   // [16 waves][lf][NCH][1 KiB]
+  if (lf > 0 && tid == 0) *stage_cnt = 0u;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // every wave's quantiser requests are in the memory pipeline before ANY weight request goes out (one s_barrier: the 128 weight
   // requests of a workgroup would otherwise sit in front of the later waves' row chunks)
   __builtin_amdgcn_s_barrier();
@@ -191,17 +209,50 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   PartW<PCH> ring[D];
   v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
   unsigned short ringsb8[D / PARTS];
-  const int n0w = f0 + wave;
-  const int nfeat = n0w < f1 ? (f1 - n0w + NWV - 1) / NWV : 0;    // features of this wave
+  const int nfeat_all = f0 + wave < f1 ? (f1 - (f0 + wave) + NWV - 1) / NWV : 0;   // features of this wave
+  constexpr int LFM = 2;                                          // LDS features per wave at most
+  const int lfe = min(lf, nfeat_all);                             // ... of THIS wave: its features 0 .. lfe - 1 arrive in LDS
+  const int n0w = f0 + wave + lfe * NWV;                          // the register ring takes the others
+  const int nfeat = nfeat_all - lfe;
   const int nsteps = nfeat * PARTS;
+  unsigned short lsbu[LFM][NCH], lsb8[LFM];                       // the scales / keeper chunk of the LDS features (registers)
+  v4i lw8[LFM];
   auto issue_ring = [&](int u0, int u1) {
 #pragma unroll
   for (int u = 0; u < D; ++u) {
-    if (u >= u0 && u < u1 && (u < nsteps || u < PARTS))                                  // (wave-uniform; a wave without features still reads one valid row)
+    if (u >= u0 && u < u1 && (u < nsteps || (u < PARTS && lfe == 0)))                    // (wave-uniform; a wave without features still reads one valid row)
       load_part<PCH>(p, min(n0w + (u / PARTS) * NWV, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
                      ringsb8[u / PARTS]);
   }
   };
+  auto issue_small = [&]() {                                      // the scales and the keeper chunk of this wave's LDS features
+#pragma unroll
+  for (int j = 0; j < LFM; ++j)
+    if (j < lfe) {
+      const int n = f0 + wave + j * NWV;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        lsbu[j][c] = reinterpret_cast<const unsigned short *>(p.sB)[(int64_t)(min(lane + 64 * c, nchunks - 1) >> 2) * p.N + n];
+      lw8[j] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
+      lsb8[j] = reinterpret_cast<const unsigned short *>(p.sB8)[n];
+    }
+  };
+  if (loader) {                                                   // the LDS-DMA requests of the whole workgroup's LDS features
+    issue_small();                                                // (in front of them: they return first)
+    const int nl = NWV - nstage;
+    for (int cw = wave - nstage; cw < NWV; cw += nl) {
+#pragma unroll
+      for (int j = 0; j < LFM; ++j) {
+        const int n = f0 + cw + j * NWV;
+        if (j < lf && n < f1) {                                   // (wave-uniform)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if (c * 64 < nchunks)
+              lds_dma_at<16>(p.B4 + (int64_t)n * K4h + min(lane + 64 * c, nchunks - 1) * 16, wl0 + (unsigned)(((cw * lf + j) * NCH + c) * 1024));
+        }
+      }
+    }
+  }
   GQ_STAMP(1);                                               // every request issued
   __builtin_amdgcn_sched_barrier(0);
   // nothing of the quantiser moves up between the loads above, and none of its requests sinks into a branch below
@@ -236,7 +287,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       __builtin_amdgcn_s_barrier();
     };
     float *red = reinterpret_cast<float *>(lds + red_offset(K4h, G));                     // [MQ][4] partial sums of squares
-    char *rowbuf = reinterpret_cast<char *>(red + 8);                                     // [MQ][H] halves, then the norm weights [H]
+    char *rowbuf = reinterpret_cast<char *>(red) + RED_BYTES;                             // [MQ][H] halves, then the norm weights [H]
     char *wbuf = rowbuf + MQ * H * 2;
     const int Gt = H >> 7;
     if constexpr (QOP == 5) {
@@ -296,17 +347,33 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           if (tid + i * NTH < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NTH) * 16) = q_wr[i];
       }
     }
+    const bool sumsq_wave = NORM && (tid >> 8) < p.M;        // (wave-uniform) waves 4 m .. 4 m + 3: the tree of row m
     if constexpr (ROWS) {
       GQ_STAMP(2);                                             // the quantiser's inputs have arrived and sit in LDS
-      lds_barrier();
+      if (lf > 0) {                                            // staging waves only: count in; the tree's waves wait for all of them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (wave < nstage && lane == 0) __hip_atomic_fetch_add(stage_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sumsq_wave) {
+          int guard = 1 << 16;                                 // (bounded: a lost count ends as a wrong answer the tests see, not a hang)
+          while (__hip_atomic_load(stage_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)nstage && --guard > 0)
+            __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        lds_barrier();
+      }
       GQ_STAMP(3);
     }
     // the weights of this wave's first D steps go out HERE: in front of the quantiser's own requests they held every wave at the
     // CU's vector-memory issue rate (~20 cycles per wave instruction: 4-12 k cycles before the first row chunk reached LDS,
-    // profiles/r06/gemvq_trace.txt); from here they overlap the sum of squares and the codes
+    // profiles/r06/gemvq_trace.txt); from here they overlap the sum of squares and the codes -- except on the waves that run the sum
+    // of squares (theirs go out behind it: a wave stuck in request issue held the tree, and with it everybody's barrier, for 6-10 k
+    // cycles) and on the loader waves (behind the last barrier: their queue is full of LDS-DMA)
     // (half of the ring up front, half here: measured equal to worse -- a CU streams ~10 bytes per clock from HBM whatever the order.
     // SiLU x up has no barrier in front of its codes and two 8-byte inputs per task in registers: its ring goes out behind the codes)
-    if constexpr (QOP != 4) issue_ring(0, D);
+    if constexpr (QOP != 4) {
+      if (!sumsq_wave && !loader) { issue_ring(0, D); issue_small(); }
+    }
     float rinv[MQ] = {0.f, 0.f};
     if constexpr (QOP == 2 || QOP == 3) {
       const int m = tid >> 8, t8 = tid & 255;               // the stand-alone kernel's 4-wave tree, one per row
@@ -322,6 +389,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       }
       lds_barrier();
       GQ_STAMP(4);                                             // sum of squares done
+      if (sumsq_wave && !loader) { issue_ring(0, D); issue_small(); }
 #pragma unroll
       for (int m2 = 0; m2 < MQ; ++m2) {
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
@@ -387,14 +455,79 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
     if constexpr (QOP == 4) issue_ring(0, D);
     GQ_STAMP(5);                                               // codes written
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA pieces have landed (nothing younger is in flight)
     lds_barrier();
-    GQ_STAMP(6);                                               // the packed operand is published
+    GQ_STAMP(6);                                               // the packed operand (and the LDS features' weights) are published
+    if (loader) issue_ring(0, D);
   }
 
   // ---- the feature loop: gemv1_w4a4_kernel's arithmetic, feature by feature.  Step s = (feature s / PARTS, part s % PARTS) sits in
   // ring slot s % D; a slot is re-filled with step s + D as soon as step s is computed (D - 1 steps of weights in flight per wave, no
   // register copies: the loop is unrolled by D, and PARTS | D keeps a feature's parts inside one trip)
   const bool leader = (lane & 3) == 0;
+  auto finish = [&](int n, const float (&acc)[MT], const v4i &w8, unsigned short sb8u) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
+    const float sb8f = (float)__builtin_bit_cast(half_t, sb8u);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mr = min(m, p.M - 1);
+      const v4i a8 = *reinterpret_cast<const v4i *>(qa8 + mr * kKeeper + (lane & 7) * 16);
+      const float sa8f = (float)qsa8[mr];
+      int d = 0;
+      d = __builtin_amdgcn_sdot4(a8[0], w8[0], d, false);
+      d = __builtin_amdgcn_sdot4(a8[1], w8[1], d, false);
+      d = __builtin_amdgcn_sdot4(a8[2], w8[2], d, false);
+      d = __builtin_amdgcn_sdot4(a8[3], w8[3], d, false);
+      d = quad_sum(d);
+      d += __builtin_amdgcn_update_dpp(0, d, 0x104, 0xF, 0xF, true);   // row_shl:4 -- lane 0 += lane 4 (the other lanes' values are not used)
+      float s = acc[m];
+      s = wave_sum_butterfly(s);
+      if (lane == 0 && m < p.M) {
+        const float c = __builtin_fmaf((float)d, sa8f * sb8f, s);
+        const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
+        void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+        const int64_t at = (int64_t)m * p.seg_n + nl;
+        if ((p.seg_f32 >> seg) & 1u) {
+          reinterpret_cast<float *>(out)[at] = c;
+        } else {
+          half_t h = f2h(c);
+          if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[at]);   // fp16 + fp16 as torch adds halves
+          reinterpret_cast<half_t *>(out)[at] = h;
+        }
+      }
+    }
+  };
+  auto chunk = [&](int ch, const v4i &w, unsigned short sbu, float (&acc)[MT]) {   // one weight chunk against every token's codes
+    const bool ok = ch < nchunks;
+    const int cc = min(ch, nchunks - 1);
+    const float sbf = (float)__builtin_bit_cast(half_t, sbu);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mr = min(m, p.M - 1);
+      const v4i a = *reinterpret_cast<const v4i *>(qa4 + mr * K4h + cc * 16);
+      const float saf = (float)qsa[(cc >> 2) * MQ + mr];
+      int d = 0;
+      d = __builtin_amdgcn_sdot8(a[0], w[0], d, false);
+      d = __builtin_amdgcn_sdot8(a[1], w[1], d, false);
+      d = __builtin_amdgcn_sdot8(a[2], w[2], d, false);
+      d = __builtin_amdgcn_sdot8(a[3], w[3], d, false);
+      d = quad_sum(d);                                    // exact: the group's 128-element integer dot
+      const float next = __builtin_fmaf((float)d, saf * sbf, acc[m]);   // exact scale product
+      acc[m] = (leader && ok) ? next : acc[m];
+    }
+  };
+  // the features whose weights the loaders put into LDS: same chunks in the same order, read with ds_read_b128
+#pragma unroll
+  for (int j = 0; j < LFM; ++j)
+    if (j < lfe) {
+      float acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+      const char *wl = lds + quant_lds_bytes(QOP, K4h, G) + ((wave * lf + j) * NCH) * 1024 + lane * 16;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (c * 64 < nchunks) chunk(lane + 64 * c, *reinterpret_cast<const v4i *>(wl + c * 1024), lsbu[j][c], acc);
+      finish(f0 + wave + j * NWV, acc, lw8[j], lsb8[j]);
+    }
   for (int base = 0; base < nsteps; base += D) {
     float acc[MT];
 #pragma unroll
@@ -409,57 +542,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           for (int m = 0; m < MT; ++m) acc[m] = 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < PCH; ++c) {
-          const int ch = lane + 64 * (part * PCH + c);
-          const bool ok = ch < nchunks;
-          const int cc = min(ch, nchunks - 1);
-          const float sbf = (float)__builtin_bit_cast(half_t, f.sbu[c]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int mr = min(m, p.M - 1);
-            const v4i a = *reinterpret_cast<const v4i *>(qa4 + mr * K4h + cc * 16);
-            const float saf = (float)qsa[(cc >> 2) * MQ + mr];
-            int d = 0;
-            d = __builtin_amdgcn_sdot8(a[0], f.w[c][0], d, false);
-            d = __builtin_amdgcn_sdot8(a[1], f.w[c][1], d, false);
-            d = __builtin_amdgcn_sdot8(a[2], f.w[c][2], d, false);
-            d = __builtin_amdgcn_sdot8(a[3], f.w[c][3], d, false);
-            d = quad_sum(d);                                    // exact: the group's 128-element integer dot
-            const float next = __builtin_fmaf((float)d, saf * sbf, acc[m]);   // exact scale product
-            acc[m] = (leader && ok) ? next : acc[m];
-          }
-        }
-        if (part == PARTS - 1) {
-          const float sb8f = (float)__builtin_bit_cast(half_t, ringsb8[u / PARTS]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int mr = min(m, p.M - 1);
-            const v4i a8 = *reinterpret_cast<const v4i *>(qa8 + mr * kKeeper + (lane & 7) * 16);
-            const float sa8f = (float)qsa8[mr];
-            int d = 0;
-            d = __builtin_amdgcn_sdot4(a8[0], ring8[u / PARTS][0], d, false);
-            d = __builtin_amdgcn_sdot4(a8[1], ring8[u / PARTS][1], d, false);
-            d = __builtin_amdgcn_sdot4(a8[2], ring8[u / PARTS][2], d, false);
-            d = __builtin_amdgcn_sdot4(a8[3], ring8[u / PARTS][3], d, false);
-            d = quad_sum(d);
-            d += __builtin_amdgcn_update_dpp(0, d, 0x104, 0xF, 0xF, true);   // row_shl:4 -- lane 0 += lane 4 (the other lanes' values are not used)
-            float s = acc[m];
-            s = wave_sum_butterfly(s);
-            if (lane == 0 && m < p.M) {
-              const float c = __builtin_fmaf((float)d, sa8f * sb8f, s);
-              const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
-              void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
-              const int64_t at = (int64_t)m * p.seg_n + nl;
-              if ((p.seg_f32 >> seg) & 1u) {
-                reinterpret_cast<float *>(out)[at] = c;
-              } else {
-                half_t h = f2h(c);
-                if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[at]);   // fp16 + fp16 as torch adds halves
-                reinterpret_cast<half_t *>(out)[at] = h;
-              }
-            }
-          }
-        }
+        for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc);
+        if (part == PARTS - 1) finish(n, acc, ring8[u / PARTS], ringsb8[u / PARTS]);
         if (base + u < 4) GQ_STAMP(7 + base + u);            // steps 0 .. 3 done
         if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
           load_part<PCH>(p, n + (D / PARTS) * NWV, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
@@ -474,15 +558,28 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 
 template <int QOP, int NCH, int MT>
 static int launch1(const GemmParams &p, hipStream_t s) {
-  const size_t lds = lds_bytes(QOP, p.K4h, p.G);
+  // LDS prefetch by loader waves (the kernel's `lf`): the RMSNorm forms at one token, at least four waves without a row chunk to stage,
+  // one or two features per wave by what fits 150 KiB
+  GemmParams q = p;
+  q.q_lf = 0;
+  if ((QOP == 2 || QOP == 3) && MT == 1 && (p.K4h * 2 + kKeeper) / 8 <= 12 * 64) {
+    // Built, bit-identical (tests/test_gpu_e2e.py with ATOM_GEMVQ_LF=2 in a tools build) and SLOWER: the Llama-7B layer at batch 1 takes
+    // 60.9 us cold with it against 53.5 without (same box, profiles/r06/ab_gemvq_lds_prefetch.txt) -- the loaders need 4-5.5 k cycles to
+    // get their eight requests each into the CU's memory queue, reach the barrier behind the sum of squares at 9-11 k cycles instead of
+    // 5 k, and issue their own ring last.  Off (0) in the product; the tools build takes ATOM_GEMVQ_LF.
+    int lf = ATOM_TUNE("ATOM_GEMVQ_LF", 0);
+    while (lf > 0 && lds_bytes(QOP, p.K4h, p.G, lf, NCH) > (size_t)150 * 1024) --lf;
+    q.q_lf = lf > 2 ? 2 : lf;
+  }
+  const size_t lds = lds_bytes(QOP, p.K4h, p.G, q.q_lf, NCH);
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 160 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   // one workgroup per CU at most; every wave of it at least one feature
   const int cap = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
   int grid = p.N / NWV;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT>), dim3((unsigned)grid), dim3(NTH), lds, s, p);
+  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT>), dim3((unsigned)grid), dim3(NTH), lds, s, q);
   return check_launch();
 }
 
