@@ -99,7 +99,7 @@ struct GemmParams {
   half_t *q_res_out;              // 3: x + residual [M, K_total] (written by workgroup 0; may alias q_res)
   const int16_t *q_idx;           // reorder index [K_total] or null (1, 2, 3)
   float q_eps, q_clip;
-  int q_lf;                       // gemvq_w4a4.hip: features per wave whose weights loader waves fetch into LDS by LDS-DMA (set by its launcher)
+  int q_roles;                    // gemvq_w4a4.hip: quantiser waves / streamer waves (set by its launcher)
   const float *q_part;            // 5 (gemvq_w4a4.hip): the decode attention's split partial states [M][heads][q_splits][130] instead of q_x
   int q_splits;
 };

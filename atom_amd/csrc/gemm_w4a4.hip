@@ -247,7 +247,7 @@ static int fill_params(GemmParams &p, const void *A4, const void *B4, const void
   p.sA = (const half_t *)sA;  p.sB = (const half_t *)sB;
   p.A8 = (const uint8_t *)A8; p.B8 = (const uint8_t *)B8;
   p.sA8 = (const half_t *)sA8; p.sB8 = (const half_t *)sB8;
-  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr; p.ws = nullptr; p.splits = 1; p.q_op = 0; p.q_part = nullptr; p.q_splits = 0; p.q_lf = 0;
+  p.D = nullptr; p.D4 = nullptr; p.Dsz = nullptr; p.ws = nullptr; p.splits = 1; p.q_op = 0; p.q_part = nullptr; p.q_splits = 0; p.q_roles = 0;
   p.M = (int)M; p.N = (int)N;
   p.K4h = (int)((K_total - kKeeper) / 2);
   p.G = (int)((K_total - kKeeper) / kGroup);

@@ -53,10 +53,7 @@ __host__ __device__ inline int quant_lds_bytes(int q_op, int K4h, int G) {   // 
   const int H = 2 * K4h + kKeeper;
   return (red_offset(K4h, G) + RED_BYTES + (q_op != 4 ? H * 2 * (MQ + 1) : 0) + 15) & ~15;
 }
-// behind it: the weight chunks the loader waves fetch by LDS-DMA while the quantiser runs -- [16 waves][lf features][NCH chunks][1 KiB]
-inline size_t lds_bytes(int q_op, int K4h, int G, int lf = 0, int nch = 0) {
-  return (size_t)quant_lds_bytes(q_op, K4h, G) + (size_t)NWV * lf * nch * 1024;
-}
+inline size_t lds_bytes(int q_op, int K4h, int G) { return (size_t)quant_lds_bytes(q_op, K4h, G); }
 
 // One step of a wave's feature loop: PCH chunks of ONE output feature (a whole feature up to 2 chunks per lane, a half or a quarter of
 // one beyond: with 16 waves per workgroup a wave has 128 registers) and the scales of those chunks' groups.  The ring below holds D steps.
@@ -118,6 +115,34 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   constexpr bool NORM = QOP == 2 || QOP == 3;
   constexpr int PS = 16, PH = 8;                            // QOP 5: KV splits at most (gemvq_merge_fits); their values in batches of PH
 
+  // ---- Roles (round 6, p.q_roles: one token, ops 1-3): waves 0 .. NP - 1 are the workgroup's QUANTISER -- they stage the rows, run the sum
+  // of squares and write the codes, synchronising among themselves through an LDS counter --, waves NP .. 15 are STREAMERS: they request
+  // their first four feature steps at once and wait for the counter to say "operand published".  A CU takes ~10 bytes per clock from HBM
+  // and a wave with 8 KB to request sits in issue for thousands of cycles (profiles/r06/gemvq_trace.txt): with every wave doing both, the
+  // quantiser's barriers waited for waves stuck in issue (operand published at 12-16 k cycles); with s_barrier out of the way the
+  // stream starts at ~1 k cycles on waves that have nothing else to do.  The quantiser waves request their own features behind the
+  // last counter.  Same arithmetic on the same bytes either way.
+  constexpr int NP = 8;
+  const bool roles = QOP <= 3 && MT == 1 && p.q_roles != 0;   // (workgroup-uniform)
+  const bool streamer = roles && wave >= NP;
+  const int PT = roles ? NP * 64 : NTH;                       // threads that share the quantiser's work
+  unsigned *sync_cnt = reinterpret_cast<unsigned *>(lds + red_offset(K4h, G) + 32);
+  int sync_no = 0;
+  auto qsync = [&]() {                                        // barrier of the quantiser's waves: an LDS counter (roles) or s_barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (roles) {
+      ++sync_no;
+      if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int guard = 1 << 18;                                    // (bounded: a lost count ends as a wrong answer the tests see, not a hang)
+      while (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(sync_no * NP) && --guard > 0)
+        __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    } else {
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  constexpr int NSYNC = NORM ? 3 : 2;                         // counters the quantiser passes: rows staged, (sum of squares,) codes written
+
   // ---- everything the quantiser reads, requested first: one memory round trip for the whole prologue.  Whole waves without work
   // issue nothing (wave-uniform guards; a CU's vector-memory path takes ~20 cycles per wave instruction: the s_memtime trace of the
   // first version, profiles/r06/gemvq_trace.txt, had 4-8 k cycles of request issue in front of the quantiser)
@@ -138,8 +163,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   for (int t = 0; t < TPT; ++t) {
     q_ri[t] = v2u{0u, 0u};
     if constexpr (QOP == 4) q_rb[t] = v2u{0u, 0u};
-    if (wbase + t * NTH < ntask) {                           // (wave-uniform)
-      const int task = min(tid + t * NTH, ntask - 1), m = task / tpr, e0 = (task - m * tpr) * CPT;
+    if (!streamer && wbase + t * PT < ntask) {               // (wave-uniform)
+      const int task = min(tid + t * PT, ntask - 1), m = task / tpr, e0 = (task - m * tpr) * CPT;
       if constexpr (QOP == 4) {
         q_ri[t] = *reinterpret_cast<const v2u *>(p.q_x + (int64_t)m * H + e0);
         q_rb[t] = *reinterpret_cast<const v2u *>(p.q_x2 + (int64_t)m * H + e0);
@@ -168,8 +193,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     for (int i = 0; i < XC; ++i) {
       q_xr[i] = h8{};
       if constexpr (QOP == 3) q_rr[i] = h8{};
-      if (wbase + i * NTH < p.M * q_nchunks) {
-        const int c = min(tid + i * NTH, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+      if (!streamer && wbase + i * PT < p.M * q_nchunks) {
+        const int c = min(tid + i * PT, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
         q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
         if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
       }
@@ -178,81 +203,46 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {
         q_wr[i] = h8{};
-        if (wbase + i * NTH < q_nchunks)
-          q_wr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x2) + min(tid + i * NTH, q_nchunks - 1) * 16);
+        if (!streamer && wbase + i * PT < q_nchunks)
+          q_wr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x2) + min(tid + i * PT, q_nchunks - 1) * 16);
       }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  // LDS prefetch (round 6, p.q_lf > 0: RMSNorm forms at one token): the waves WITHOUT a row chunk to stage -- waves nstage .. 15 -- are
-  // the workgroup's loaders: behind their own (late-needed) task inputs they request the first q_lf features of EVERY wave by LDS-DMA,
-  // into LDS, while waves 0 .. nstage - 1 stage the rows and run the sum of squares.  The stream then starts ~1 k cycles into the
-  // kernel instead of behind the quantiser's first barrier, occupies no registers, and blocks (at the CU's ~10 B per clock from HBM)
-  // only waves that have nothing else to do; the staging waves synchronise among themselves through an LDS counter instead of an
-  // s_barrier the loaders would arrive late at.
-  const int nstage = (p.M * q_nchunks + 63) >> 6;            // waves with a row chunk to stage
-  const int lf = (NORM && MT == 1) ? p.q_lf : 0;             // (workgroup-uniform)
-  const bool loader = lf > 0 && wave >= nstage;
-  unsigned *stage_cnt = reinterpret_cast<unsigned *>(lds + red_offset(K4h, G) + 32);
-  const unsigned wl0 = lds_addr(lds) + (unsigned)quant_lds_bytes(QOP, K4h, G);   // [16 waves][lf][NCH][1 KiB]
-  if (lf > 0 && tid == 0) *stage_cnt = 0u;
+  if (roles && tid == 0) *sync_cnt = 0u;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // every wave's quantiser requests are in the memory pipeline before ANY weight request goes out (one s_barrier: the 128 weight
   // requests of a workgroup would otherwise sit in front of the later waves' row chunks)
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- the weights of this wave's first D steps (NCH <= 2: its first D features): in flight while the quantiser runs
+  // ---- the weights of this wave's first D steps (NCH <= 2: its first D features)
   constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1), PCH = NCH / PARTS;
-  constexpr int D = 4;                                            // ring slots; the unrolled loop below needs PARTS | D
+  constexpr int D = (NCH <= 4 && MT == 1) ? 6 : 4;                             // ring slots; the unrolled loop below needs PARTS | D
   static_assert(PCH * PARTS == NCH && D % PARTS == 0, "chunks per lane: 1, 2, 4, 6 or 8");
   PartW<PCH> ring[D];
   v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
   unsigned short ringsb8[D / PARTS];
-  const int nfeat_all = f0 + wave < f1 ? (f1 - (f0 + wave) + NWV - 1) / NWV : 0;   // features of this wave
-  constexpr int LFM = 2;                                          // LDS features per wave at most
-  const int lfe = min(lf, nfeat_all);                             // ... of THIS wave: its features 0 .. lfe - 1 arrive in LDS
-  const int n0w = f0 + wave + lfe * NWV;                          // the register ring takes the others
-  const int nfeat = nfeat_all - lfe;
+  // (roles: the quantiser waves request their own features behind the last counter.  Giving ALL features to the streamers -- nothing
+  // requested late -- measured the same: eight waves then do the arithmetic of sixteen, 1.2 k instead of 0.8 k cycles per feature step)
+  const int fstride = NWV;
+  const int n0w = f0 + wave;
+  const int nfeat = n0w < f1 ? (f1 - n0w + fstride - 1) / fstride : 0;    // features of this wave
   const int nsteps = nfeat * PARTS;
-  unsigned short lsbu[LFM][NCH], lsb8[LFM];                       // the scales / keeper chunk of the LDS features (registers)
-  v4i lw8[LFM];
   auto issue_ring = [&](int u0, int u1) {
 #pragma unroll
   for (int u = 0; u < D; ++u) {
-    if (u >= u0 && u < u1 && (u < nsteps || (u < PARTS && lfe == 0)))                    // (wave-uniform; a wave without features still reads one valid row)
-      load_part<PCH>(p, min(n0w + (u / PARTS) * NWV, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
+    if (u >= u0 && u < u1 && (u < nsteps || (u < PARTS && !roles)))                      // (wave-uniform; a wave without features still reads one valid row)
+      load_part<PCH>(p, min(n0w + (u / PARTS) * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
                      ringsb8[u / PARTS]);
   }
   };
-  auto issue_small = [&]() {                                      // the scales and the keeper chunk of this wave's LDS features
-#pragma unroll
-  for (int j = 0; j < LFM; ++j)
-    if (j < lfe) {
-      const int n = f0 + wave + j * NWV;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        lsbu[j][c] = reinterpret_cast<const unsigned short *>(p.sB)[(int64_t)(min(lane + 64 * c, nchunks - 1) >> 2) * p.N + n];
-      lw8[j] = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
-      lsb8[j] = reinterpret_cast<const unsigned short *>(p.sB8)[n];
-    }
-  };
-  if (loader) {                                                   // the LDS-DMA requests of the whole workgroup's LDS features
-    issue_small();                                                // (in front of them: they return first)
-    const int nl = NWV - nstage;
-    for (int cw = wave - nstage; cw < NWV; cw += nl) {
-#pragma unroll
-      for (int j = 0; j < LFM; ++j) {
-        const int n = f0 + cw + j * NWV;
-        if (j < lf && n < f1) {                                   // (wave-uniform)
-#pragma unroll
-          for (int c = 0; c < NCH; ++c)
-            if (c * 64 < nchunks)
-              lds_dma_at<16>(p.B4 + (int64_t)n * K4h + min(lane + 64 * c, nchunks - 1) * 16, wl0 + (unsigned)(((cw * lf + j) * NCH + c) * 1024));
-        }
-      }
-    }
-  }
+  // ---- the quantiser: the token rows' packed operand, built in LDS (its barriers wait for LDS only)
+  uint8_t *qa4 = reinterpret_cast<uint8_t *>(lds);                                        // [MQ][K4h]
+  uint8_t *qa8 = qa4 + MQ * K4h;                                                          // [MQ][128]
+  half_t *qsa = reinterpret_cast<half_t *>(qa8 + MQ * kKeeper);                           // [G][MQ]
+  half_t *qsa8 = qsa + (size_t)G * MQ;                                                    // [MQ]
+  if (!streamer) {
   GQ_STAMP(1);                                               // every request issued
   __builtin_amdgcn_sched_barrier(0);
   // nothing of the quantiser moves up between the loads above, and none of its requests sinks into a branch below
@@ -276,16 +266,6 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
   }
 
-  // ---- the quantiser: the token rows' packed operand, built in LDS (its barriers wait for LDS only)
-  uint8_t *qa4 = reinterpret_cast<uint8_t *>(lds);                                        // [MQ][K4h]
-  uint8_t *qa8 = qa4 + MQ * K4h;                                                          // [MQ][128]
-  half_t *qsa = reinterpret_cast<half_t *>(qa8 + MQ * kKeeper);                           // [G][MQ]
-  half_t *qsa8 = qsa + (size_t)G * MQ;                                                    // [MQ]
-  {
-    auto lds_barrier = [] {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
     float *red = reinterpret_cast<float *>(lds + red_offset(K4h, G));                     // [MQ][4] partial sums of squares
     char *rowbuf = reinterpret_cast<char *>(red) + RED_BYTES;                             // [MQ][H] halves, then the norm weights [H]
     char *wbuf = rowbuf + MQ * H * 2;
@@ -330,7 +310,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     if constexpr (QOP <= 3) {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
-        const int c = tid + i * NTH;                         // the first workgroup writes the residual stream)
+        const int c = tid + i * PT;                          // the first workgroup writes the residual stream)
         if (c < p.M * q_nchunks) {
           const int m = c / q_nchunks, cc = c - m * q_nchunks;
           h8 v = q_xr[i];
@@ -344,35 +324,22 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       if constexpr (QOP >= 2) {
 #pragma unroll
         for (int i = 0; i < XC; ++i)
-          if (tid + i * NTH < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * NTH) * 16) = q_wr[i];
+          if (tid + i * PT < q_nchunks) *reinterpret_cast<h8 *>(wbuf + (tid + i * PT) * 16) = q_wr[i];
       }
     }
     const bool sumsq_wave = NORM && (tid >> 8) < p.M;        // (wave-uniform) waves 4 m .. 4 m + 3: the tree of row m
     if constexpr (ROWS) {
       GQ_STAMP(2);                                             // the quantiser's inputs have arrived and sit in LDS
-      if (lf > 0) {                                            // staging waves only: count in; the tree's waves wait for all of them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wave < nstage && lane == 0) __hip_atomic_fetch_add(stage_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (sumsq_wave) {
-          int guard = 1 << 16;                                 // (bounded: a lost count ends as a wrong answer the tests see, not a hang)
-          while (__hip_atomic_load(stage_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)nstage && --guard > 0)
-            __builtin_amdgcn_s_sleep(1);
-          asm volatile("" ::: "memory");
-        }
-      } else {
-        lds_barrier();
-      }
+      qsync();
       GQ_STAMP(3);
     }
-    // the weights of this wave's first D steps go out HERE: in front of the quantiser's own requests they held every wave at the
-    // CU's vector-memory issue rate (~20 cycles per wave instruction: 4-12 k cycles before the first row chunk reached LDS,
-    // profiles/r06/gemvq_trace.txt); from here they overlap the sum of squares and the codes -- except on the waves that run the sum
-    // of squares (theirs go out behind it: a wave stuck in request issue held the tree, and with it everybody's barrier, for 6-10 k
-    // cycles) and on the loader waves (behind the last barrier: their queue is full of LDS-DMA)
-    // (half of the ring up front, half here: measured equal to worse -- a CU streams ~10 bytes per clock from HBM whatever the order.
-    // SiLU x up has no barrier in front of its codes and two 8-byte inputs per task in registers: its ring goes out behind the codes)
+    // Without roles the weights of this wave's first D steps go out HERE: in front of the quantiser's own requests they held every wave
+    // at the CU's vector-memory issue rate (4-12 k cycles before the first row chunk reached LDS, profiles/r06/gemvq_trace.txt); from
+    // here they overlap the sum of squares and the codes -- except on the waves that run the sum of squares (theirs go out behind it).
+    // (Half of the ring up front, half here: measured equal to worse.  SiLU x up has no barrier in front of its codes and two 8-byte
+    // inputs per task in registers: its ring goes out behind the codes.)
     if constexpr (QOP != 4) {
-      if (!sumsq_wave && !loader) { issue_ring(0, D); issue_small(); }
+      if (!roles && !sumsq_wave) issue_ring(0, D);
     }
     float rinv[MQ] = {0.f, 0.f};
     if constexpr (QOP == 2 || QOP == 3) {
@@ -387,9 +354,9 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         ss = wave_sum_butterfly(ss);
         if (lane == 0) red[m * 4 + (wave & 3)] = ss;
       }
-      lds_barrier();
+      qsync();
       GQ_STAMP(4);                                             // sum of squares done
-      if (sumsq_wave && !loader) { issue_ring(0, D); issue_small(); }
+      if (!roles && sumsq_wave) issue_ring(0, D);
 #pragma unroll
       for (int m2 = 0; m2 < MQ; ++m2) {
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
@@ -401,8 +368,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     // values, the same maximum, the same scale, the same codes -- spread over four times the threads)
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
-      if (wbase + t * NTH < ntask) {                         // (wave-uniform; ntask is a multiple of 32: whole groups per wave half)
-        const int task = min(tid + t * NTH, ntask - 1);
+      if (wbase + t * PT < ntask) {                          // (wave-uniform; ntask is a multiple of 32: whole groups per wave half)
+        const int task = min(tid + t * PT, ntask - 1);
         const int m = task / tpr, e0 = (task - m * tpr) * CPT;
         const int g = e0 >> 7, j = (e0 >> 2) & 31;
         const bool keeper = g == Gt - 1;
@@ -434,7 +401,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         float tr[CPT];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) tr[i] = group_code<false>(v[i], gs);
-        if (tid + t * NTH < ntask) {
+        if (tid + t * PT < ntask) {
           if (keeper) {                                        // 4 INT8 codes: one word of pack_codes16's keeper form
             const float lo = __builtin_fmaf(tr[1], 256.f, tr[0] + 32896.f), hi = __builtin_fmaf(tr[3], 256.f, tr[2] + 32896.f);
             *reinterpret_cast<unsigned *>(qa8 + m * kKeeper + j * 4) = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
@@ -455,10 +422,18 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
     if constexpr (QOP == 4) issue_ring(0, D);
     GQ_STAMP(5);                                               // codes written
-    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA pieces have landed (nothing younger is in flight)
-    lds_barrier();
-    GQ_STAMP(6);                                               // the packed operand (and the LDS features' weights) are published
-    if (loader) issue_ring(0, D);
+    qsync();
+    GQ_STAMP(6);                                               // the packed operand is published
+    if (roles) issue_ring(0, D);                               // the quantiser waves' own features
+  } else {
+    // streamers: the stream starts here; the operand is published once the quantiser's waves have passed their last counter
+    issue_ring(0, D);
+    GQ_STAMP(1);
+    int guard = 1 << 20;
+    while (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(NSYNC * NP) && --guard > 0)
+      __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+    GQ_STAMP(6);
   }
 
   // ---- the feature loop: gemv1_w4a4_kernel's arithmetic, feature by feature.  Step s = (feature s / PARTS, part s % PARTS) sits in
@@ -515,19 +490,6 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       acc[m] = (leader && ok) ? next : acc[m];
     }
   };
-  // the features whose weights the loaders put into LDS: same chunks in the same order, read with ds_read_b128
-#pragma unroll
-  for (int j = 0; j < LFM; ++j)
-    if (j < lfe) {
-      float acc[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-      const char *wl = lds + quant_lds_bytes(QOP, K4h, G) + ((wave * lf + j) * NCH) * 1024 + lane * 16;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (c * 64 < nchunks) chunk(lane + 64 * c, *reinterpret_cast<const v4i *>(wl + c * 1024), lsbu[j][c], acc);
-      finish(f0 + wave + j * NWV, acc, lw8[j], lsb8[j]);
-    }
   for (int base = 0; base < nsteps; base += D) {
     float acc[MT];
 #pragma unroll
@@ -535,7 +497,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       const int part = u % PARTS;
       const int fi = base / PARTS + u / PARTS;              // this wave's fi-th feature
       if (base + u < nsteps) {                              // (wave-uniform)
-        const int n = n0w + fi * NWV;
+        const int n = n0w + fi * fstride;
         PartW<PCH> &f = ring[u];
         if (part == 0) {
 #pragma unroll
@@ -544,9 +506,9 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #pragma unroll
         for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc);
         if (part == PARTS - 1) finish(n, acc, ring8[u / PARTS], ringsb8[u / PARTS]);
-        if (base + u < 4) GQ_STAMP(7 + base + u);            // steps 0 .. 3 done
+        if (base == 0 && u < 4) GQ_STAMP(7 + u);              // steps 0 .. 3 done
         if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
-          load_part<PCH>(p, n + (D / PARTS) * NWV, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
+          load_part<PCH>(p, n + (D / PARTS) * fstride, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
       }
     }
   }
@@ -558,22 +520,15 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 
 template <int QOP, int NCH, int MT>
 static int launch1(const GemmParams &p, hipStream_t s) {
-  // LDS prefetch by loader waves (the kernel's `lf`): the RMSNorm forms at one token, at least four waves without a row chunk to stage,
-  // one or two features per wave by what fits 150 KiB
+  // roles (the kernel's comment): one token, ops 1-3, the rows and the norm weight within one 16-byte chunk per thread of the eight
+  // quantiser waves and at most TPT1 tasks per thread of them.  (Round 6 also built LOADER waves that fetched every wave's first
+  // features into LDS by LDS-DMA: bit-identical and slower -- profiles/r06/ab_gemvq_lds_prefetch.txt, commit ea86eed -- and removed.)
   GemmParams q = p;
-  q.q_lf = 0;
-  if ((QOP == 2 || QOP == 3) && MT == 1 && (p.K4h * 2 + kKeeper) / 8 <= 12 * 64) {
-    // Built, bit-identical (tests/test_gpu_e2e.py with ATOM_GEMVQ_LF=2 in a tools build) and SLOWER: the Llama-7B layer at batch 1 takes
-    // 60.9 us cold with it against 53.5 without (same box, profiles/r06/ab_gemvq_lds_prefetch.txt) -- the loaders need 4-5.5 k cycles to
-    // get their eight requests each into the CU's memory queue, reach the barrier behind the sum of squares at 9-11 k cycles instead of
-    // 5 k, and issue their own ring last.  Off (0) in the product; the tools build takes ATOM_GEMVQ_LF.
-    int lf = ATOM_TUNE("ATOM_GEMVQ_LF", 0);
-    while (lf > 0 && lds_bytes(QOP, p.K4h, p.G, lf, NCH) > (size_t)150 * 1024) --lf;
-    q.q_lf = lf > 2 ? 2 : lf;
-  }
-  const size_t lds = lds_bytes(QOP, p.K4h, p.G, q.q_lf, NCH);
+  const int H_ = p.K4h * 2 + kKeeper;
+  q.q_roles = (QOP <= 3 && MT == 1 && p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64) ? ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) : 0;
+  const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 160 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   // one workgroup per CU at most; every wave of it at least one feature
   const int cap = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
   int grid = p.N / NWV;
