@@ -10,12 +10,18 @@
 // that the quantiser runs ONCE PER CU:
 //   * grid = one workgroup of 16 waves per CU (at most); a workgroup owns a contiguous range of the output features (XCD-contiguous:
 //     a 64-byte line of weight scales serves 32 adjacent features), wave w of it the features w, w + 16, ... of that range;
-//   * every wave requests the weight chunks of its FIRST TWO features before anything else, then the workgroup runs the quantiser
-//     (1024 threads: every load of the token rows, norm weights and reorder indices is issued in one batch, three LDS barriers) and
-//     leaves the packed operand -- INT4 codes, INT8 keeper, fp16 scales: the bytes the stand-alone quantiser kernels write -- in LDS;
-//   * the feature loop keeps two features' weights in flight per wave (32 waves x 2-8 KiB per CU), reads the token's codes out of LDS
-//     (one ds_read_b128 per weight chunk) and forms every sum exactly as gemv1_w4a4_kernel does: lane l owns chunks l, l + 64, ... in
-//     ascending order, a quad sums a group exactly, the quad leader applies c = fma(idot, sA * sB, c), 64-lane butterfly, keeper last.
+//   * the quantiser's own requests (token rows, norm weights, reorder indices) go out FIRST, in one batch, and one s_barrier keeps
+//     every weight request behind them: the chip hands a CU about 10 bytes per clock, so whatever is requested first is what arrives
+//     first (with the weight ring in front, the quantiser's inputs reached LDS after 6-12 k cycles: profiles/r06/gemvq_trace.txt);
+//   * at one token the waves have roles (q_roles): waves 0-7 run the quantiser and synchronise through an LDS counter (qsync), waves
+//     8-15 request their first D feature steps right behind the barrier and spin on that counter until the packed operand -- INT4
+//     codes, INT8 keeper, fp16 scales: the bytes the stand-alone quantiser kernels write -- is in LDS; the quantiser waves request their
+//     features behind their last qsync.  At two tokens, and for the ops whose rows need all 1024 threads (SiLU x up, split merge),
+//     every wave does both jobs with s_barrier in qsync's place (profiles/r06/ab_gemvq_roles.txt);
+//   * the feature loop keeps a ring of D steps in flight per wave (a step = a whole, a half or a quarter of one feature's chunks:
+//     PartW below), refilled in place inside a loop unrolled by D, reads the token's codes out of LDS (one ds_read_b128 per weight
+//     chunk) and forms every sum exactly as gemv1_w4a4_kernel does: lane l owns chunks l, l + 64, ... in ascending order, a quad sums a
+//     group exactly, the quad leader applies c = fma(idot, sA * sB, c), 64-lane butterfly, keeper last.
 // Output: bit-identical to the stand-alone quantiser launch followed by atom_gemm_w4a4_multi (which runs gemv1_w4a4_kernel for these
 // token counts) -- atom_gemm_w4a4_packed_order() = 64 on both sides.
 // Quantiser arithmetic: the kernel-flavoured mode of quant_kernels.hip slot by slot (Reorder.cuh:137-178, RMSNorm.cuh:112-151,
