@@ -160,6 +160,7 @@ struct DecodeParams {
 // (x >> 4k) & 0x000F000F | 0x64006400 is one v_and_or_b32 (plus one shift for k > 0): 7 instructions per 8 elements,
 // and v_fma_mix_f32 reads the halves directly.  The bias 1024 is removed once per token, never per element.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nib8h(unsigned x, h2 (&m)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -212,13 +213,31 @@ __device__ __forceinline__ TileRegs load_tile(const TileBase &tb, int64_t page, 
   return r;
 }
 
-__global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
-  const int lane = threadIdx.x;
+// WGM (round 6): the KV splits of a (sequence, head) pair are WAVES of one workgroup and their partial states meet in LDS -- no workspace,
+// no merge launch (4.7 us of a decode step at batch 16).  A workgroup is always 12 waves = a CU's resident set at this kernel's
+// registers: 12 / splits pairs x splits (a 6-wave workgroup per pair left every second wave slot empty -- the second one does not fit
+// beside the first's 2 + 2 + 1 + 1 waves per SIMD -- and cost 38.5 us instead of 27.3: profiles/r06/ab_decode_ring.txt).  Used when
+// pairs alone fill the chip and splits divides 12 (batch_decode_impl).  The merge below is decode_merge_kernel's, operation for
+// operation: same bits.
+constexpr int kWgmWaves = 12;
+template <bool WGM>
+__global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_kernel(DecodeParams p) {
+  const int lane = threadIdx.x & 63;
   const int t = lane >> 2, u = lane & 3;
   const int N = p.kv.N, P = p.kv.P;
-  const int h = blockIdx.x % N, b = blockIdx.x / N, sp = blockIdx.y;
+  int pair = blockIdx.x, sp = blockIdx.y, lp = 0;       // (sequence, head) pair, KV split, pair within the workgroup
+  bool live = true;
+  if constexpr (WGM) {
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    lp = w / p.splits;
+    sp = w - lp * p.splits;
+    pair = (int)blockIdx.x * (kWgmWaves / p.splits) + lp;
+    live = pair < p.kv.batch * N;                       // (the last workgroup's spare waves: no tiles, no writes, the barriers only)
+    pair = min(pair, p.kv.batch * N - 1);
+  }
+  const int h = pair % N, b = pair / N;
   const int pg0 = p.kv.indptr[b];
-  const int seq_len = (p.kv.indptr[b + 1] - pg0 - 1) * P + p.kv.last_page_offset[b];
+  const int seq_len = live ? (p.kv.indptr[b + 1] - pg0 - 1) * P + p.kv.last_page_offset[b] : 0;
   const int ntiles = (max(seq_len, 0) + 15) >> 4;       // (an empty sequence: no tiles, no page-table read, output zeros)
   const int chunk = (ntiles + p.splits - 1) / p.splits;
   const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
@@ -244,8 +263,9 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   // last token quantises them (lanes 0-31 K, 32-63 V: kv_quant_append_kernel's arithmetic), writes the cache slot, and hands the 64 + 64
   // code bytes and the two (scale, zero) pairs to the lane of that token through LDS -- the attention below never waits for the store
   // to come back from memory, and the step saves a launch.  Same cache bytes, same output as append -> decode.
-  __shared__ unsigned short stash_q[2][32];
-  __shared__ unsigned stash_sz[2];
+  constexpr int LP = WGM ? kWgmWaves / 2 : 1;           // pairs per workgroup at most
+  __shared__ unsigned short stash_q[LP][2][32];
+  __shared__ unsigned stash_sz[LP][2];
   const int last_tile = (seq_len - 1) >> 4;
   const bool appends = p.k32 != nullptr && seq_len > 0 && last_tile >= tile0 && last_tile < tile1;   // wave-uniform
   if (appends) {
@@ -257,17 +277,20 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     const int64_t slot = ((((int64_t)p.kv.indices[pg0 + pos / P] * p.kv.L + p.kv.layer) * 2 + kvh) * N + h) * P + pos % P;
     *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = w;
     if (l == 0) *reinterpret_cast<unsigned *>(p.kv.param + slot * 2) = sz;
-    stash_q[kvh][l] = w;
-    if (l == 0) stash_sz[kvh] = sz;
+    stash_q[lp][kvh][l] = w;
+    if (l == 0) stash_sz[lp][kvh] = sz;
   }
   __syncthreads();
+  // (a deeper ring -- 3, 4, 6 tiles requested per wave, refilled in place -- measured slower at every batch: profiles/r06/ab_decode_ring.txt)
   TileRegs cur, nxt;
   if (tile0 < tile1) cur = load_tile(tb, page_of(tile0), tile0 % tpp);
   if (tile0 + 1 < tile1) nxt = load_tile(tb, page_of(tile0 + 1), (tile0 + 1) % tpp);
   int64_t page2 = page_of(tile0 + 2);
 
   // q rotated to the relative position of MY token of the first tile: A = R((len-1 - j) f) q, pairs (i, i+64)
-  float A1[16], A2[16], C16[16], S16[16];
+  // (round 6: kept as register PAIRS -- A[i] = {A1, A2}, SC[i] = {sin, cos} of the 16-position step -- so that the per-tile rotation is
+  // two packed FP32 instructions per pair instead of four scalar ones, and the sum of A sixteen packed adds instead of 32)
+  v2f A[16], SC[16];
   {
     const half_t *qp = p.q + ((int64_t)b * N + h) * kHeadDim;
     v4u r1[2], r2[2];
@@ -285,9 +308,10 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
       float s, c;
       sincos_rev(delta * fr, s, c);
       const float q1 = (float)h1[i], q2 = (float)h2p[i];
-      A1[i] = q1 * c - q2 * s;
-      A2[i] = q2 * c + q1 * s;
-      sincos_rev(16.0f * fr, S16[i], C16[i]);
+      A[i] = v2f{q1 * c - q2 * s, q2 * c + q1 * s};
+      float s16, c16;
+      sincos_rev(16.0f * fr, s16, c16);
+      SC[i] = v2f{s16, c16};
     }
   }
 
@@ -304,16 +328,17 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     page2 = page_of(tile + 3);
     const bool valid = tile * 16 + t < seq_len;
     if (appends && tile == last_tile && t == ((seq_len - 1) & 15)) {   // my token is the one appended above: its bytes come from LDS
-      const char *sk = reinterpret_cast<const char *>(&stash_q[0][0]), *sv = reinterpret_cast<const char *>(&stash_q[1][0]);
+      const char *sk = reinterpret_cast<const char *>(&stash_q[lp][0][0]), *sv = reinterpret_cast<const char *>(&stash_q[lp][1][0]);
       r.k1 = *reinterpret_cast<const v2u *>(sk + 8 * u);
       r.k2 = *reinterpret_cast<const v2u *>(sk + 32 + 8 * u);
       r.v = *reinterpret_cast<const v4u *>(sv + 16 * u);
-      r.kq = stash_sz[0];
-      r.vq = stash_sz[1];
+      r.kq = stash_sz[lp][0];
+      r.vq = stash_sz[lp][1];
     }
 
     // score = sum over my 16 pairs of (u1*ks - kz) * A1 + (u2*ks - kz) * A2 = ks * sum((1024+u) . A) - (kz + 1024 ks) * sum(A)
-    float acc = 0.f, sumA = 0.f;
+    float acc = 0.f;
+    v2f sum2 = v2f{0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       h2 m1[4], m2[4];
@@ -321,14 +346,15 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
       nib8h(r.k2[w], m2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        acc = __builtin_fmaf((float)m1[k].x, A1[8 * w + k], acc);
-        acc = __builtin_fmaf((float)m1[k].y, A1[8 * w + 4 + k], acc);
-        acc = __builtin_fmaf((float)m2[k].x, A2[8 * w + k], acc);
-        acc = __builtin_fmaf((float)m2[k].y, A2[8 * w + 4 + k], acc);
+        acc = __builtin_fmaf((float)m1[k].x, A[8 * w + k].x, acc);
+        acc = __builtin_fmaf((float)m1[k].y, A[8 * w + 4 + k].x, acc);
+        acc = __builtin_fmaf((float)m2[k].x, A[8 * w + k].y, acc);
+        acc = __builtin_fmaf((float)m2[k].y, A[8 * w + 4 + k].y, acc);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sumA += A1[i] + A2[i];
+    for (int i = 0; i < 16; ++i) sum2 += A[i];             // v_pk_add_f32
+    const float sumA = sum2.x + sum2.y;
     const float ks = (float)__builtin_bit_cast(half_t, (unsigned short)(r.kq & 0xFFFF));
     const float kz = (float)__builtin_bit_cast(half_t, (unsigned short)(r.kq >> 16));
     float s = quad_sum_f(__builtin_fmaf(acc, ks, -(__builtin_fmaf(kNibBias, ks, kz) * sumA))) * qk_scale;
@@ -367,9 +393,10 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
     // my token of the next tile is 16 positions later: A <- R(-16 f) A = (A1 C + A2 S, A2 C - A1 S)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float a1 = A1[i], a2 = A2[i];
-      A1[i] = __builtin_fmaf(a1, C16[i], a2 * S16[i]);
-      A2[i] = __builtin_fmaf(-a1, S16[i], a2 * C16[i]);
+      // {fma(a1, C, a2 * S), fma(a1, -S, a2 * C)}: the scalar form's four operations, bit for bit (fma(-a1, S, x) = fma(a1, -S, x))
+      v2f tt;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=&v"(tt) : "v"(A[i]), "v"(SC[i]));
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(A[i]) : "v"(A[i]), "v"(SC[i]), "v"(tt));
     }
   }
 
@@ -398,6 +425,40 @@ __global__ __launch_bounds__(64, 3) void batch_decode_kernel(DecodeParams p) {
   zacc = over_quads(zacc * sc, fadd);
 #pragma unroll
   for (int i = 0; i < 32; ++i) o[i] = over_quads(o[i] * sc, fadd) - zacc;   // sum p*(s*u - z)
+  if constexpr (WGM) {
+    // partial states [wave][130] through LDS, then decode_merge_kernel's arithmetic: 128 threads per pair
+    __shared__ float part[kWgmWaves][kHeadDim + 2];
+    const int w = lp * p.splits + sp;
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<v4f *>(&part[w][32 * u + 4 * i]) = v4f{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+      if (u == 0) {
+        part[w][kHeadDim] = mall;
+        part[w][kHeadDim + 1] = d;
+      }
+    }
+    __syncthreads();
+    const int mp = (int)threadIdx.x >> 7, dim = (int)threadIdx.x & 127;
+    const int mpair = (int)blockIdx.x * (kWgmWaves / p.splits) + mp;
+    if (mp >= kWgmWaves / p.splits || mpair >= p.kv.batch * N) return;
+    const float(*pp)[kHeadDim + 2] = &part[mp * p.splits];
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < kWgmWaves; ++s)
+      if (s < p.splits) M = fmaxf(M, pp[s][kHeadDim]);
+    float acc = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < kWgmWaves; ++s)
+      if (s < p.splits) {
+        const float mv = pp[s][kHeadDim];
+        const float wgt = mv == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv - M);
+        acc = __builtin_fmaf(pp[s][dim], wgt, acc);
+        den = __builtin_fmaf(pp[s][kHeadDim + 1], wgt, den);
+      }
+    p.o[(int64_t)mpair * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
+    return;
+  }
   if (t != 0) return;
   if (p.splits == 1) {
     const float rd = d > 0.f ? 1.0f / d : 0.f;
@@ -497,6 +558,7 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
 // rounds x (tiles per wave + 2) under at least 8 tiles per split (measured: profiles/r01_kv_decode.txt).
 static int decode_splits(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
+  if (const int forced = ATOM_TUNE("ATOM_DECODE_SPLITS", 0)) return forced;
   const int64_t tiles = (int64_t)max_pages * (P / 16), pairs = (int64_t)batch * N;
   const int min_tiles = ATOM_TUNE("ATOM_DECODE_MIN_TILES", 4);   // (round 6: 4 -- a wave alone on its SIMD issues one VALU per ~7 cycles, so at small batches twice the waves with half the tiles each win: 11.0 -> 9.0 us at batch 1, context 1024)
   int64_t smax = tiles / min_tiles;
@@ -570,7 +632,10 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   if ((o && !aligned16(o)) || !aligned16(q)) return ATOM_ERR_ALIGN;
   int splits = decode_splits(batch, num_heads, max_pages_per_seq, page_size);
   const size_t need = (size_t)batch * num_heads * splits * (kHeadDim + 2) * sizeof(float);
-  if (splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) splits = 1;
+  // sequences x heads fill the chip on their own: the splits become the waves of one workgroup and merge in LDS -- one launch, no
+  // workspace (same split count, same merge arithmetic: the same bits as kernel + decode_merge_kernel)
+  const bool wgm = o && splits > 1 && kWgmWaves % splits == 0 && (int64_t)batch * num_heads >= ATOM_TUNE("ATOM_DECODE_WGM_PAIRS", 256);
+  if (!wgm && splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) splits = 1;
   // o == NULL: the split partial states stay in the workspace un-merged (atom_batch_decode_i4_splits() of them; the consumer merges:
   // atom_gemm_w4a4_multi_merge_q) -- only meaningful when the KV range IS split
   if (!o && splits < 2) return ATOM_ERR_INVALID_ARG;
@@ -579,7 +644,12 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
                  (const half_t *)q, (half_t *)o, (float *)workspace, splits,
                  1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale, k32, v32};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(batch_decode_kernel, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
+  if (wgm) {
+    const int ppw = kWgmWaves / splits;                 // (sequence, head) pairs per workgroup
+    hipLaunchKernelGGL(batch_decode_kernel<true>, dim3((unsigned)((batch * num_heads + ppw - 1) / ppw)), dim3(64 * kWgmWaves), 0, s, p);
+    return check_launch();
+  }
+  hipLaunchKernelGGL(batch_decode_kernel<false>, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
   if (splits > 1 && o)
     hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace,
                        (half_t *)o, splits);
