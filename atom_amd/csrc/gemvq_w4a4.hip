@@ -105,7 +105,6 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // workgroup b runs on XCD b % 8: XCD-contiguous order, then a contiguous share of the features
   const int xq = (int)gridDim.x >> 3, xr = (int)gridDim.x & 7, xx = blockIdx.x & 7;
   const int lw = xx * xq + min(xx, xr) + ((int)blockIdx.x >> 3);
-  const int f0 = (int)((int64_t)lw * p.N / (int)gridDim.x), f1 = (int)((int64_t)(lw + 1) * p.N / (int)gridDim.x);
 #ifdef ATOM_TOOLS   // tools/r06/gemvq_trace.py: s_memtime stamps of the first and the last workgroup into p.Dsz as u32 [2][16 waves][16]
   unsigned *trb = nullptr;
   if (p.Dsz && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) trb = reinterpret_cast<unsigned *>(p.Dsz) + ((blockIdx.x ? 16 : 0) + wave) * 16;
@@ -115,6 +114,12 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #define GQ_STAMP(k) do { } while (0)
 #endif
   GQ_STAMP(0);
+  {  // the kernel arguments the prologue needs, in ONE batch of scalar loads (left to itself hipcc fetches each where it is first used: a
+     // scalar-cache round trip in front of every group of requests)
+    const void *a0 = p.q_x, *a1 = p.q_x2, *a2 = p.q_res, *a3 = p.q_idx, *a4 = p.B4, *a5 = p.sB, *a6 = p.q_res_out;
+    const int i0 = p.M, i1 = p.K4h, i2 = p.G, i3 = p.N, i4 = p.q_roles;
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4));
+  }
   // QOP 5 (round 6): the token rows are the decode attention's output still in KV-split form -- FP32 partial states [M][heads][splits]
   // [128 values, m, d] (csrc/kv_i4.hip) -- merged here exactly as decode_merge_kernel merges them, then reordered and quantised as QOP 1
   constexpr bool ROWS = QOP <= 3 || QOP == 5;               // ops that stage fp16 token rows in LDS (gathered through the reorder index)
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     q_ri[t] = v2u{0u, 0u};
     if constexpr (QOP == 4) q_rb[t] = v2u{0u, 0u};
     if (!streamer && wbase + t * PT < ntask) {               // (wave-uniform)
-      const int task = min(tid + t * PT, ntask - 1), m = task / tpr, e0 = (task - m * tpr) * CPT;
+      const int task = min(tid + t * PT, ntask - 1), m = MT == 1 ? 0 : task / tpr, e0 = (task - m * tpr) * CPT;   // (MT == 1: no division)
       if constexpr (QOP == 4) {
         q_ri[t] = *reinterpret_cast<const v2u *>(p.q_x + (int64_t)m * H + e0);
         q_rb[t] = *reinterpret_cast<const v2u *>(p.q_x2 + (int64_t)m * H + e0);
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     }
   }
   if constexpr (QOP == 5) {                                 // (one chunk per thread: M x K_total <= 8192, gemvq_merge_fits)
-    const int c = min(tid, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+    const int c = min(tid, p.M * q_nchunks - 1), m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
     const float *wp = p.q_part + ((int64_t)(m * (H >> 7) + (cc >> 4)) * p.q_splits) * 130 + (cc & 15) * 8;
     pwp = wp;
 #pragma unroll
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       q_xr[i] = h8{};
       if constexpr (QOP == 3) q_rr[i] = h8{};
       if (!streamer && wbase + i * PT < p.M * q_nchunks) {
-        const int c = min(tid + i * PT, p.M * q_nchunks - 1), m = c / q_nchunks, cc = c - m * q_nchunks;
+        const int c = min(tid + i * PT, p.M * q_nchunks - 1), m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
         q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
         if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
       }
@@ -231,6 +236,10 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   unsigned short ringsb8[D / PARTS];
   // (roles: the quantiser waves request their own features behind the last counter.  Giving ALL features to the streamers -- nothing
   // requested late -- measured the same: eight waves then do the arithmetic of sixteen, 1.2 k instead of 0.8 k cycles per feature step)
+  // (computed HERE, behind the quantiser's requests, and with one 32-bit division: the 64-bit form cost ~250 scalar instructions in
+  // front of the first request)
+  const int fq = p.N / (int)gridDim.x, fr = p.N - fq * (int)gridDim.x;
+  const int f0 = lw * fq + min(lw, fr), f1 = f0 + fq + (lw < fr ? 1 : 0);
   const int fstride = NWV;
   const int n0w = f0 + wave;
   const int nfeat = n0w < f1 ? (f1 - n0w + fstride - 1) / fstride : 0;    // features of this wave
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
         const int c = tid + i * PT;                          // the first workgroup writes the residual stream)
         if (c < p.M * q_nchunks) {
-          const int m = c / q_nchunks, cc = c - m * q_nchunks;
+          const int m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
           h8 v = q_xr[i];
           if constexpr (QOP == 3) {
             v = v + q_rr[i];
@@ -346,6 +355,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     // inputs per task in registers: its ring goes out behind the codes.)
     if constexpr (QOP != 4) {
       if (!roles && !sumsq_wave) issue_ring(0, D);
+    } else {
+      if (p.q_roles & 2) issue_ring(0, D);                   // (SiLU x up, "early ring": behind the gate / up requests, in front of the codes)
     }
     float rinv[MQ] = {0.f, 0.f};
     if constexpr (QOP == 2 || QOP == 3) {
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       GQ_STAMP(4);                                             // sum of squares done
       if (!roles && sumsq_wave) issue_ring(0, D);
 #pragma unroll
-      for (int m2 = 0; m2 < MQ; ++m2) {
+      for (int m2 = 0; m2 < MT; ++m2) {                      // (every thread: ~110 instructions per row)
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
         const float var = (H & (H - 1)) == 0 ? tot * (1.0f / (float)H) : tot / (float)H;
         rinv[m2] = rinv_sqrt_exact(var + p.q_eps);
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     for (int t = 0; t < TPT; ++t) {
       if (wbase + t * PT < ntask) {                          // (wave-uniform; ntask is a multiple of 32: whole groups per wave half)
         const int task = min(tid + t * PT, ntask - 1);
-        const int m = task / tpr, e0 = (task - m * tpr) * CPT;
+        const int m = MT == 1 ? 0 : task / tpr, e0 = (task - m * tpr) * CPT;
         const int g = e0 >> 7, j = (e0 >> 2) & 31;
         const bool keeper = g == Gt - 1;
         float v[CPT];
@@ -426,7 +437,9 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         }
       }
     }
-    if constexpr (QOP == 4) issue_ring(0, D);
+    if constexpr (QOP == 4) {
+      if (!(p.q_roles & 2)) issue_ring(0, D);
+    }
     GQ_STAMP(5);                                               // codes written
     qsync();
     GQ_STAMP(6);                                               // the packed operand is published
@@ -532,6 +545,7 @@ static int launch1(const GemmParams &p, hipStream_t s) {
   GemmParams q = p;
   const int H_ = p.K4h * 2 + kKeeper;
   q.q_roles = (QOP <= 3 && MT == 1 && p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64) ? ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) : 0;
+  if (QOP == 4) q.q_roles = ATOM_TUNE("ATOM_GEMVQ_EARLY4", 1) ? 2 : 0;   // bit 1: SiLU x up requests its weight ring in front of the codes
   const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
   if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
