@@ -26,6 +26,7 @@
 // token counts) -- atom_gemm_w4a4_packed_order() = 64 on both sides.
 // Quantiser arithmetic: the kernel-flavoured mode of quant_kernels.hip slot by slot (Reorder.cuh:137-178, RMSNorm.cuh:112-151,
 // Activate.cuh:112-167), the sum of squares as the same fixed-shape FP32 tree (256 threads per row).
+#include <type_traits>
 #include "common.h"
 #include "quant_math.h"
 
@@ -94,7 +95,7 @@ __device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, 
 
 // QOP: 1 reorder, 2 RMSNorm + reorder, 3 residual add + RMSNorm + reorder, 4 SiLU(x) * x2.  NCH: 16-byte weight chunks per lane
 // (>= ceil(K4 / 2048)).  MT: token rows.
-template <int QOP, int NCH, int MT>
+template <int QOP, int NCH, int MT, int D>
 __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -229,7 +230,11 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 
   // ---- the weights of this wave's first D steps (NCH <= 2: its first D features)
   constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1), PCH = NCH / PARTS;
-  constexpr int D = (NCH <= 4 && MT == 1) ? 6 : 4;                             // ring slots; the unrolled loop below needs PARTS | D
+  // D = ring slots (template): the host picks the number of steps a wave of this launch has when that is <= 6 (launch1), so that the
+  // ring holds a wave's WHOLE share, every slot is requested unconditionally, and the first trip below is straight-line code --
+  // hipcc then waits for exactly the step it is about to use (s_waitcnt vmcnt(n) with n > 0).  With requests or refills under
+  // run-time conditions it falls back to vmcnt(0) at every step: a wave then waited for its whole ring before its first feature and ran
+  // its five or six steps with nothing in flight (~4 k idle cycles at the end of gate / up, profiles/r06/gemvq_trace.txt).
   static_assert(PCH * PARTS == NCH && D % PARTS == 0, "chunks per lane: 1, 2, 4, 6 or 8");
   PartW<PCH> ring[D];
   v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
@@ -244,13 +249,15 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   const int n0w = f0 + wave;
   const int nfeat = n0w < f1 ? (f1 - n0w + fstride - 1) / fstride : 0;    // features of this wave
   const int nsteps = nfeat * PARTS;
-  auto issue_ring = [&](int u0, int u1) {
+  auto issue_ring = [&]() {
 #pragma unroll
-  for (int u = 0; u < D; ++u) {
-    if (u >= u0 && u < u1 && (u < nsteps || (u < PARTS && !roles)))                      // (wave-uniform; a wave without features still reads one valid row)
-      load_part<PCH>(p, min(n0w + (u / PARTS) * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
+    for (int u = 0; u < D; ++u) {                         // (a slot past the wave's last step re-requests that step's feature: an L1 hit)
+      const int fi = min(u / PARTS, max(nfeat - 1, 0));
+      load_part<PCH>(p, min(n0w + fi * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
                      ringsb8[u / PARTS]);
-  }
+      if constexpr (MT == 1 && QOP != 5)                  // step by step: hipcc otherwise issues every step's 16-byte loads first and the
+        __builtin_amdgcn_sched_barrier(0);                // scale loads last -- and step 0 then waits for (nearly) the whole ring
+    }                                                     // (two tokens / the merge op: no registers to spare for the fixed order)
   };
   // ---- the quantiser: the token rows' packed operand, built in LDS (its barriers wait for LDS only)
   uint8_t *qa4 = reinterpret_cast<uint8_t *>(lds);                                        // [MQ][K4h]
@@ -354,9 +361,9 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     // (Half of the ring up front, half here: measured equal to worse.  SiLU x up has no barrier in front of its codes and two 8-byte
     // inputs per task in registers: its ring goes out behind the codes.)
     if constexpr (QOP != 4) {
-      if (!roles && !sumsq_wave) issue_ring(0, D);
+      if (!roles && !sumsq_wave) issue_ring();
     } else {
-      if (p.q_roles & 2) issue_ring(0, D);                   // (SiLU x up, "early ring": behind the gate / up requests, in front of the codes)
+      if (p.q_roles & 2) issue_ring();                   // (SiLU x up, "early ring": behind the gate / up requests, in front of the codes)
     }
     float rinv[MQ] = {0.f, 0.f};
     if constexpr (QOP == 2 || QOP == 3) {
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       }
       qsync();
       GQ_STAMP(4);                                             // sum of squares done
-      if (!roles && sumsq_wave) issue_ring(0, D);
+      if (!roles && sumsq_wave) issue_ring();
 #pragma unroll
       for (int m2 = 0; m2 < MT; ++m2) {                      // (every thread: ~110 instructions per row)
         const float tot = ((red[m2 * 4 + 0] + red[m2 * 4 + 1]) + red[m2 * 4 + 2]) + red[m2 * 4 + 3];
@@ -438,15 +445,15 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       }
     }
     if constexpr (QOP == 4) {
-      if (!(p.q_roles & 2)) issue_ring(0, D);
+      if (!(p.q_roles & 2)) issue_ring();
     }
     GQ_STAMP(5);                                               // codes written
     qsync();
     GQ_STAMP(6);                                               // the packed operand is published
-    if (roles) issue_ring(0, D);                               // the quantiser waves' own features
+    if (roles) issue_ring();                               // the quantiser waves' own features
   } else {
     // streamers: the stream starts here; the operand is published once the quantiser's waves have passed their last counter
-    issue_ring(0, D);
+    issue_ring();
     GQ_STAMP(1);
     int guard = 1 << 20;
     while (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(NSYNC * NP) && --guard > 0)
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // ring slot s % D; a slot is re-filled with step s + D as soon as step s is computed (D - 1 steps of weights in flight per wave, no
   // register copies: the loop is unrolled by D, and PARTS | D keeps a feature's parts inside one trip)
   const bool leader = (lane & 3) == 0;
-  auto finish = [&](int n, const float (&acc)[MT], const v4i &w8, unsigned short sb8u) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
+  auto finish = [&](int seg, int nl, const float (&acc)[MT], const v4i &w8, unsigned short sb8u) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
     const float sb8f = (float)__builtin_bit_cast(half_t, sb8u);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -477,7 +484,6 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       s = wave_sum_butterfly(s);
       if (lane == 0 && m < p.M) {
         const float c = __builtin_fmaf((float)d, sa8f * sb8f, s);
-        const int seg = n / p.seg_n, nl = n - seg * p.seg_n;
         void *out = seg == 0 ? p.seg_out[0] : (seg == 1 ? p.seg_out[1] : p.seg_out[2]);
         const int64_t at = (int64_t)m * p.seg_n + nl;
         if ((p.seg_f32 >> seg) & 1u) {
@@ -509,8 +515,12 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       acc[m] = (leader && ok) ? next : acc[m];
     }
   };
-  for (int base = 0; base < nsteps; base += D) {
-    float acc[MT];
+  // output segment of this wave's current feature, advanced by the feature stride (a division per feature cost ~20 scalar instructions
+  // of the ~100 a step has)
+  int seg = n0w / p.seg_n, nl = n0w - seg * p.seg_n;
+  float acc[MT];
+  auto trip = [&](auto first_c, int base) {
+    constexpr bool FIRST = decltype(first_c)::value;
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       const int part = u % PARTS;
@@ -524,12 +534,22 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc);
-        if (part == PARTS - 1) finish(n, acc, ring8[u / PARTS], ringsb8[u / PARTS]);
-        if (base == 0 && u < 4) GQ_STAMP(7 + u);              // steps 0 .. 3 done
+        if (part == PARTS - 1) {
+          finish(seg, nl, acc, ring8[u / PARTS], ringsb8[u / PARTS]);
+          nl += fstride;
+          while (nl >= p.seg_n) { nl -= p.seg_n; ++seg; }
+        }
+        if (FIRST && u < 4) GQ_STAMP(7 + u);                // steps 0 .. 3 done
         if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
           load_part<PCH>(p, n + (D / PARTS) * fstride, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
       }
     }
+  };
+  if constexpr (MT == 1) {
+    trip(std::true_type{}, 0);                               // straight-line: precise waits on the ring
+    for (int base = D; base < nsteps; base += D) trip(std::false_type{}, base);
+  } else {                                                   // (two tokens: one copy of the step code -- registers)
+    for (int base = 0; base < nsteps; base += D) trip(std::false_type{}, base);
   }
   GQ_STAMP(11);                                              // all features of this wave done
 #ifdef ATOM_TOOLS
@@ -537,8 +557,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #endif
 }
 
-template <int QOP, int NCH, int MT>
-static int launch1(const GemmParams &p, hipStream_t s) {
+template <int QOP, int NCH, int MT, int D>
+static int launch1d(const GemmParams &p, hipStream_t s) {
   // roles (the kernel's comment): one token, ops 1-3, the rows and the norm weight within one 16-byte chunk per thread of the eight
   // quantiser waves and at most TPT1 tasks per thread of them.  (Round 6 also built LOADER waves that fetched every wave's first
   // features into LDS by LDS-DMA: bit-identical and slower -- profiles/r06/ab_gemvq_lds_prefetch.txt, commit ea86eed -- and removed.)
@@ -548,14 +568,38 @@ static int launch1(const GemmParams &p, hipStream_t s) {
   if (QOP == 4) q.q_roles = ATOM_TUNE("ATOM_GEMVQ_EARLY4", 1) ? 2 : 0;   // bit 1: SiLU x up requests its weight ring in front of the codes
   const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT, D>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   // one workgroup per CU at most; every wave of it at least one feature
   const int cap = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
   int grid = p.N / NWV;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT>), dim3((unsigned)grid), dim3(NTH), lds, s, q);
+  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT, D>), dim3((unsigned)grid), dim3(NTH), lds, s, q);
   return check_launch();
+}
+
+// ring depth: the steps per wave of this launch (its features x parts) when the ring can hold them all -- at most 6 slots at one token
+// and <= 4 chunks per lane, 4 otherwise (registers)
+template <int QOP, int NCH, int MT>
+static int launch1(const GemmParams &p, hipStream_t s) {
+  constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1);
+  int grid = p.N / NWV;
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  const int per_wg = (p.N + grid - 1) / grid, steps = (per_wg + NWV - 1) / NWV * PARTS;
+  if constexpr (MT == 1 && NCH <= 4) {
+    if constexpr (PARTS == 1) {
+      if (steps <= 1) return launch1d<QOP, NCH, MT, 1>(p, s);
+      if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
+      if (steps <= 3) return launch1d<QOP, NCH, MT, 3>(p, s);
+    } else {
+      if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
+    }
+    if (steps <= 4) return launch1d<QOP, NCH, MT, 4>(p, s);
+    return launch1d<QOP, NCH, MT, 6>(p, s);
+  } else {
+    return launch1d<QOP, NCH, MT, 4>(p, s);
+  }
 }
 
 template <int QOP, int MT>
