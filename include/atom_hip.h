@@ -415,7 +415,9 @@ int atom_kv_quant_append_f32(void *kv_data, void *kv_param, const int32_t *kv_in
  * Replaces: FlashInferBatchDecodeKernel_i4 (flashinfer_impl.cuh:9-46; decode.cuh:480-676) = punica_ops.cc:82-120
  * batch_decode_i4 (rope_theta 1e4, rope_scale 1 there).  max_pages_per_seq (host-side upper bound of npages_b, 0 =
  * unknown) lets long sequences at small batch split their KV range over several waves: FP32 partial states go to
- * `workspace` (atom_batch_decode_i4_workspace_bytes; NULL / too small = no split) and a second launch merges them. */
+ * `workspace` (atom_batch_decode_i4_workspace_bytes; NULL / too small = no split) and a second launch merges them.  Where
+ * batch x num_heads >= 256 and the split count divides 12 (round 6) the splits are waves of one workgroup instead and merge in LDS:
+ * one launch, the workspace is not touched, the same bits. */
 size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_size, int max_pages_per_seq);
 /* ... how many waves share a (sequence, head)'s KV range for these arguments (1 = no split, no workspace use).  With o == NULL and a
  * split count >= 2 the two decode entry points leave the partial states in the workspace UN-merged, as float [batch][heads][splits][130]
