@@ -35,8 +35,8 @@ namespace gemvq {
 
 constexpr int NTH = 1024, NWV = NTH / 64;
 constexpr int MQ = 2;                     // token rows at most
-constexpr int CPT = 4;                    // channels per quantiser task: a 128-channel group = 32 adjacent lanes
-constexpr int TPT1 = 3, XC = 2;           // quantiser tasks per thread and token row / 16-byte row chunks per thread at most (gemvq_fits)
+constexpr int CPT = 8;                    // channels per quantiser task: a 128-channel group = 16 adjacent lanes (one DPP row)
+constexpr int TPT1 = 2, XC = 2;           // quantiser tasks per thread and token row / 16-byte row chunks per thread at most (gemvq_fits)
 
 __device__ __forceinline__ int quad_sum(int d) {
   d += __builtin_amdgcn_mov_dpp(d, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -44,11 +44,10 @@ __device__ __forceinline__ int quad_sum(int d) {
   return d;
 }
 
-// max over the aligned 32 lanes this lane belongs to (a quantisation group of 4-channel tasks): exact, order-free
-__device__ __forceinline__ float max32(float a) {
+// max over the aligned 16 lanes this lane belongs to (a quantisation group of 8-channel tasks = one DPP row): exact, order-free
+__device__ __forceinline__ float max16(float a) {
   a = max8(a);
   a = fmaxf(a, dpp_f<0x140>(a));                      // row_mirror: lanes 8-15 <-> 7-0 of the row
-  a = fmaxf(a, __shfl_xor(a, 16));
   return a;
 }
 
@@ -147,24 +146,29 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       int guard = 1 << 18;                                    // (bounded: a lost count ends as a wrong answer the tests see, not a hang)
       while (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(sync_no * NP) && --guard > 0)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(1);                          // (polling without the sleep: the same layer time)
       asm volatile("" ::: "memory");
     } else {
       __builtin_amdgcn_s_barrier();
     }
   };
-  constexpr int NSYNC = NORM ? 3 : 2;                         // counters the quantiser passes: rows staged, (sum of squares,) codes written
+  constexpr int NSYNC = 2;                                    // counters the quantiser passes: rows staged (+ sum of squares), codes written
+  // roles + RMSNorm: the rows are requested by the four waves that run the sum of squares -- two chunks per thread, the tree's own
+  // (chunk t8, chunk t8 + 256) -- so the sum runs on REGISTERS as soon as they arrive and one counter covers "rows staged" and "sum of
+  // squares written" (a counter costs 400-700 cycles: LDS atomic + poll; profiles/r06/gemvq_trace_fine.txt)
+  const bool regsum = NORM && roles;
+  const int PR = regsum ? 256 : PT;                           // threads that request / stage the token rows
 
   // ---- everything the quantiser reads, requested first: one memory round trip for the whole prologue.  Whole waves without work
   // issue nothing (wave-uniform guards; a CU's vector-memory path takes ~20 cycles per wave instruction: the s_memtime trace of the
   // first version, profiles/r06/gemvq_trace.txt, had 4-8 k cycles of request issue in front of the quantiser)
   const int q_nchunks = H >> 3;                              // 16-byte chunks of a row
-  const int tpr = H / CPT;                                   // tasks per row: 4 channels each, 32 per quantisation group
+  const int tpr = H / CPT;                                   // tasks per row: 8 channels each, 16 per quantisation group
   const int ntask = p.M * tpr;
   const int wbase = tid & ~63;                               // this wave's first thread
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   constexpr int TPT = TPT1 * MT;
-  v2u q_ri[TPT], q_rb[QOP == 4 ? TPT : 1];                  // per task: 4 reorder indices (ops 1-3) / 4 gate and 4 up values (op 4)
+  v4u q_ri[TPT], q_rb[QOP == 4 ? TPT : 1];                  // per task: 8 reorder indices (ops 1-3) / 8 gate and 8 up values (op 4)
   h8 q_xr[ROWS ? XC : 1], q_rr[QOP == 3 ? XC : 1], q_wr[NORM ? XC : 1];
   typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
   typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
@@ -173,15 +177,15 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   const float *pwp = nullptr;
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
-    q_ri[t] = v2u{0u, 0u};
-    if constexpr (QOP == 4) q_rb[t] = v2u{0u, 0u};
+    q_ri[t] = v4u{0u, 0u, 0u, 0u};
+    if constexpr (QOP == 4) q_rb[t] = v4u{0u, 0u, 0u, 0u};
     if (!streamer && wbase + t * PT < ntask) {               // (wave-uniform)
       const int task = min(tid + t * PT, ntask - 1), m = MT == 1 ? 0 : task / tpr, e0 = (task - m * tpr) * CPT;   // (MT == 1: no division)
       if constexpr (QOP == 4) {
-        q_ri[t] = *reinterpret_cast<const v2u *>(p.q_x + (int64_t)m * H + e0);
-        q_rb[t] = *reinterpret_cast<const v2u *>(p.q_x2 + (int64_t)m * H + e0);
+        q_ri[t] = *reinterpret_cast<const v4u *>(p.q_x + (int64_t)m * H + e0);
+        q_rb[t] = *reinterpret_cast<const v4u *>(p.q_x2 + (int64_t)m * H + e0);
       } else if (p.q_idx) {
-        q_ri[t] = *reinterpret_cast<const v2u *>(p.q_idx + e0);
+        q_ri[t] = *reinterpret_cast<const v4u *>(p.q_idx + e0);
       }
     }
   }
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     for (int i = 0; i < XC; ++i) {
       q_xr[i] = h8{};
       if constexpr (QOP == 3) q_rr[i] = h8{};
-      if (!streamer && wbase + i * PT < p.M * q_nchunks) {
-        const int c = min(tid + i * PT, p.M * q_nchunks - 1), m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
+      if (!streamer && tid < PR && wbase + i * PR < p.M * q_nchunks) {       // (wave-uniform: PR is a multiple of 64)
+        const int c = min(tid + i * PR, p.M * q_nchunks - 1), m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
         q_xr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_x + (int64_t)m * H) + cc * 16);
         if constexpr (QOP == 3) q_rr[i] = *reinterpret_cast<const h8 *>(reinterpret_cast<const char *>(p.q_res + (int64_t)m * H) + cc * 16);
       }
@@ -332,8 +336,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     if constexpr (QOP <= 3) {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {                         // rows (3: x + residual, one fp16 add per element as torch adds halves;
-        const int c = tid + i * PT;                          // the first workgroup writes the residual stream)
-        if (c < p.M * q_nchunks) {
+        const int c = tid + i * PR;                          // the first workgroup writes the residual stream)
+        if (tid < PR && c < p.M * q_nchunks) {
           const int m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
           h8 v = q_xr[i];
           if constexpr (QOP == 3) {
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
             if (lw == 0) *reinterpret_cast<h8 *>(reinterpret_cast<char *>(p.q_res_out + (int64_t)m * H) + cc * 16) = v;
           }
           *reinterpret_cast<h8 *>(rowbuf + m * H * 2 + cc * 16) = v;
+          q_xr[i] = v;                                       // (regsum: the sum of squares below reads it from here)
         }
       }
       if constexpr (QOP >= 2) {
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     const bool sumsq_wave = NORM && (tid >> 8) < p.M;        // (wave-uniform) waves 4 m .. 4 m + 3: the tree of row m
     if constexpr (ROWS) {
       GQ_STAMP(2);                                             // the quantiser's inputs have arrived and sit in LDS
-      qsync();
+      if (!regsum) qsync();
       GQ_STAMP(3);
     }
     // Without roles the weights of this wave's first D steps go out HERE: in front of the quantiser's own requests they held every wave
@@ -370,10 +375,19 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       const int m = tid >> 8, t8 = tid & 255;               // the stand-alone kernel's 4-wave tree, one per row
       if (m < p.M) {
         float ss = 0.f;
-        for (int c = t8; c < q_nchunks; c += 256) {          // chunk (i * 4 + wave) * 64 + lane, i ascending
-          const h8 v = *reinterpret_cast<const h8 *>(rowbuf + m * H * 2 + c * 16);
+        if (regsum) {                                        // (one token: thread t8 holds chunks t8 and t8 + 256 = the tree's own)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)v[k], (float)v[k], ss);
+          for (int i = 0; i < XC; ++i)
+            if (t8 + i * 256 < q_nchunks) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)q_xr[i][k], (float)q_xr[i][k], ss);
+            }
+        } else {
+          for (int c = t8; c < q_nchunks; c += 256) {        // chunk (i * 4 + wave) * 64 + lane, i ascending
+            const h8 v = *reinterpret_cast<const h8 *>(rowbuf + m * H * 2 + c * 16);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss = __builtin_fmaf((float)v[k], (float)v[k], ss);
+          }
         }
         ss = wave_sum_butterfly(ss);
         if (lane == 0) red[m * 4 + (wave & 3)] = ss;
@@ -388,14 +402,16 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         rinv[m2] = rinv_sqrt_exact(var + p.q_eps);
       }
     }
-    // the codes: 4 channels per thread, a 128-channel group = 32 adjacent lanes (the stand-alone kernels take 16 per thread: the same
-    // values, the same maximum, the same scale, the same codes -- spread over four times the threads)
+    GQ_STAMP(12);                                              // 1 / sqrt done
+    // the codes: 8 channels per thread, a 128-channel group = 16 adjacent lanes (the stand-alone kernels take 16 per thread: the same
+    // values, the same maximum, the same scale, the same codes -- spread over twice the threads; 4 per thread took two passes per wave
+    // at hidden 4096, and a pass is bound by the wave's own instruction issue: profiles/r06/gemvq_trace_fine.txt)
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
-      if (wbase + t * PT < ntask) {                          // (wave-uniform; ntask is a multiple of 32: whole groups per wave half)
+      if (wbase + t * PT < ntask) {                          // (wave-uniform; ntask is a multiple of 16: whole groups per DPP row)
         const int task = min(tid + t * PT, ntask - 1);
         const int m = MT == 1 ? 0 : task / tpr, e0 = (task - m * tpr) * CPT;
-        const int g = e0 >> 7, j = (e0 >> 2) & 31;
+        const int g = e0 >> 7, j = (e0 >> 3) & 15;
         const bool keeper = g == Gt - 1;
         float v[CPT];
         if constexpr (QOP == 4) {
@@ -420,22 +436,31 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) amax = fmaxf(amax, fabsf(v[i]));
-        amax = max32(amax);
+        amax = max16(amax);
         const GroupScale gs = group_scale<false>(amax, keeper, p.q_clip);
         float tr[CPT];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) tr[i] = group_code<false>(v[i], gs);
         if (tid + t * PT < ntask) {
-          if (keeper) {                                        // 4 INT8 codes: one word of pack_codes16's keeper form
-            const float lo = __builtin_fmaf(tr[1], 256.f, tr[0] + 32896.f), hi = __builtin_fmaf(tr[3], 256.f, tr[2] + 32896.f);
-            *reinterpret_cast<unsigned *>(qa8 + m * kKeeper + j * 4) = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
-          } else {                                             // 4 INT4 codes: half a word of its nibble form
-            float lo = 34952.f;
+          if (keeper) {                                        // 8 INT8 codes: two words of pack_codes16's keeper form
+            unsigned w2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float lo = __builtin_fmaf(tr[4 * k + 1], 256.f, tr[4 * k] + 32896.f), hi = __builtin_fmaf(tr[4 * k + 3], 256.f, tr[4 * k + 2] + 32896.f);
+              w2[k] = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x80808080u;
+            }
+            *reinterpret_cast<v2u *>(qa8 + m * kKeeper + j * 8) = v2u{w2[0], w2[1]};
+          } else {                                             // 8 INT4 codes: one word of its nibble form
+            float lo = 34952.f, hi = 34952.f;
             lo = __builtin_fmaf(tr[0], 1.f, lo);
             lo = __builtin_fmaf(tr[1], 16.f, lo);
             lo = __builtin_fmaf(tr[2], 256.f, lo);
             lo = __builtin_fmaf(tr[3], 4096.f, lo);
-            *reinterpret_cast<unsigned short *>(qa4 + m * K4h + g * 64 + j * 2) = (unsigned short)((unsigned)lo ^ 0x8888u);
+            hi = __builtin_fmaf(tr[4], 1.f, hi);
+            hi = __builtin_fmaf(tr[5], 16.f, hi);
+            hi = __builtin_fmaf(tr[6], 256.f, hi);
+            hi = __builtin_fmaf(tr[7], 4096.f, hi);
+            *reinterpret_cast<unsigned *>(qa4 + m * K4h + g * 64 + j * 4) = ((unsigned)lo | ((unsigned)hi << 16)) ^ 0x88888888u;
           }
           if (j == 0) {
             if (keeper) qsa8[m] = f2h(gs.s_store);
@@ -443,6 +468,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           }
         }
       }
+      if (t == 0) GQ_STAMP(13);                                // first pass of the codes done
     }
     if constexpr (QOP == 4) {
       if (!(p.q_roles & 2)) issue_ring();
@@ -595,8 +621,8 @@ static int launch1(const GemmParams &p, hipStream_t s) {
     } else {
       if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
     }
-    if (steps <= 4) return launch1d<QOP, NCH, MT, 4>(p, s);
-    return launch1d<QOP, NCH, MT, 6>(p, s);
+    if (steps <= 4 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);   // (the merge op has no registers for six slots)
+    return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
   } else {
     return launch1d<QOP, NCH, MT, 4>(p, s);
   }
@@ -621,11 +647,11 @@ static int launch_mt(const GemmParams &p, hipStream_t s) {
 }  // namespace gemvq
 
 // THE shape predicate of this launch (atom_gemm_w4a4_multi_q routes one or two tokens here when it holds): per thread of the 1024 at
-// most three quantiser tasks of 4 channels per token row (hidden <= 12,288) and two 16-byte chunks of the token rows / the norm weight (ops 1-3), at most 8 weight chunks
-// per lane (K_total <= 16,512), everything within 128 KiB of LDS.
+// most two quantiser tasks of 8 channels per token row -- kept at hidden <= 12,288, the range the tests cover -- and two 16-byte chunks of
+// the token rows / the norm weight (ops 1-3), at most 8 weight chunks per lane (K_total <= 16,512), everything within 128 KiB of LDS.
 bool gemvq_fits(int q_op, int64_t M, int64_t N, int64_t H) {
   if (q_op < 1 || q_op > 4 || M < 1 || M > gemvq::MQ || H < 2 * kKeeper || ((H - kKeeper) % kGroup) != 0 || N < gemvq::NWV) return false;
-  if (H / gemvq::CPT > gemvq::TPT1 * gemvq::NTH) return false;
+  if (H / gemvq::CPT > gemvq::TPT1 * gemvq::NTH || H > 12288) return false;
   if (q_op <= 3 && (M * (H >> 3) > gemvq::XC * gemvq::NTH || (H >> 3) > gemvq::XC * gemvq::NTH)) return false;
   const int K4h = (int)((H - kKeeper) / 2), G = (int)((H - kKeeper) / kGroup);
   const int need = ((K4h >> 4) + 63) / 64;                 // weight chunks per lane

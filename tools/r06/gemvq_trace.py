@@ -17,7 +17,7 @@ from atom_amd import ops  # noqa: E402
 from tests.helpers import rand_gemm_operands, to_device  # noqa: E402
 
 dev = torch.device("cuda")
-NAMES = ["entry", "issued", "inputs->LDS", "barrier1", "sumsq", "codes", "published", "step0", "step1", "step2", "step3", "done"]
+NAMES = ["entry", "issued", "inputs->LDS", "barrier1", "sumsq", "codes", "published", "step0", "step1", "step2", "step3", "done", "1/sqrt", "codes pass 0"]
 
 
 def run(op, N, nseg, K, copies):
@@ -50,10 +50,11 @@ def run(op, N, nseg, K, copies):
     for wg in range(2):
         rt = [(int(t[wg, w, 14]) - int(t[wg, w, 15])) & 0xFFFFFFFF for w in range(16)]
         print(f" workgroup {'first' if wg == 0 else 'last'}: wave lifetime by s_memrealtime {min(rt) / 100:.2f} .. {max(rt) / 100:.2f} us")
-        for w in (0, 7, 15):
+        for w in (0, 3, 4, 7, 15):
             base = int(t[wg, w, 0])
-            d = [((int(t[wg, w, k]) - base) & 0xFFFFFFFF) for k in range(12)]
-            print(f"  wave {w:2d} cycles since entry: " + "  ".join(f"{NAMES[k]} {d[k]}" for k in range(1, 12) if t[wg, w, k] != 0))
+            d = [((int(t[wg, w, k]) - base) & 0xFFFFFFFF) for k in range(14)]
+            order = [1, 2, 3, 4, 12, 13, 5, 6, 7, 8, 9, 10, 11]
+            print(f"  wave {w:2d} cycles since entry: " + "  ".join(f"{NAMES[k]} {d[k]}" for k in order if t[wg, w, k] != 0))
 
 
 run("rmsnorm", 4096, 3, 4096, 12)
