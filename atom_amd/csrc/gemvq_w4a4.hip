@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     GQ_STAMP(12);                                              // 1 / sqrt done
     // the codes: 8 channels per thread, a 128-channel group = 16 adjacent lanes (the stand-alone kernels take 16 per thread: the same
     // values, the same maximum, the same scale, the same codes -- spread over twice the threads; 4 per thread took two passes per wave
-    // at hidden 4096, and a pass is bound by the wave's own instruction issue: profiles/r06/gemvq_trace_fine.txt)
+    // at hidden 4096, and a pass costs its VALU instructions -- two quantiser waves fill a SIMD: profiles/r06/gemvq_trace_fine.txt)
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
       if (wbase + t * PT < ntask) {                          // (wave-uniform; ntask is a multiple of 16: whole groups per DPP row)

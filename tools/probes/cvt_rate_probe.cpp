@@ -64,16 +64,22 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, unsigned long l
   float s = 0; for (int i = 0; i < 16; ++i) s += a[i] + d[i].x + d[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// Two views per occupancy: "t0" = s_memtime ticks per instruction of wave 0 of one workgroup -- the OLDEST wave of its SIMD, served first:
+// its pace barely changes with the waves beside it and says nothing about throughput --; "simd" = the whole launch by HIP events:
+// nanoseconds per instruction and SIMD (what the hardware sustains).
 template <int MODE> void run(const char *name, float *out) {
   static unsigned long long *cyc = nullptr; if (!cyc) (void)hipMalloc(&cyc, 8);
-  printf("%-44s", name);
+  printf("%-32s", name);
   for (int wps = 1; wps <= 4; ++wps) {
-    const int iters = 4000;
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, out, 200, cyc);
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, out, 2000, cyc);
+    (void)hipEventRecord(e0);
     hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, out, iters, cyc);
-    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     unsigned long long hc; (void)hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
-    printf("  %dw/SIMD: %5.2f cyc per instr per SIMD", wps, (double)hc / iters / 64.0 / wps);
+    printf("  %dw: t0 %5.2f simd %5.3f ns", wps, (double)hc / iters / 64.0, ms * 1e6 / iters / 64.0 / wps);
   }
   printf("\n");
 }
