@@ -210,7 +210,10 @@ def test_multi_projection_launch_equals_separate_launches(M, N, K, nseg):
 
 @pytest.mark.parametrize("M", [1, 2])
 @pytest.mark.parametrize("op,N,K,nseg", [("rmsnorm", 4096, 4096, 3), ("reorder", 4096, 4096, 1), ("add_rmsnorm", 11008, 4096, 2), ("silu_mul", 4096, 11008, 1),
-                                         ("rmsnorm", 1408, 640, 2), ("silu_mul", 512, 1408, 1), ("add_rmsnorm", 256, 5120, 3), ("reorder", 64, 256, 1)])
+                                         ("rmsnorm", 1408, 640, 2), ("silu_mul", 512, 1408, 1), ("add_rmsnorm", 256, 5120, 3), ("reorder", 64, 256, 1),
+                                         # (round 6: the dot-product kernel's ring depth follows a wave's feature steps -- 2, 4, and 8 steps on a
+                                         # ring of 6: a second, refilling trip with a ragged last workgroup)
+                                         ("reorder", 8192, 1024, 1), ("rmsnorm", 16384, 1024, 1), ("add_rmsnorm", 32000, 1024, 1)])
 def test_quantiser_inside_the_gemm_launch_equals_quantiser_then_gemm(op, N, K, nseg, M):
     """atom_gemm_w4a4_multi_q (one or two tokens of a decode step): the quantiser that precedes the projections -- reorder, RMSNorm,
     residual add + RMSNorm, SiLU x up -- runs inside the GEMM launch, every workgroup on its own copy of the rows.  Every output
