@@ -37,6 +37,17 @@ def test_algorithmic_bytes_match_baseline_md():
     assert bench.algorithmic_bytes(1, 4096, 4096) == 8923264           # config 2
 
 
+def test_committed_traffic_profile_is_of_these_kernel_sources():
+    """bench.py quotes roofline.traffic only from a PMC pass taken on the kernel sources of THIS tree (the summaries under
+    profiles/rNN carry the hash of atom_amd/csrc): a kernel edit without a fresh tools/profile_bench.sh pass would silently turn the
+    field into null.  The headline format's traffic must be there, and above the algorithmic bytes (eight L2s fetch the operands)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = bench.measured_traffic(4096, 4096, 4096, "f6")
+    assert t is not None, "profiles/rNN/bench_hbm_traffic_f6.json is not of kernel sources " + bench.kernel_source_sha()[:12]
+    assert bench.algorithmic_bytes(4096, 4096, 4096) < t < 4 * bench.algorithmic_bytes(4096, 4096, 4096)
+
+
 def test_bench_gpus_flag_starts_the_ranks():
     """`python bench.py --gpus 2` (no torch.distributed environment) must itself start 2 ranks and report n_gpus = 2; the
     launch / rendezvous / barrier / timed-region / aggregation code is the product's, only the step is a CPU stand-in."""
