@@ -488,11 +488,13 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
 // The partial states were written by waves on other XCDs, so each request is a trip to memory (~1.5 us): the two run-time loops of
 // rounds 1-5 (one for the maximum, one for the sums, their loads inside) paid it 2 x splits times in sequence on a 130-thread kernel
 // (4.7 us per decode step for 133 KB).  Same operations in the same order: same bits.
+// SB = splits handled in one batch of loads: 8 or 16 by the launcher.  (Round 6 lowered the KV-split size to 4 tiles: a batch-1 step at
+// context 1024 has 16 splits, and with SB = 8 that took the run-time loops below -- four dependent trips to memory instead of one.)
+template <int SB>
 __global__ __launch_bounds__(128) void decode_merge_kernel(const float *ws, half_t *o, int splits) {
   const int64_t bh = blockIdx.x;
   const int dim = threadIdx.x;
   const float *wp = ws + bh * splits * (kHeadDim + 2);
-  constexpr int SB = 8;
   float M = -INFINITY;
   if (splits <= SB) {
     float ov[SB], mv[SB], dv[SB];
@@ -651,8 +653,12 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   }
   hipLaunchKernelGGL(batch_decode_kernel<false>, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
   if (splits > 1 && o)
-    hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace,
-                       (half_t *)o, splits);
+  {
+    if (splits <= 8)
+      hipLaunchKernelGGL(decode_merge_kernel<8>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
+    else
+      hipLaunchKernelGGL(decode_merge_kernel<16>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
+  }
   return check_launch();
 }
 
