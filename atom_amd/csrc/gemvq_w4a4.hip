@@ -71,9 +71,12 @@ struct PartW {
 
 // (`w8`, `sb8u`: the keeper chunk lane % 8 of the feature and its scale, requested with the feature's last part -- `last` is a constant
 // once the loops are unrolled)
-template <int PCH>
+// (`addu`: with ADD, the fp16 addend of the feature's output -- the residual stream behind o_proj / down_proj -- requested with the
+// weights instead of behind the last sum, where it was a trip to memory at the end of every wave; unconditional: a valid dummy address
+// when the launch has no addend or the feature lies in another segment, so that the wait counts stay exact)
+template <int PCH, bool ADD = false>
 __device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, bool last, int lane, int nchunks, PartW<PCH> &f, v4i &w8,
-                                          unsigned short &sb8u) {
+                                          unsigned short &sb8u, unsigned short *addu = nullptr) {
   const uint8_t *brow = p.B4 + (int64_t)n * p.K4h;
   const unsigned short *sBu = reinterpret_cast<const unsigned short *>(p.sB);
 #pragma unroll
@@ -89,6 +92,11 @@ __device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, 
   if (last) {
     w8 = *reinterpret_cast<const v4i *>(p.B8 + (int64_t)n * kKeeper + (lane & 7) * 16);
     sb8u = reinterpret_cast<const unsigned short *>(p.sB8)[n];
+    if constexpr (ADD) {
+      const unsigned short *ap = (p.seg_add && n < p.seg_n) ? reinterpret_cast<const unsigned short *>(p.seg_add) + n
+                                                            : reinterpret_cast<const unsigned short *>(p.sB8) + n;
+      addu[0] = *ap;
+    }
   }
 }
 
@@ -243,6 +251,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   PartW<PCH> ring[D];
   v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
   unsigned short ringsb8[D / PARTS];
+  constexpr bool ADD = MT == 1 && D <= 4;                         // the output addend rides in the ring (one token, up to four slots: registers)
+  unsigned short ringadd[ADD ? D / PARTS : 1];
   // (roles: the quantiser waves request their own features behind the last counter.  Giving ALL features to the streamers -- nothing
   // requested late -- measured the same: eight waves then do the arithmetic of sixteen, 1.2 k instead of 0.8 k cycles per feature step)
   // (computed HERE, behind the quantiser's requests, and with one 32-bit division: the 64-bit form cost ~250 scalar instructions in
@@ -257,8 +267,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #pragma unroll
     for (int u = 0; u < D; ++u) {                         // (a slot past the wave's last step re-requests that step's feature: an L1 hit)
       const int fi = min(u / PARTS, max(nfeat - 1, 0));
-      load_part<PCH>(p, min(n0w + fi * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
-                     ringsb8[u / PARTS]);
+      load_part<PCH, ADD>(p, min(n0w + fi * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
+                          ringsb8[u / PARTS], &ringadd[ADD ? u / PARTS : 0]);
       if constexpr (MT == 1 && QOP != 5)                  // step by step: hipcc otherwise issues every step's 16-byte loads first and the
         __builtin_amdgcn_sched_barrier(0);                // scale loads last -- and step 0 then waits for (nearly) the whole ring
     }                                                     // (two tokens / the merge op: no registers to spare for the fixed order)
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // ring slot s % D; a slot is re-filled with step s + D as soon as step s is computed (D - 1 steps of weights in flight per wave, no
   // register copies: the loop is unrolled by D, and PARTS | D keeps a feature's parts inside one trip)
   const bool leader = (lane & 3) == 0;
-  auto finish = [&](int seg, int nl, const float (&acc)[MT], const v4i &w8, unsigned short sb8u) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
+  auto finish = [&](int seg, int nl, const float (&acc)[MT], const v4i &w8, unsigned short sb8u, unsigned short addu) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
     const float sb8f = (float)__builtin_bit_cast(half_t, sb8u);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -516,7 +526,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           reinterpret_cast<float *>(out)[at] = c;
         } else {
           half_t h = f2h(c);
-          if (seg == 0 && p.seg_add) h = f2h((float)h + (float)p.seg_add[at]);   // fp16 + fp16 as torch adds halves
+          if (seg == 0 && p.seg_add)                           // fp16 + fp16 as torch adds halves
+            h = f2h((float)h + (ADD ? (float)__builtin_bit_cast(half_t, addu) : (float)p.seg_add[at]));
           reinterpret_cast<half_t *>(out)[at] = h;
         }
       }
@@ -561,13 +572,14 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #pragma unroll
         for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc);
         if (part == PARTS - 1) {
-          finish(seg, nl, acc, ring8[u / PARTS], ringsb8[u / PARTS]);
+          finish(seg, nl, acc, ring8[u / PARTS], ringsb8[u / PARTS], ringadd[ADD ? u / PARTS : 0]);
           nl += fstride;
           while (nl >= p.seg_n) { nl -= p.seg_n; ++seg; }
         }
         if (FIRST && u < 4) GQ_STAMP(7 + u);                // steps 0 .. 3 done
         if (base + u + D < nsteps)                          // this slot's next tenant: step s + D = the same part of feature fi + D / PARTS
-          load_part<PCH>(p, n + (D / PARTS) * fstride, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS]);
+          load_part<PCH, ADD>(p, n + (D / PARTS) * fstride, part, part == PARTS - 1, lane, nchunks, f, ring8[u / PARTS], ringsb8[u / PARTS],
+                              &ringadd[ADD ? u / PARTS : 0]);
       }
     }
   };
