@@ -220,6 +220,9 @@ __device__ __forceinline__ TileRegs load_tile(const TileBase &tb, int64_t page, 
 // pairs alone fill the chip and splits divides 12 (batch_decode_impl).  The merge below is decode_merge_kernel's, operation for
 // operation: same bits.
 constexpr int kWgmWaves = 12;
+#ifndef ATOM_DECODE_DP
+#define ATOM_DECODE_DP 2
+#endif
 template <bool WGM>
 __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_kernel(DecodeParams p) {
   const int lane = threadIdx.x & 63;
@@ -258,7 +261,6 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
     tb.lv = t * 64 + 16 * u;
     tb.lq = t * 2;
   }
-  auto page_of = [&](int tile) { return ntiles > 0 ? (int64_t)p.kv.indices[pg0 + min(tile, ntiles - 1) / tpp] : (int64_t)0; };
   // Fused append (round 6; p.k32 != NULL): this step's k / v of head h arrive as FP32 sums.  The ONE wave whose tile range holds the
   // last token quantises them (lanes 0-31 K, 32-63 V: kv_quant_append_kernel's arithmetic), writes the cache slot, and hands the 64 + 64
   // code bytes and the two (scale, zero) pairs to the lane of that token through LDS -- the attention below never waits for the store
@@ -281,11 +283,46 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
     if (l == 0) stash_sz[lp][kvh] = sz;
   }
   __syncthreads();
-  // (a deeper ring -- 3, 4, 6 tiles requested per wave, refilled in place -- measured slower at every batch: profiles/r06/ab_decode_ring.txt)
-  TileRegs cur, nxt;
-  if (tile0 < tile1) cur = load_tile(tb, page_of(tile0), tile0 % tpp);
-  if (tile0 + 1 < tile1) nxt = load_tile(tb, page_of(tile0 + 1), (tile0 + 1) % tpp);
-  int64_t page2 = page_of(tile0 + 2);
+  // ---- the tile pipeline (round 6, second form).  The ISA of rounds 1-5 defeated its own prefetch: the page-table entry of the tile three
+  // ahead was a VECTOR load (the kernel also writes the cache, so hipcc will not use the scalar cache for kv_indices) consumed through
+  // v_readfirstlane behind s_waitcnt vmcnt(0) at the top of every iteration, and `cur = nxt` copied registers whose loads were still in
+  // flight (another vmcnt(0)): every iteration waited for everything it had requested.  Now: (a) the page entries of this wave's whole
+  // tile range arrive in ONE vector load -- lane i holds the entry of page p0 + i, read per tile with v_readlane (a second load only
+  // past 64 pages) --; (b) DP tile buffers used in rotation, no copies (the loop is unrolled by DP; 2 measured best, 3-5 within 1-4 %:
+  // profiles/r06/ab_decode_ring2.txt); (c) the refill of a buffer is
+  // UNCONDITIONAL -- past the wave's last tile it re-reads that tile (resident lines) -- so that every trip issues the same requests
+  // and hipcc's waits are exact counts (csrc/gemvq_w4a4.hip learned the same: requests under run-time conditions end as vmcnt(0)).
+  const int nt = max(tile1 - tile0, 0);
+  const int p0 = tile0 / tpp;                           // first page of my range (relative to pg0)
+  const int plast = nt > 0 ? (tile1 - 1) / tpp : p0;
+  int pseg = 0;                                          // 64-page segment held in pgv
+  int pgv = 0;
+  if (nt > 0) pgv = p.kv.indices[pg0 + min(p0 + lane, plast)];
+  // the refill cursor: tile rt = (page rp relative to p0, sub-tile rs), advancing until my last tile
+  int rt = tile0, rp = 0, rs = tile0 - p0 * tpp;
+  auto advance = [&]() {
+    if (rt + 1 < tile1) {
+      ++rt;
+      if (++rs == tpp) { rs = 0; ++rp; }
+    }
+  };
+  auto page_at = [&](int prel) -> int64_t {               // (uniform) entry of page p0 + prel
+    if ((prel >> 6) != pseg) {                          // beyond the 64 entries held: the next segment (once per 1024+ tokens of a wave)
+      pseg = prel >> 6;
+      pgv = p.kv.indices[pg0 + min(p0 + pseg * 64 + lane, plast)];
+      asm volatile("" : "+v"(pgv));                      // (waited for HERE, inside the branch: pending at the join it would cost every tile a vmcnt(0))
+    }
+    return (int64_t)__builtin_amdgcn_readlane(pgv, prel & 63);
+  };
+  constexpr int DP = ATOM_DECODE_DP;                     // tile buffers (tools builds: -DATOM_DECODE_DP=n)
+  TileRegs ring[DP];
+  if (nt > 0) {
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+      ring[u] = load_tile(tb, page_at(rp), rs);
+      advance();
+    }
+  }
 
   // q rotated to the relative position of MY token of the first tile: A = R((len-1 - j) f) q, pairs (i, i+64)
   // (round 6: kept as register PAIRS -- A[i] = {A1, A2}, SC[i] = {sin, cos} of the 16-position step -- so that the per-tile rotation is
@@ -321,11 +358,12 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
   float m = -INFINITY, d = 0.f, zacc = 0.f;
   const float qk_scale = p.sm_scale * kLog2e;           // decode.cuh:500: softmax in base 2
 
-  for (int tile = tile0; tile < tile1; ++tile) {
-    TileRegs r = cur;
-    cur = nxt;
-    if (tile + 2 < tile1) nxt = load_tile(tb, page2, (tile + 2) % tpp);
-    page2 = page_of(tile + 3);
+  for (int base = tile0; base < tile1; base += DP) {
+#pragma unroll
+  for (int ru = 0; ru < DP; ++ru) {
+    const int tile = base + ru;
+    TileRegs &r = ring[ru];
+    if (tile < tile1) {                                  // (wave-uniform; the last trip may be partial)
     const bool valid = tile * 16 + t < seq_len;
     if (appends && tile == last_tile && t == ((seq_len - 1) & 15)) {   // my token is the one appended above: its bytes come from LDS
       const char *sk = reinterpret_cast<const char *>(&stash_q[lp][0][0]), *sv = reinterpret_cast<const char *>(&stash_q[lp][1][0]);
@@ -398,6 +436,10 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
       asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=&v"(tt) : "v"(A[i]), "v"(SC[i]));
       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(A[i]) : "v"(A[i]), "v"(SC[i]), "v"(tt));
     }
+    }
+    r = load_tile(tb, page_at(rp), rs);                  // this buffer's next tenant: DP tiles on (my last tile again at the end)
+    advance();
+  }
   }
 
   // merge the 16 quads: lanes with equal u hold the same 32 output dims.  Butterfly over lane bits 5, 4, 3, 2 without the LDS
