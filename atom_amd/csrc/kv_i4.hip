@@ -698,8 +698,10 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   {
     if (splits <= 8)
       hipLaunchKernelGGL(decode_merge_kernel<8>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
-    else
+    else if (splits <= 16)
       hipLaunchKernelGGL(decode_merge_kernel<16>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
+    else
+      hipLaunchKernelGGL(decode_merge_kernel<32>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
   }
   return check_launch();
 }
