@@ -1363,6 +1363,9 @@ struct QRegs {
   // slot 2.  All opaque to the compiler: it would otherwise re-derive one from another with a v_add per use, or merge two 8-byte
   // loads of a fragment into a ds_read2_b64 (half the LDS rate).
   int aW[2][3], aA[2][3], aS[2], aB[2];
+#ifdef ATOM_F6_PAIR128                       // tools, TIMING ONLY: lane addresses of a pair-interleaved record (see q_frag_pair)
+  int aWp[2][3];
+#endif
 };
 
 // SL = 0..2: compile-time stage slot; SL < 0: the slot's byte offset arrives at run time in `ro` (the two keeper-prefetch steps
@@ -1379,6 +1382,22 @@ __device__ __forceinline__ v8i q_frag(const char *lds, const int (&a)[2][3], int
   asm volatile("" ::: "memory");   // keeps the compiler from pairing this fragment's loads with the next fragment's
   return v8i{(int)x.x, (int)x.y, (int)y.x, (int)y.y, (int)z.x, (int)z.y, 0, 0};
 }
+#ifdef ATOM_F6_PAIR128
+// TIMING ONLY (-DATOM_F6_PAIR128, tools/ab_build.sh): the two feature fragments of a row pair as THREE ds_read_b128 -- what a
+// pair-interleaved record (row pair i = 208 bytes: per k-block the 16-byte pieces [a0 b0][a1 b1][a2 b2], then the scales) would allow --
+// instead of 2 x 3 ds_read_b64.  The bytes in LDS are still the shipped layout, so the RESULTS ARE GARBAGE; the instruction mix, the
+// addresses' bank pattern (13 x 16 bytes between lanes: conflict-free) and the waits are those of the real thing.
+template <class C, int SL>
+__device__ __forceinline__ void q_frag_pair(const char *lds, const int (&a)[2][3], int off, int ro, v8i &f0, v8i &f1) {
+  const char *b = lds + (SL < 0 ? ro : q_imm<C, SL>()) + off;
+  const v4u x = *reinterpret_cast<const v4u *>(b + a[q_set<SL>()][0]);
+  const v4u y = *reinterpret_cast<const v4u *>(b + a[q_set<SL>()][1]);
+  const v4u z = *reinterpret_cast<const v4u *>(b + a[q_set<SL>()][2]);
+  asm volatile("" ::: "memory");
+  f0 = v8i{(int)x.x, (int)x.y, (int)y.x, (int)y.y, (int)z.x, (int)z.y, 0, 0};
+  f1 = v8i{(int)x.z, (int)x.w, (int)y.z, (int)y.w, (int)z.z, (int)z.w, 0, 0};
+}
+#endif
 // The token scale of a row: the fp32 copy at byte 100 of its record.  Read as the 8-byte pair at byte 96 (fp16 copy + fp32 copy) and the
 // upper dword used (round 6): the 16 rows of a lane group are 208 bytes = 52 dwords apart -- two-way conflicts on the 32 banks a
 // ds_read_b32 sees (52 l mod 32 repeats after 8 rows: SQ_LDS_BANK_CONFLICT = 15 % of the LDS cycles of the round-5 kernel), none on the
@@ -1472,12 +1491,20 @@ __device__ __forceinline__ void q_step(QRegs<C, PAIR> &R, const char *lds, float
         R.sa[0] = q_scale<C, NX>(lds, R, p_row(0) * PITCH, rn);
       }
       if (i == 13) {                                         // fragments fb 0,1: last read by this slot
+#ifdef ATOM_F6_PAIR128
+        q_frag_pair<C, NX>(lds, R.aWp, p_row(0) * PITCH, rn, R.af[0], R.af[1]);
+#else
         R.af[0] = q_frag<C, NX>(lds, R.aW, p_row(0) * PITCH, rn);
         R.af[1] = q_frag<C, NX>(lds, R.aW, p_row(1) * PITCH, rn);
+#endif
       }
       if (i == 15) {
+#ifdef ATOM_F6_PAIR128
+        q_frag_pair<C, NX>(lds, R.aWp, p_row(2) * PITCH, rn, R.af[2], R.af[3]);
+#else
         R.af[2] = q_frag<C, NX>(lds, R.aW, p_row(2) * PITCH, rn);
         R.af[3] = q_frag<C, NX>(lds, R.aW, p_row(3) * PITCH, rn);
+#endif
         R.bf[1] = q_frag<C, NX>(lds, R.aA, p_row(1) * PITCH, rn);        // next step's block 1
         R.sa[1] = q_scale<C, NX>(lds, R, p_row(1) * PITCH, rn);
       }
@@ -1704,6 +1731,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void gemm_w4a4_f6q_kernel(GemmParams
         R.aW[st][k] = lw + 8 * k + st * 2 * Q::STAGE;
         R.aA[st][k] = la + kb * 24 + 8 * k + st * 2 * Q::STAGE;
         asm volatile("" : "+v"(R.aW[st][k]), "+v"(R.aA[st][k]));
+#ifdef ATOM_F6_PAIR128
+        R.aWp[st][k] = ((wn * 64 * PITCH + l15 * (2 * PITCH) + kb * 48 + 16 * k + st * 2 * Q::STAGE) & ~15);
+        asm volatile("" : "+v"(R.aWp[st][k]));
+#endif
       }
       R.aS[st] = la + 96 + st * 2 * Q::STAGE;
       R.aB[st] = (wn * 64 + 8 * kb) * 4 + st * 2 * Q::STAGE;
