@@ -155,6 +155,23 @@ def test_fused_quantiser_shape_query():
     assert fmq(1, 4096, 1, 4096, 1) == 0 and fmq(1, 4096, 1, 4096, 17) == 0 and fmq(2, 4096, 1, 8192, 8) == 0 and fmq(3, 4096, 1, 4096, 8) == 0
 
 
+def test_decode_split_policy_query():
+    """atom_batch_decode_i4_splits / _workspace_bytes (host-side functions of the shape): how many waves share a (sequence, head)'s KV range.
+    Round 6: splits of at least 4 tiles of 16 tokens; one round of at most 3072 waves where the pairs allow it.  Llama-7B heads,
+    context 1024 = 64 pages of 16: 16 splits at batch 1-4, 12 at 8, 6 at 16 (the splits are then waves of 12-wave workgroups that merge
+    in LDS), 3 from 32 on (two rounds of a third of the range beat one round of all of it); the workspace holds batch x heads x splits partial states of 130 floats."""
+    from atom_amd import _lib
+    L = _lib.lib()
+    sp = lambda b, pages, heads=32, page=16: L.atom_batch_decode_i4_splits(b, heads, page, pages)
+    assert [sp(b, 64) for b in (1, 2, 4, 8, 16, 32, 64, 128)] == [16, 16, 16, 12, 6, 3, 3, 3]
+    assert sp(1, 0) == 1 and sp(1, 4) == 1 and sp(1, 8) == 2 and sp(1, 256) <= 64        # unknown / short / long contexts
+    assert 16 <= sp(1, 64, page=32) <= 32                                                # 32-token pages: 128 tiles
+    for b in (1, 8, 16, 64):
+        s_ = sp(b, 64)
+        assert L.atom_batch_decode_i4_workspace_bytes(b, 32, 16, 64) == (b * 32 * s_ * 130 * 4 if s_ > 1 else 0)
+    assert sp(0, 64) == 0 and L.atom_batch_decode_i4_workspace_bytes(0, 32, 16, 64) == 0
+
+
 def test_bf6_convert_result_never_overlaps_its_sources_at_an_offset(tmp_path):
     """Guard against a code-generation trap of hipcc (ROCm 7.2): v_cvt_scalef32_2xpk16_bf6_f32 reads two 16-register sources over
     several passes and writes a 6-register result; the register allocator may place the result INSIDE a source at an offset
