@@ -227,6 +227,11 @@ template <bool WGM>
 __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_kernel(DecodeParams p) {
   const int lane = threadIdx.x & 63;
   const int t = lane >> 2, u = lane & 3;
+  {  // the kernel arguments the prologue dereferences, in ONE batch of scalar loads: the page-table chain below (indptr -> indices ->
+     // tiles) is three dependent trips as it is; hipcc fetched last_page_offset's pointer a trip late
+    const void *a0 = p.kv.indptr, *a1 = p.kv.indices, *a2 = p.kv.last_page_offset, *a3 = p.q, *a4 = p.kv.data, *a5 = p.kv.param, *a6 = p.k32, *a7 = p.v32;
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7));
+  }
   const int N = p.kv.N, P = p.kv.P;
   int pair = blockIdx.x, sp = blockIdx.y, lp = 0;       // (sequence, head) pair, KV split, pair within the workgroup
   bool live = true;
@@ -465,17 +470,37 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
   const float sc = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mall);
   d = over_quads(d * sc, fadd);
   zacc = over_quads(zacc * sc, fadd);
+  // The 32 values per lane: the same butterfly as a REDUCE-SCATTER (round 6).  Stage 1 (lane ^ 32) swaps a value of the half I give away
+  // against my partner's value of the half I keep -- v_permlane32_swap(o[i], o[16 + i]) leaves {mine, partner's} of dims i in lanes
+  // 0-31 and of dims 16 + i in lanes 32-63 --, stage 2 (lane ^ 16) halves again, stages 3, 4 run on the 8 values left: 16 + 8 swaps and
+  // 16 + 8 + 16 additions instead of 64 + 128.  Every sum pairs the same two operands in the same stage order as over_quads: same bits.
+  // Afterwards lane (t, u) holds og[i] = dim 32 u + 8 (t >> 2) + i -- in every lane of its (t >> 2) group.
+  float og[8];
+  {
+    float y[16];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) o[i] = over_quads(o[i] * sc, fadd) - zacc;   // sum p*(s*u - z)
+    for (int i = 0; i < 16; ++i) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[i] * sc), __float_as_uint(o[16 + i] * sc), false, false);
+      y[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[i]), __float_as_uint(y[8 + i]), false, false);
+      float z = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      z = z + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(z), 0x128, 0xF, 0xF, true));   // row_ror:8
+      z = z + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(z), 0x124, 0xF, 0xF, true));   // row_ror:4
+      og[i] = z - zacc;                                      // sum p*(s*u - z)
+    }
+  }
+  const int tg = t >> 2;                                     // my dims: 32 u + 8 tg .. + 7
   if constexpr (WGM) {
     // partial states [wave][130] through LDS, then decode_merge_kernel's arithmetic: 128 threads per pair
     __shared__ float part[kWgmWaves][kHeadDim + 2];
     const int w = lp * p.splits + sp;
-    if (t == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<v4f *>(&part[w][32 * u + 4 * i]) = v4f{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
-      if (u == 0) {
+    if ((t & 3) == 0) {
+      *reinterpret_cast<v4f *>(&part[w][32 * u + 8 * tg]) = v4f{og[0], og[1], og[2], og[3]};
+      *reinterpret_cast<v4f *>(&part[w][32 * u + 8 * tg + 4]) = v4f{og[4], og[5], og[6], og[7]};
+      if (lane == 0) {
         part[w][kHeadDim] = mall;
         part[w][kHeadDim + 1] = d;
       }
@@ -501,24 +526,19 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
     p.o[(int64_t)mpair * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
     return;
   }
-  if (t != 0) return;
+  if ((t & 3) != 0) return;
   if (p.splits == 1) {
     const float rd = d > 0.f ? 1.0f / d : 0.f;
-    half_t *op = p.o + ((int64_t)b * N + h) * kHeadDim + 32 * u;
+    v4u pk;
+    half_t *hv = reinterpret_cast<half_t *>(&pk);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      v4u pk;
-      half_t *hv = reinterpret_cast<half_t *>(&pk);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) hv[i] = (half_t)(o[8 * w + i] * rd);
-      *reinterpret_cast<v4u *>(op + 8 * w) = pk;
-    }
+    for (int i = 0; i < 8; ++i) hv[i] = (half_t)(og[i] * rd);
+    *reinterpret_cast<v4u *>(p.o + ((int64_t)b * N + h) * kHeadDim + 32 * u + 8 * tg) = pk;
   } else {
     float *wp = p.ws + (((int64_t)b * N + h) * p.splits + sp) * (kHeadDim + 2);
-#pragma unroll
-    for (int w = 0; w < 8; ++w)
-      *reinterpret_cast<v4f *>(wp + 32 * u + 4 * w) = v4f{o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]};
-    if (u == 0) {
+    *reinterpret_cast<v4f *>(wp + 32 * u + 8 * tg) = v4f{og[0], og[1], og[2], og[3]};
+    *reinterpret_cast<v4f *>(wp + 32 * u + 8 * tg + 4) = v4f{og[4], og[5], og[6], og[7]};
+    if (lane == 0) {
       wp[kHeadDim] = mall;
       wp[kHeadDim + 1] = d;
     }
