@@ -502,13 +502,29 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // ring slot s % D; a slot is re-filled with step s + D as soon as step s is computed (D - 1 steps of weights in flight per wave, no
   // register copies: the loop is unrolled by D, and PARTS | D keeps a feature's parts inside one trip)
   const bool leader = (lane & 3) == 0;
+  // One token, rows of at most two chunks per lane, a ring of at most four slots (registers): the token's codes and scales this lane
+  // multiplies with are the same for every feature -- read out of LDS ONCE behind the publication instead of at the head of every
+  // feature step (two LDS round trips in front of each step's first dot product)
+  constexpr bool HOIST = MT == 1 && NCH <= 2 && D <= 4 && QOP != 5;
+  v4i ha[HOIST ? NCH : 1], ha8 = {};
+  float hs[HOIST ? NCH : 1], hs8 = 0.f;
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int cc = min(lane + 64 * c, nchunks - 1);
+      ha[c] = *reinterpret_cast<const v4i *>(qa4 + cc * 16);
+      hs[c] = (float)qsa[(cc >> 2) * MQ];
+    }
+    ha8 = *reinterpret_cast<const v4i *>(qa8 + (lane & 7) * 16);
+    hs8 = (float)qsa8[0];
+  }
   auto finish = [&](int seg, int nl, const float (&acc)[MT], const v4i &w8, unsigned short sb8u, unsigned short addu) {   // keeper, 64-lane sum, output: gemv1_w4a4_kernel's tail
     const float sb8f = (float)__builtin_bit_cast(half_t, sb8u);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int mr = min(m, p.M - 1);
-      const v4i a8 = *reinterpret_cast<const v4i *>(qa8 + mr * kKeeper + (lane & 7) * 16);
-      const float sa8f = (float)qsa8[mr];
+      const v4i a8 = HOIST ? ha8 : *reinterpret_cast<const v4i *>(qa8 + mr * kKeeper + (lane & 7) * 16);
+      const float sa8f = HOIST ? hs8 : (float)qsa8[mr];
       int d = 0;
       d = __builtin_amdgcn_sdot4(a8[0], w8[0], d, false);
       d = __builtin_amdgcn_sdot4(a8[1], w8[1], d, false);
@@ -533,15 +549,15 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       }
     }
   };
-  auto chunk = [&](int ch, const v4i &w, unsigned short sbu, float (&acc)[MT]) {   // one weight chunk against every token's codes
+  auto chunk = [&](int ch, const v4i &w, unsigned short sbu, float (&acc)[MT], int hc = 0) {   // one weight chunk against every token's codes (hc: the chunk's index per lane, HOIST)
     const bool ok = ch < nchunks;
     const int cc = min(ch, nchunks - 1);
     const float sbf = (float)__builtin_bit_cast(half_t, sbu);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int mr = min(m, p.M - 1);
-      const v4i a = *reinterpret_cast<const v4i *>(qa4 + mr * K4h + cc * 16);
-      const float saf = (float)qsa[(cc >> 2) * MQ + mr];
+      const v4i a = HOIST ? ha[HOIST ? hc : 0] : *reinterpret_cast<const v4i *>(qa4 + mr * K4h + cc * 16);
+      const float saf = HOIST ? hs[HOIST ? hc : 0] : (float)qsa[(cc >> 2) * MQ + mr];
       int d = 0;
       d = __builtin_amdgcn_sdot8(a[0], w[0], d, false);
       d = __builtin_amdgcn_sdot8(a[1], w[1], d, false);
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           for (int m = 0; m < MT; ++m) acc[m] = 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc);
+        for (int c = 0; c < PCH; ++c) chunk(lane + 64 * (part * PCH + c), f.w[c], f.sbu[c], acc, part * PCH + c);
         if (part == PARTS - 1) {
           finish(seg, nl, acc, ring8[u / PARTS], ringsb8[u / PARTS], ringadd[ADD ? u / PARTS : 0]);
           nl += fstride;
