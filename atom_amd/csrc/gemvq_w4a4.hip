@@ -102,7 +102,12 @@ __device__ __forceinline__ void load_part(const GemmParams &p, int n, int part, 
 
 // QOP: 1 reorder, 2 RMSNorm + reorder, 3 residual add + RMSNorm + reorder, 4 SiLU(x) * x2.  NCH: 16-byte weight chunks per lane
 // (>= ceil(K4 / 2048)).  MT: token rows.
-template <int QOP, int NCH, int MT, int D>
+// OWN (with roles; launch1 picks it where a workgroup's whole share is at most two feature steps of its eight streamer waves -- N <= 4096:
+// o_proj): the streamer waves own EVERY feature, the quantiser waves none -- everything is requested while the quantiser runs and
+// nothing behind the operand's publication, where the quantiser waves' own single step was the tail of the launch (o_proj: done at
+// 7.8 k instead of 8.5 k cycles).  With three steps per wave and more the eight streamers' arithmetic costs more than it saves
+// (q / k / v: profiles/r06/ab_gemvq_own.txt).
+template <int QOP, int NCH, int MT, int D, bool OWN = false>
 __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -259,9 +264,10 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // front of the first request)
   const int fq = p.N / (int)gridDim.x, fr = p.N - fq * (int)gridDim.x;
   const int f0 = lw * fq + min(lw, fr), f1 = f0 + fq + (lw < fr ? 1 : 0);
-  const int fstride = NWV;
-  const int n0w = f0 + wave;
-  const int nfeat = n0w < f1 ? (f1 - n0w + fstride - 1) / fstride : 0;    // features of this wave
+  const bool sall = OWN && roles;                       // (OWN is only launched with roles)
+  constexpr int fstride = OWN ? NWV - NP : NWV;
+  const int n0w = f0 + (OWN ? wave - NP : wave);
+  const int nfeat = (OWN && wave < NP) ? 0 : (n0w < f1 ? (f1 - n0w + fstride - 1) / fstride : 0);    // features of this wave
   const int nsteps = nfeat * PARTS;
   auto issue_ring = [&]() {
 #pragma unroll
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     GQ_STAMP(5);                                               // codes written
     qsync();
     GQ_STAMP(6);                                               // the packed operand is published
-    if (roles) issue_ring();                               // the quantiser waves' own features
+    if (roles && !sall) issue_ring();                      // the quantiser waves' own features
   } else {
     // streamers: the stream starts here; the operand is published once the quantiser's waves have passed their last counter
     issue_ring();
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 #endif
 }
 
-template <int QOP, int NCH, int MT, int D>
+template <int QOP, int NCH, int MT, int D, bool OWN = false>
 static int launch1d(const GemmParams &p, hipStream_t s) {
   // roles (the kernel's comment): one token, ops 1-3, the rows and the norm weight within one 16-byte chunk per thread of the eight
   // quantiser waves and at most TPT1 tasks per thread of them.  (Round 6 also built LOADER waves that fetched every wave's first
@@ -622,13 +628,13 @@ static int launch1d(const GemmParams &p, hipStream_t s) {
   if (QOP == 4) q.q_roles = ATOM_TUNE("ATOM_GEMVQ_EARLY4", 1) ? 2 : 0;   // bit 1: SiLU x up requests its weight ring in front of the codes
   const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
-  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT, D>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
+  if (ensure_max_lds(reinterpret_cast<const void *>(&gemvq_w4a4_kernel<QOP, NCH, MT, D, OWN>), 128 * 1024, attr_done) != ATOM_OK) return ATOM_ERR_LAUNCH;
   // one workgroup per CU at most; every wave of it at least one feature
   const int cap = ATOM_TUNE("ATOM_GEMVQ_GRID", 256);
   int grid = p.N / NWV;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT, D>), dim3((unsigned)grid), dim3(NTH), lds, s, q);
+  hipLaunchKernelGGL((gemvq_w4a4_kernel<QOP, NCH, MT, D, OWN>), dim3((unsigned)grid), dim3(NTH), lds, s, q);
   return check_launch();
 }
 
@@ -641,6 +647,12 @@ static int launch1(const GemmParams &p, hipStream_t s) {
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
   const int per_wg = (p.N + grid - 1) / grid, steps = (per_wg + NWV - 1) / NWV * PARTS;
+  if constexpr (MT == 1 && NCH <= 2 && QOP <= 3) {
+    // roles (launch1d's predicate) and a share of at most two steps per streamer wave: they own every feature (OWN)
+    const int H_ = p.K4h * 2 + kKeeper, sall = (per_wg + 7) / 8;
+    if (p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64 && ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) && ATOM_TUNE("ATOM_GEMVQ_OWN", 1) && sall <= 2)
+      return sall <= 1 ? launch1d<QOP, NCH, MT, 1, true>(p, s) : launch1d<QOP, NCH, MT, 2, true>(p, s);
+  }
   if constexpr (MT == 1 && NCH <= 4) {
     if constexpr (PARTS == 1) {
       if (steps <= 1) return launch1d<QOP, NCH, MT, 1>(p, s);
