@@ -223,8 +223,12 @@ constexpr int kWgmWaves = 12;
 #ifndef ATOM_DECODE_DP
 #define ATOM_DECODE_DP 2
 #endif
-template <bool WGM>
-__global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_kernel(DecodeParams p) {
+// INNER (round 6, !WGM): the splits come in workgroups of INNER waves whose partial states meet in LDS and leave as ONE partial state
+// (un-normalised values, running maximum, denominator: the state a single wave writes) -- a batch-1 step at context 1024 then hands 4
+// partial states per head to the merge (or to o_proj's launch: atom_gemm_w4a4_multi_merge_q) instead of 16.  p.splits counts waves.
+constexpr int kInner = 4;
+template <bool WGM, int INNER = 1>
+__global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_decode_kernel(DecodeParams p) {
   const int lane = threadIdx.x & 63;
   const int t = lane >> 2, u = lane & 3;
   {  // the kernel arguments the prologue dereferences, in ONE batch of scalar loads: the page-table chain below (indptr -> indices ->
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
   }
   const int N = p.kv.N, P = p.kv.P;
   int pair = blockIdx.x, sp = blockIdx.y, lp = 0;       // (sequence, head) pair, KV split, pair within the workgroup
+  if constexpr (!WGM && INNER > 1) sp = (int)blockIdx.y * INNER + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   bool live = true;
   if constexpr (WGM) {
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -526,6 +531,46 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64, 3) void batch_decode_ker
     p.o[(int64_t)mpair * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
     return;
   }
+  if constexpr (INNER > 1) {
+    // the INNER waves' states through LDS; 128 threads fold them into one partial state in wave order: M = max m_s, w_s = 2^(m_s - M),
+    // O = sum o_s w_s, D = sum d_s w_s (the merge's own operations, without its final division)
+    __shared__ float ipart[INNER][kHeadDim + 2];
+    const int w = (int)threadIdx.x >> 6;
+    if ((t & 3) == 0) {
+      *reinterpret_cast<v4f *>(&ipart[w][32 * u + 8 * tg]) = v4f{og[0], og[1], og[2], og[3]};
+      *reinterpret_cast<v4f *>(&ipart[w][32 * u + 8 * tg + 4]) = v4f{og[4], og[5], og[6], og[7]};
+      if (lane == 0) {
+        ipart[w][kHeadDim] = mall;
+        ipart[w][kHeadDim + 1] = d;
+      }
+    }
+    __syncthreads();
+    const int dim = threadIdx.x;
+    if (dim >= kHeadDim) return;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < INNER; ++s2) M = fmaxf(M, ipart[s2][kHeadDim]);
+    float acc = 0.f, den = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < INNER; ++s2) {
+      const float mv = ipart[s2][kHeadDim];
+      const float wgt = mv == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv - M);
+      acc = __builtin_fmaf(ipart[s2][dim], wgt, acc);
+      den = __builtin_fmaf(ipart[s2][kHeadDim + 1], wgt, den);
+    }
+    const int outer = p.splits / INNER;
+    if (outer == 1) {                                    // the only partial state of its pair: the output
+      p.o[((int64_t)b * N + h) * kHeadDim + dim] = (half_t)(den > 0.f ? acc / den : 0.f);
+    } else {
+      float *wp = p.ws + (((int64_t)b * N + h) * outer + blockIdx.y) * (kHeadDim + 2);
+      wp[dim] = acc;
+      if (dim == 0) {
+        wp[kHeadDim] = M;
+        wp[kHeadDim + 1] = den;
+      }
+    }
+    return;
+  }
   if ((t & 3) != 0) return;
   if (p.splits == 1) {
     const float rd = d > 0.f ? 1.0f / d : 0.f;
@@ -620,7 +665,7 @@ static int check_kv(const void *kv_data, const void *kv_param, const int32_t *in
 // KV splits: batch*heads*splits waves run in rounds of 3072 (12 resident waves per CU); a wave costs its tiles plus about
 // two tiles of prologue (32 sincos) and merge, the merge kernel grows with the splits.  Pick the split count that minimises
 // rounds x (tiles per wave + 2) under at least 8 tiles per split (measured: profiles/r01_kv_decode.txt).
-static int decode_splits(int batch, int N, int max_pages, int P) {
+static int decode_splits_total(int batch, int N, int max_pages, int P) {
   if (max_pages <= 0) return 1;
   if (const int forced = ATOM_TUNE("ATOM_DECODE_SPLITS", 0)) return forced;
   const int64_t tiles = (int64_t)max_pages * (P / 16), pairs = (int64_t)batch * N;
@@ -635,6 +680,18 @@ static int decode_splits(int batch, int N, int max_pages, int P) {
     if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)s; }
   }
   return best;
+}
+
+// The plan of a decode call: waves per (sequence, head) pair, and how many of them share a workgroup and leave ONE partial state
+// (kInner where the pairs do not fill the chip and the count divides; the pairs-fill-the-chip case merges ALL of a pair's waves in
+// one workgroup: batch_decode_impl's wgm).  decode_splits() = partial states per pair as the merge / the workspace see them.
+static int decode_inner(int batch, int N, int total) {
+  if ((int64_t)batch * N >= ATOM_TUNE("ATOM_DECODE_WGM_PAIRS", 256) && kWgmWaves % total == 0) return 1;   // (wgm)
+  return (ATOM_TUNE("ATOM_DECODE_INNER", 1) && total >= kInner && total % kInner == 0) ? kInner : 1;
+}
+static int decode_splits(int batch, int N, int max_pages, int P) {
+  const int total = decode_splits_total(batch, N, max_pages, P);
+  return total / decode_inner(batch, N, total);
 }
 
 }  // namespace atom
@@ -694,28 +751,32 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   if (st != ATOM_OK) return st;
   if (!q || !(rope_theta > 0.f) || !(rope_scale > 0.f)) return ATOM_ERR_INVALID_ARG;
   if ((o && !aligned16(o)) || !aligned16(q)) return ATOM_ERR_ALIGN;
-  int splits = decode_splits(batch, num_heads, max_pages_per_seq, page_size);
-  const size_t need = (size_t)batch * num_heads * splits * (kHeadDim + 2) * sizeof(float);
+  int total = decode_splits_total(batch, num_heads, max_pages_per_seq, page_size);     // waves per (sequence, head) pair
   // sequences x heads fill the chip on their own: the splits become the waves of one workgroup and merge in LDS -- one launch, no
   // workspace (same split count, same merge arithmetic: the same bits as kernel + decode_merge_kernel)
-  const bool wgm = o && splits > 1 && kWgmWaves % splits == 0 && (int64_t)batch * num_heads >= ATOM_TUNE("ATOM_DECODE_WGM_PAIRS", 256);
-  if (!wgm && splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) splits = 1;
+  const bool wgm = o && total > 1 && kWgmWaves % total == 0 && (int64_t)batch * num_heads >= ATOM_TUNE("ATOM_DECODE_WGM_PAIRS", 256);
+  int inner = wgm ? 1 : decode_inner(batch, num_heads, total);
+  int splits = total / inner;                           // partial states per pair (what the merge and the workspace see)
+  const size_t need = (size_t)batch * num_heads * splits * (kHeadDim + 2) * sizeof(float);
+  if (!wgm && splits > 1 && (!workspace || workspace_bytes < need || !aligned16(workspace))) { total = 1; inner = 1; splits = 1; }
   // o == NULL: the split partial states stay in the workspace un-merged (atom_batch_decode_i4_splits() of them; the consumer merges:
   // atom_gemm_w4a4_multi_merge_q) -- only meaningful when the KV range IS split
   if (!o && splits < 2) return ATOM_ERR_INVALID_ARG;
   DecodeParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
                   layer_idx, num_heads, page_size},
-                 (const half_t *)q, (half_t *)o, (float *)workspace, splits,
+                 (const half_t *)q, (half_t *)o, (float *)workspace, total,
                  1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale, k32, v32};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (wgm) {
-    const int ppw = kWgmWaves / splits;                 // (sequence, head) pairs per workgroup
+    const int ppw = kWgmWaves / total;                  // (sequence, head) pairs per workgroup
     hipLaunchKernelGGL(batch_decode_kernel<true>, dim3((unsigned)((batch * num_heads + ppw - 1) / ppw)), dim3(64 * kWgmWaves), 0, s, p);
     return check_launch();
   }
-  hipLaunchKernelGGL(batch_decode_kernel<false>, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
-  if (splits > 1 && o)
-  {
+  if (inner == kInner)
+    hipLaunchKernelGGL((batch_decode_kernel<false, kInner>), dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64 * kInner), 0, s, p);
+  else
+    hipLaunchKernelGGL(batch_decode_kernel<false>, dim3((unsigned)(batch * num_heads), (unsigned)splits), dim3(64), 0, s, p);
+  if (splits > 1 && o) {
     if (splits <= 8)
       hipLaunchKernelGGL(decode_merge_kernel<8>, dim3((unsigned)(batch * num_heads)), dim3(128), 0, s, (const float *)workspace, (half_t *)o, splits);
     else if (splits <= 16)

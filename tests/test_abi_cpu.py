@@ -158,14 +158,14 @@ def test_fused_quantiser_shape_query():
 def test_decode_split_policy_query():
     """atom_batch_decode_i4_splits / _workspace_bytes (host-side functions of the shape): how many waves share a (sequence, head)'s KV range.
     Round 6: splits of at least 4 tiles of 16 tokens; one round of at most 3072 waves where the pairs allow it.  Llama-7B heads,
-    context 1024 = 64 pages of 16: 16 splits at batch 1-4, 12 at 8, 6 at 16 (the splits are then waves of 12-wave workgroups that merge
+    context 1024 = 64 pages of 16: 16 waves per pair at batch 1-4 that leave 4 partial states (4 waves per workgroup merge in LDS), 12 at 8, 6 at 16 (the splits are then waves of 12-wave workgroups that merge
     in LDS), 3 from 32 on (two rounds of a third of the range beat one round of all of it); the workspace holds batch x heads x splits partial states of 130 floats."""
     from atom_amd import _lib
     L = _lib.lib()
     sp = lambda b, pages, heads=32, page=16: L.atom_batch_decode_i4_splits(b, heads, page, pages)
-    assert [sp(b, 64) for b in (1, 2, 4, 8, 16, 32, 64, 128)] == [16, 16, 16, 12, 6, 3, 3, 3]
-    assert sp(1, 0) == 1 and sp(1, 4) == 1 and sp(1, 8) == 2 and sp(1, 256) <= 64        # unknown / short / long contexts
-    assert 16 <= sp(1, 64, page=32) <= 32                                                # 32-token pages: 128 tiles
+    assert [sp(b, 64) for b in (1, 2, 4, 8, 16, 32, 64, 128)] == [4, 4, 4, 12, 6, 3, 3, 3]
+    assert sp(1, 0) == 1 and sp(1, 4) == 1 and sp(1, 8) == 2 and sp(1, 16) == 1 and sp(1, 256) <= 64   # unknown / short / long contexts (16 pages: 4 waves, one workgroup, no partial state)
+    assert 4 <= sp(1, 64, page=32) <= 32                                                 # 32-token pages: 128 tiles
     for b in (1, 8, 16, 64):
         s_ = sp(b, 64)
         assert L.atom_batch_decode_i4_workspace_bytes(b, 32, 16, 64) == (b * 32 * s_ * 130 * 4 if s_ > 1 else 0)

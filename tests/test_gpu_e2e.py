@@ -343,12 +343,12 @@ def test_decoder_layer_fused_decode_step_equals_one_launch_per_projection(bsz):
     assert torch.equal(outs[0], outs[1])                      # (round 6: batch 1 included -- see csrc/gemvq_w4a4.hip)
 
 
-@pytest.mark.parametrize("bsz,ctx", [(1, 300), (1, 130), (1, 1030)])
+@pytest.mark.parametrize("bsz,ctx", [(1, 520), (1, 130), (1, 1030), (1, 2500)])
 def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
     """Round 6: with the KV range of a decode step split over several waves (long contexts at small batches), the decode op leaves its
     partial states un-merged and o_proj's launch merges them in front of its reorder quantiser (atom_gemm_w4a4_multi_merge_q).  The op
     against batch_decode_i4 (merge launch) -> dense_layer_gemm_i4_multi_q("reorder"), and a whole decode layer with and without it:
-    bit for bit (4 / 8 / 16 splits here; the second batch of eight splits is a second trip to memory inside the launch)."""
+    bit for bit (waves in workgroups of four that leave one partial state each, or single waves: 2 / 2 / 4 / 8 partial states here)."""
     import atom_amd.e2e.llama as E
     from atom_amd import ops
     from atom_amd.e2e import LlamaDecoderLayer

@@ -126,6 +126,8 @@ def layer_main(ctx=1024, batches=(1, 16, 64), hidden=4096, heads=32, inter=11008
     from atom_amd.e2e import llama as _e2e
     if "ATOM_FUSED_Q_MASK" in os.environ:                    # tools only: which quantisers ride inside their consumers (e2e.DecodeFusion)
         _e2e.FUSION.q_mask = int(os.environ["ATOM_FUSED_Q_MASK"])
+    if "ATOM_MERGE_IN_O_PROJ" in os.environ:                 # ... the KV-split merge inside o_proj's launch
+        _e2e.FUSION.merge_in_o_proj = bool(int(os.environ["ATOM_MERGE_IN_O_PROJ"]))
     if "ATOM_FUSED_Q_MASK2" in os.environ:                   # ... at two tokens
         _e2e.FUSION.q_mask2 = int(os.environ["ATOM_FUSED_Q_MASK2"])
     from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
