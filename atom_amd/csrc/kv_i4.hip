@@ -226,7 +226,10 @@ constexpr int kWgmWaves = 12;
 // INNER (round 6, !WGM): the splits come in workgroups of INNER waves whose partial states meet in LDS and leave as ONE partial state
 // (un-normalised values, running maximum, denominator: the state a single wave writes) -- a batch-1 step at context 1024 then hands 4
 // partial states per head to the merge (or to o_proj's launch: atom_gemm_w4a4_multi_merge_q) instead of 16.  p.splits counts waves.
-constexpr int kInner = 4;
+#ifndef ATOM_DECODE_KINNER
+#define ATOM_DECODE_KINNER 4
+#endif
+constexpr int kInner = ATOM_DECODE_KINNER;
 template <bool WGM, int INNER = 1>
 __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_decode_kernel(DecodeParams p) {
   const int lane = threadIdx.x & 63;
