@@ -612,7 +612,8 @@ def quant_append_kv_i4(kv, k_f32: torch.Tensor, v_f32: torch.Tensor, layer_idx: 
 
 
 def decode_splits(batch: int, kv) -> int:
-    """How many waves share a (sequence, head)'s KV range in batch_decode_i4 for this cache (1: no split)."""
+    """How many partial states per (sequence, head) batch_decode_i4 produces for this cache (1: none; small batches: one per workgroup of
+    four KV-split waves)."""
     num_layers, num_heads, page_size, head_dim = _kv_dims(kv)
     return int(L.lib().atom_batch_decode_i4_splits(int(batch), num_heads, page_size, int(getattr(kv, "max_pages", 0))))
 

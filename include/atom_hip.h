@@ -419,7 +419,9 @@ int atom_kv_quant_append_f32(void *kv_data, void *kv_param, const int32_t *kv_in
  * batch x num_heads >= 256 and the split count divides 12 (round 6) the splits are waves of one workgroup instead and merge in LDS:
  * one launch, the workspace is not touched, the same bits. */
 size_t atom_batch_decode_i4_workspace_bytes(int batch, int num_heads, int page_size, int max_pages_per_seq);
-/* ... how many waves share a (sequence, head)'s KV range for these arguments (1 = no split, no workspace use).  With o == NULL and a
+/* ... how many PARTIAL STATES per (sequence, head) the call produces for these arguments (1 = none: no workspace use).  At small batches
+ * the waves that share a pair's KV range come in workgroups of four that leave one partial state each (round 6), so this is the
+ * number of such workgroups, not of waves.  With o == NULL and a
  * split count >= 2 the two decode entry points leave the partial states in the workspace UN-merged, as float [batch][heads][splits][130]
  * (128 un-normalised values, running maximum, denominator), for a consumer that merges them itself: atom_gemm_w4a4_multi_merge_q. */
 int atom_batch_decode_i4_splits(int batch, int num_heads, int page_size, int max_pages_per_seq);
