@@ -134,6 +134,12 @@ template <int R, int MT, int OUT>
 __global__ __launch_bounds__(256) void gemv1_w4a4_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {  // the kernel arguments in ONE batch of scalar loads (hipcc fetched them in three, a scalar-cache round trip apart, in front of the
+     // first request of a kernel that is one trip to HBM long)
+    const void *a0 = p.A4, *a1 = p.B4, *a2 = p.sA, *a3 = p.sB, *a4 = p.A8, *a5 = p.B8, *a6 = p.sA8, *a7 = p.sB8, *a8_ = p.D;
+    const int i0 = p.M, i1 = p.N, i2 = p.K4h, i3 = p.G, i4 = p.ref_layout, i5 = (int)gridDim.x;   // (gridDim: an implicit argument behind the struct)
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8_), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5));
+  }
   const int K4h = p.K4h;
   const int nchunks = K4h >> 4;
   const bool leader = (lane & 3) == 0;

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   {  // the kernel arguments the prologue needs, in ONE batch of scalar loads (left to itself hipcc fetches each where it is first used: a
      // scalar-cache round trip in front of every group of requests)
     const void *a0 = p.q_x, *a1 = p.q_x2, *a2 = p.q_res, *a3 = p.q_idx, *a4 = p.B4, *a5 = p.sB, *a6 = p.q_res_out;
-    const int i0 = p.M, i1 = p.K4h, i2 = p.G, i3 = p.N, i4 = p.q_roles;
-    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4));
+    const int i0 = p.M, i1 = p.K4h, i2 = p.G, i3 = p.N, i4 = p.q_roles, i5 = (int)gridDim.x;     // (gridDim: an implicit argument behind the struct)
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5));
   }
   // QOP 5 (round 6): the token rows are the decode attention's output still in KV-split form -- FP32 partial states [M][heads][splits]
   // [128 values, m, d] (csrc/kv_i4.hip) -- merged here exactly as decode_merge_kernel merges them, then reordered and quantised as QOP 1
