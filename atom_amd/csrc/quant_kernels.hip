@@ -239,6 +239,12 @@ __device__ __forceinline__ void quant_slot_h(const unsigned (&z)[8], const ActQu
 template <int OP, bool SIM, bool DQ, int NP, int FMT, int HC = 0>
 __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  {  // the kernel arguments in ONE batch of scalar loads (round 6: hipcc fetched them in two or three, a scalar-cache round trip apart;
+     // at decode batches this kernel is a chain of such trips)
+    const void *a0 = p.x, *a1 = p.b, *a2 = p.res, *a3 = p.res_out, *a4 = p.idx, *a5 = p.o8, *a6 = p.o4, *a7 = p.s8, *a8_ = p.s4, *a9 = p.xq;
+    const int i0 = (int)p.M, i1 = p.H, i2 = p.ref_layout, i3 = p.w_lds, i4 = (int)gridDim.x, i5 = (int)p.f6_rows, i6 = (int)p.ld;
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8_), "s"(a9), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6));
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = HC ? HC : p.H;
@@ -537,6 +543,12 @@ __global__ __launch_bounds__(256) void act_quant2_kernel(ActQuantParams p) {
 template <bool SIM, bool DQ, int FMT>
 __global__ __launch_bounds__(256) void silu_quant2_kernel(ActQuantParams p) {
   const int tid = threadIdx.x;
+  {  // the kernel arguments in ONE batch of scalar loads (round 6: hipcc fetched them in two or three, a scalar-cache round trip apart;
+     // at decode batches this kernel is a chain of such trips)
+    const void *a0 = p.x, *a1 = p.b, *a2 = p.res, *a3 = p.res_out, *a4 = p.idx, *a5 = p.o8, *a6 = p.o4, *a7 = p.s8, *a8_ = p.s4, *a9 = p.xq;
+    const int i0 = (int)p.M, i1 = p.H, i2 = p.ref_layout, i3 = p.w_lds, i4 = (int)gridDim.x, i5 = (int)p.f6_rows, i6 = (int)p.ld;
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8_), "s"(a9), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6));
+  }
   // rows by XCD (see act_quant2_kernel): the grid is 8 * ceil(M / 8); XCD x takes rows [x * cm, (x + 1) * cm)
   const int64_t cm = (p.M + 7) >> 3;
   const int64_t r = (blockIdx.x & 7) * cm + (blockIdx.x >> 3);
