@@ -146,8 +146,25 @@ __global__ __launch_bounds__(256) void kv_quant_append_kernel(QuantAppendParams 
 }
 
 // ------------------------------------------------------------------------------------------------ decode
+// x / d for 0 <= x < 2^31 by a multiplication with a reciprocal the HOST prepared: s = ceil(log2 d), m = ceil(2^(31+s) / d) < 2^32,
+// q = mulhi(x, m) >> (s - 1) -- exact, since x * (m d - 2^(31+s)) < 2^31 * 2^s; d = 1: m = 0, q = x.  (The decode kernel's prologue held
+// seven 32-bit divisions by run-time values -- heads, splits, tiles per page, page length --, ~30 instructions and a VALU -> SALU round
+// trip each, two of them between the dependent loads of the page-table chain.)
+struct FastDiv {
+  unsigned m, sh;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  if (d <= 1) return FastDiv{0u, 0u};
+  unsigned s = 0;
+  while ((1u << s) < d) ++s;
+  return FastDiv{(unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d), s - 1};
+}
+__device__ __forceinline__ int fdiv(int x, FastDiv f) { return f.m ? (int)(__umulhi((unsigned)x, f.m) >> f.sh) : x; }
+
 struct DecodeParams {
   KvParams kv;
+  FastDiv dN, dsplits, dtpp, dP;   // reciprocals of kv.N, splits, kv.P / 16, kv.P
+  int ppw;                         // WGM: (sequence, head) pairs per workgroup = kWgmWaves / splits
   const half_t *q;      // [B, N, 128]
   half_t *o;            // [B, N, 128]
   float *ws;            // splits > 1: [B, N, splits, 130] = o[128] (not normalised), m, d
@@ -245,17 +262,17 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
   bool live = true;
   if constexpr (WGM) {
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    lp = w / p.splits;
+    lp = fdiv(w, p.dsplits);
     sp = w - lp * p.splits;
-    pair = (int)blockIdx.x * (kWgmWaves / p.splits) + lp;
+    pair = (int)blockIdx.x * p.ppw + lp;
     live = pair < p.kv.batch * N;                       // (the last workgroup's spare waves: no tiles, no writes, the barriers only)
     pair = min(pair, p.kv.batch * N - 1);
   }
-  const int h = pair % N, b = pair / N;
+  const int b = fdiv(pair, p.dN), h = pair - b * N;
   const int pg0 = p.kv.indptr[b];
   const int seq_len = live ? (p.kv.indptr[b + 1] - pg0 - 1) * P + p.kv.last_page_offset[b] : 0;
   const int ntiles = (max(seq_len, 0) + 15) >> 4;       // (an empty sequence: no tiles, no page-table read, output zeros)
-  const int chunk = (ntiles + p.splits - 1) / p.splits;
+  const int chunk = fdiv(ntiles + p.splits - 1, p.dsplits);
   const int tile0 = sp * chunk, tile1 = min(ntiles, tile0 + chunk);
   const int tpp = P >> 4;                               // 16-token tiles per page
 
@@ -289,7 +306,8 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
     unsigned sz;
     const unsigned short w = quant_head_u4(x, sz);
     const int pos = seq_len - 1;
-    const int64_t slot = ((((int64_t)p.kv.indices[pg0 + pos / P] * p.kv.L + p.kv.layer) * 2 + kvh) * N + h) * P + pos % P;
+    const int ppage = fdiv(pos, p.dP);
+    const int64_t slot = ((((int64_t)p.kv.indices[pg0 + ppage] * p.kv.L + p.kv.layer) * 2 + kvh) * N + h) * P + (pos - ppage * P);
     *reinterpret_cast<unsigned short *>(p.kv.data + slot * 64 + 2 * l) = w;
     if (l == 0) *reinterpret_cast<unsigned *>(p.kv.param + slot * 2) = sz;
     stash_q[lp][kvh][l] = w;
@@ -306,8 +324,8 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
   // UNCONDITIONAL -- past the wave's last tile it re-reads that tile (resident lines) -- so that every trip issues the same requests
   // and hipcc's waits are exact counts (csrc/gemvq_w4a4.hip learned the same: requests under run-time conditions end as vmcnt(0)).
   const int nt = max(tile1 - tile0, 0);
-  const int p0 = tile0 / tpp;                           // first page of my range (relative to pg0)
-  const int plast = nt > 0 ? (tile1 - 1) / tpp : p0;
+  const int p0 = fdiv(tile0, p.dtpp);                   // first page of my range (relative to pg0)
+  const int plast = nt > 0 ? fdiv(tile1 - 1, p.dtpp) : p0;
   int pseg = 0;                                          // 64-page segment held in pgv
   int pgv = 0;
   if (nt > 0) pgv = p.kv.indices[pg0 + min(p0 + lane, plast)];
@@ -341,6 +359,26 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
   // (round 6: kept as register PAIRS -- A[i] = {A1, A2}, SC[i] = {sin, cos} of the 16-position step -- so that the per-tile rotation is
   // two packed FP32 instructions per pair instead of four scalar ones, and the sum of A sixteen packed adds instead of 32)
   v2f A[16], SC[16];
+  // The frequency of pair j and the sin / cos of its 16-position step depend on j alone: lane j computes them for j = lane (one exp2, one
+  // sin, one cos instead of 16 + 32 per lane -- the 16 token lanes of a quarter used to repeat each other's work, ~45 transcendental and
+  // ~150 other instructions of a prologue that was a fifth of the wave's instructions at 11 tiles) and the wave shares them through its own
+  // 768 bytes of LDS: no workgroup barrier, a wave's LDS operations complete in order.  Same expressions on the same inputs: same bits.
+  constexpr int RW = WGM ? kWgmWaves : INNER;
+  __shared__ float rope_fr[RW][64];
+  __shared__ v2f rope_sc[RW][64];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  {
+    // decode.cuh:535-539: freq = rope_inv_scale * theta^(-2 (i mod 64) / 128); here in revolutions
+    const float fr = p.rope_inv_scale * 0.15915494309189535f *
+                     __builtin_amdgcn_exp2f(-p.log2_theta * (float)(2 * lane) * (1.0f / kHeadDim));
+    float s16, c16;
+    sincos_rev(16.0f * fr, s16, c16);
+    rope_fr[wv][lane] = fr;
+    rope_sc[wv][lane] = v2f{s16, c16};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   {
     const half_t *qp = p.q + ((int64_t)b * N + h) * kHeadDim;
     v4u r1[2], r2[2];
@@ -352,16 +390,12 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
     const float delta = (float)((seq_len - 1) - (tile0 * 16 + t));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      // decode.cuh:535-539: freq = rope_inv_scale * theta^(-2 (i mod 64) / 128); here in revolutions
-      const float fr = p.rope_inv_scale * 0.15915494309189535f *
-                       __builtin_amdgcn_exp2f(-p.log2_theta * (float)(2 * (16 * u + i)) * (1.0f / kHeadDim));
+      const float fr = rope_fr[wv][16 * u + i];
       float s, c;
       sincos_rev(delta * fr, s, c);
       const float q1 = (float)h1[i], q2 = (float)h2p[i];
       A[i] = v2f{q1 * c - q2 * s, q2 * c + q1 * s};
-      float s16, c16;
-      sincos_rev(16.0f * fr, s16, c16);
-      SC[i] = v2f{s16, c16};
+      SC[i] = rope_sc[wv][16 * u + i];
     }
   }
 
@@ -515,8 +549,8 @@ __global__ __launch_bounds__(WGM ? 64 * kWgmWaves : 64 * INNER, 3) void batch_de
     }
     __syncthreads();
     const int mp = (int)threadIdx.x >> 7, dim = (int)threadIdx.x & 127;
-    const int mpair = (int)blockIdx.x * (kWgmWaves / p.splits) + mp;
-    if (mp >= kWgmWaves / p.splits || mpair >= p.kv.batch * N) return;
+    const int mpair = (int)blockIdx.x * p.ppw + mp;
+    if (mp >= p.ppw || mpair >= p.kv.batch * N) return;
     const float(*pp)[kHeadDim + 2] = &part[mp * p.splits];
     float M = -INFINITY;
 #pragma unroll
@@ -767,6 +801,8 @@ static int batch_decode_impl(void *o, const void *q, const float *k32, const flo
   if (!o && splits < 2) return ATOM_ERR_INVALID_ARG;
   DecodeParams p{{(uint8_t *)kv_data, (half_t *)kv_param, kv_indptr, kv_indices, last_page_offset, batch, num_layers,
                   layer_idx, num_heads, page_size},
+                 make_fastdiv((unsigned)num_heads), make_fastdiv((unsigned)total), make_fastdiv((unsigned)(page_size >> 4)),
+                 make_fastdiv((unsigned)page_size), wgm ? kWgmWaves / total : 1,
                  (const half_t *)q, (half_t *)o, (float *)workspace, total,
                  1.0f / sqrtf((float)kHeadDim), log2f(rope_theta), 1.0f / rope_scale, k32, v32};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

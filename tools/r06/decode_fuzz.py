@@ -1,6 +1,8 @@
 """Randomised check of the decode attention after round 6's rebuild (csrc/kv_i4.hip): for random batches / heads / page sizes / lengths,
 (a) against the numpy oracle (2e-3 of the output scale), (b) the fused append against append-then-decode (bit for bit, cache bytes too),
-(c) split against unsplit KV ranges (2e-3).   python tools/r06/decode_fuzz.py [cases]   (on the GPU box)"""
+(c) split against unsplit KV ranges (2e-3).   python tools/r06/decode_fuzz.py [cases]   (on the GPU box)
+The last line carries a SHA-256 over every output's bits: two builds (ATOM_LIB=...) that print the same digest are bit-identical on these cases."""
+import hashlib
 import os
 import sys
 
@@ -18,6 +20,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 t2n = lambda t: t.detach().cpu().numpy()
 bad = 0
+digest = hashlib.sha256()
 for case in range(ncases):
     heads = int(rng.choice([1, 4, 8, 32]))
     block = int(rng.choice([16, 32, 64]))
@@ -51,6 +54,8 @@ for case in range(ncases):
     splits = ops.decode_splits(B, kv)
     kv.max_pages = 0
     o1 = ops.batch_decode_i4(q, kv, 1)
+    for o_ in (outs[0], o1):
+        digest.update(t2n(o_.view(torch.int16)).tobytes())
     ok_c = torch.allclose(o1.float(), outs[0].float(), atol=2e-3 * float(o1.float().abs().max()) + 1e-3, rtol=0)
     ok_a = True
     if sum(seqlens) * heads <= 40000:                       # the numpy oracle is slow
@@ -60,4 +65,4 @@ for case in range(ncases):
     if not (ok_a and ok_b and ok_c):
         bad += 1
         print(f"case {case}: heads {heads} block {block} B {B} max len {max(seqlens)} splits {splits}: oracle {ok_a} fused {ok_b} split {ok_c}")
-print(f"{ncases} cases, {bad} bad")
+print(f"{ncases} cases, {bad} bad; outputs sha256 {digest.hexdigest()[:16]}")
