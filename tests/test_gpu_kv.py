@@ -58,9 +58,10 @@ def test_init_and_append_kv_bit_exact(seqlens, heads, block):
 
 @pytest.mark.parametrize("seqlens,heads,block", [([37, 5, 16, 1], 4, 16), ([300], 32, 16), ([129, 64, 250], 8, 32),
                                                   ([2000, 7], 4, 16), ([300, 17, 260, 33, 1, 290, 128, 64], 32, 16),
-                                                  ([150] * 19 + [3], 32, 16)])
+                                                  ([150] * 19 + [3], 32, 16), ([210, 97, 5], 5, 48), ([300] * 7 + [49], 40, 48)])
 def test_batch_decode_matches_oracle(seqlens, heads, block):
-    """Tolerance 2e-3 of the output scale: FP32 accumulation, hardware exp2, incremental RoPE rotation (the reference
+    """The last two: head counts and page lengths that are not powers of two (40 heads = Llama-13B; 3 tiles per page) -- the kernel divides
+    by them through host-prepared reciprocals.  Tolerance 2e-3 of the output scale: FP32 accumulation, hardware exp2, incremental RoPE rotation (the reference
     itself uses __sincosf / __powf fast intrinsics, decode.cuh:63-66,537).  The last two shapes have >= 256 (sequence, head) pairs
     and a split KV range: the splits are waves of 12-wave workgroups that merge in LDS (4 splits x 3 pairs, 256 pairs: the last
     workgroup has spare waves; 2 splits x 6 pairs)."""
@@ -183,7 +184,7 @@ def test_fused_quant_append_equals_o4_gemm_plus_append(seqlens, heads, block):
 
 @pytest.mark.parametrize("seqlens,heads,block", [([5, 17, 32, 1, 16], 4, 16), ([1041, 1024, 1025, 48], 8, 16), ([300] * 3 + [33], 32, 32),
                                                   ([2000, 7], 4, 16), ([300, 17, 260, 33, 1, 290, 128, 64], 32, 16),
-                                                  ([150] * 19 + [3], 32, 16)])
+                                                  ([150] * 19 + [3], 32, 16), ([210, 97, 5, 48, 49], 5, 48), ([300] * 7 + [49], 40, 48)])
 def test_decode_with_the_append_inside_equals_append_then_decode(seqlens, heads, block):
     """atom_batch_decode_append_i4 (round 6): quantising this step's FP32 k / v sums, writing them into the last token's cache slot and
     attending over the cache in ONE launch leaves the cache bytes of atom_kv_quant_append_f32 and gives the output of the two launches,
