@@ -544,6 +544,9 @@ int atom_gemm_w4a4_multi_merge_q(const void *partials_f32, int splits, const int
   p.q_eps = 0.f; p.q_clip = clip;
   p.q_part = (const float *)partials_f32;
   p.q_splits = splits;
+#ifdef ATOM_TOOLS   // traced run (tools/r06/gemvq_trace.py)
+  if (const char *e = getenv("ATOM_TRACE_PTR")) p.Dsz = reinterpret_cast<half_t *>(strtoull(e, nullptr, 16));
+#endif
   return launch_gemvq_multi_q(p, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -16,8 +16,9 @@
 //   * at one token the waves have roles (q_roles): waves 0-7 run the quantiser and synchronise through an LDS counter (qsync), waves
 //     8-15 request their first D feature steps right behind the barrier and spin on that counter until the packed operand -- INT4
 //     codes, INT8 keeper, fp16 scales: the bytes the stand-alone quantiser kernels write -- is in LDS; the quantiser waves request their
-//     features behind their last qsync.  At two tokens, and for the ops whose rows need all 1024 threads (SiLU x up, split merge),
-//     every wave does both jobs with s_barrier in qsync's place (profiles/r06/ab_gemvq_roles.txt);
+//     features behind their last qsync (the split merge, q_op 5, too, when its row fits the eight quantiser waves).  At two tokens, and
+//     for SiLU x up, whose row needs all 1024 threads, every wave does both jobs with s_barrier in qsync's place
+//     (profiles/r06/ab_gemvq_roles.txt, ab_gemvq_roles4.txt);
 //   * the feature loop keeps a ring of D steps in flight per wave (a step = a whole, a half or a quarter of one feature's chunks:
 //     PartW below), refilled in place inside a loop unrolled by D, reads the token's codes out of LDS (one ds_read_b128 per weight
 //     chunk) and forms every sum exactly as gemv1_w4a4_kernel does: lane l owns chunks l, l + 64, ... in ascending order, a quad sums a
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // stream starts at ~1 k cycles on waves that have nothing else to do.  The quantiser waves request their own features behind the
   // last counter.  Same arithmetic on the same bytes either way.
   constexpr int NP = 8;
-  const bool roles = QOP <= 3 && MT == 1 && p.q_roles != 0;   // (workgroup-uniform)
+  const bool roles = (QOP <= 3 || QOP == 5) && MT == 1 && p.q_roles != 0;   // (workgroup-uniform)
   const bool streamer = roles && wave >= NP;
   const int PT = roles ? NP * 64 : NTH;                       // threads that share the quantiser's work
   unsigned *sync_cnt = reinterpret_cast<unsigned *>(lds + red_offset(K4h, G) + 32);
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
   v4f_u po[QOP == 5 ? PH : 1][2];                           // QOP 5: my chunk's 8 values of the first PH splits, and every split's (m, d)
   v2f_u pmd[QOP == 5 ? PS : 1];
+  v2f_u pmy = v2f_u{-INFINITY, 0.f};                        // QOP 5: the (m, d) of split lane % 16 of my head -- one request; the 16 lanes of a head share them through LDS
   const float *pwp = nullptr;
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
@@ -202,20 +204,24 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       }
     }
   }
-  if constexpr (QOP == 5) {                                 // (one chunk per thread: M x K_total <= 8192, gemvq_merge_fits)
+  if (QOP == 5 && !streamer) {                              // (one chunk per thread: M x K_total <= 8192, gemvq_merge_fits; wave-uniform)
     const int c = min(tid, p.M * q_nchunks - 1), m = MT == 1 ? 0 : c / q_nchunks, cc = c - m * q_nchunks;
-    const float *wp = p.q_part + ((int64_t)(m * (H >> 7) + (cc >> 4)) * p.q_splits) * 130 + (cc & 15) * 8;
+    // thread j of a head's 16 takes values 4 j .. 4 j + 3 and 64 + 4 j .. + 3 of it: each request of the 16 lanes is 256 contiguous bytes
+    // (8 contiguous values per thread -- every request touching all four lines of the record -- measured the same: the 133 KB a
+    // workgroup reads take their 2 k cycles at the CU's 64 bytes per clock either way, profiles/r06/ab_merge_in_o_proj4.txt)
+    const float *wp = p.q_part + ((int64_t)(m * (H >> 7) + (cc >> 4)) * p.q_splits) * 130 + (cc & 15) * 4;
     pwp = wp;
 #pragma unroll
     for (int sp = 0; sp < PS; ++sp) {
       const int sc = min(sp, p.q_splits - 1);
       if (sp < PH) {
         po[sp][0] = *reinterpret_cast<const v4f_u *>(wp + sc * 130);
-        po[sp][1] = *reinterpret_cast<const v4f_u *>(wp + sc * 130 + 4);
+        po[sp][1] = *reinterpret_cast<const v4f_u *>(wp + sc * 130 + 64);
       }
-      if (sp < PH || p.q_splits > PH) pmd[sp] = *reinterpret_cast<const v2f_u *>(wp + sc * 130 + 128 - (cc & 15) * 8);
-      else pmd[sp] = v2f_u{-INFINITY, 0.f};
     }
+    // (a wave's vector-memory instruction costs ~16 cycles of the CU's request path whatever its width: with every lane asking for all
+    // 8-16 (m, d) pairs of its head the 33 requests per thread were issued at 5.0 k cycles, with one pair per lane at 4.3 k)
+    pmy = *reinterpret_cast<const v2f_u *>(wp + min(lane & 15, p.q_splits - 1) * 130 + 128 - (cc & 15) * 4);
   }
   if constexpr (QOP <= 3) {
 #pragma unroll
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
       const int fi = min(u / PARTS, max(nfeat - 1, 0));
       load_part<PCH, ADD>(p, min(n0w + fi * fstride, p.N - 1), u % PARTS, u % PARTS == PARTS - 1, lane, nchunks, ring[u], ring8[u / PARTS],
                           ringsb8[u / PARTS], &ringadd[ADD ? u / PARTS : 0]);
-      if constexpr (MT == 1 && QOP != 5)                  // step by step: hipcc otherwise issues every step's 16-byte loads first and the
+      if constexpr (MT == 1 && (QOP != 5 || OWN))         // step by step: hipcc otherwise issues every step's 16-byte loads first and the
         __builtin_amdgcn_sched_barrier(0);                // scale loads last -- and step 0 then waits for (nearly) the whole ring
     }                                                     // (two tokens / the merge op: no registers to spare for the fixed order)
   };
@@ -296,8 +302,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   if constexpr (QOP == 5) {
 #pragma unroll
     for (int sp = 0; sp < PH; ++sp) asm volatile("" : "+v"(po[sp][0]), "+v"(po[sp][1]));
-#pragma unroll
-    for (int sp = 0; sp < PS; ++sp) asm volatile("" : "+v"(pmd[sp]));
+    asm volatile("" : "+v"(pmy));
   }
   if constexpr (QOP <= 3) {
 #pragma unroll
@@ -314,6 +319,19 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     const int Gt = H >> 7;
     if constexpr (QOP == 5) {
       // out[dim] = sum_s o_s[dim] 2^(m_s - M) / sum_s d_s 2^(m_s - M), splits in order: decode_merge_kernel's operations, same bits
+      {  // the head's (m, d) pairs: lane j of a head's 16 holds split j's; through the (unused) norm-weight area of LDS, wave-local --
+         // a wave's LDS operations complete in order, no barrier
+        v2f_u *mdx = reinterpret_cast<v2f_u *>(wbuf);
+        if (tid < p.M * q_nchunks) mdx[tid] = pmy;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int sp = 0; sp < PS; ++sp) {
+          pmd[sp] = v2f_u{-INFINITY, 0.f};
+          if ((sp < PH || p.q_splits > PH) && tid < p.M * q_nchunks) pmd[sp] = mdx[(tid & ~15) + sp];
+        }
+      }
       float M_ = -INFINITY;
 #pragma unroll
       for (int sp = 0; sp < PS; ++sp)
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
           for (int sp = 0; sp < PH; ++sp) {                  // the next batch of splits: one more trip to memory
             const int sc = min(hb * PH + sp, p.q_splits - 1);
             po[sp][0] = *reinterpret_cast<const v4f_u *>(pwp + sc * 130);
-            po[sp][1] = *reinterpret_cast<const v4f_u *>(pwp + sc * 130 + 4);
+            po[sp][1] = *reinterpret_cast<const v4f_u *>(pwp + sc * 130 + 64);
           }
         }
 #pragma unroll
@@ -346,7 +364,10 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
         h8 v;
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (half_t)(den > 0.f ? acc[k] / den : 0.f);
-        *reinterpret_cast<h8 *>(rowbuf + tid * 16) = v;      // (chunk tid of the [M][H] rows: contiguous)
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        char *hb = rowbuf + (tid & ~15) * 16 + (tid & 15) * 8;     // my head's 128 halves of the [M][H] rows: values 4 j .. and 64 + 4 j ..
+        *reinterpret_cast<h4 *>(hb) = h4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<h4 *>(hb + 128) = h4{v[4], v[5], v[6], v[7]};
       }
     }
     if constexpr (QOP <= 3) {
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
   // One token, rows of at most two chunks per lane, a ring of at most four slots (registers): the token's codes and scales this lane
   // multiplies with are the same for every feature -- read out of LDS ONCE behind the publication instead of at the head of every
   // feature step (two LDS round trips in front of each step's first dot product)
-  constexpr bool HOIST = MT == 1 && NCH <= 2 && D <= 4 && QOP != 5;
+  constexpr bool HOIST = MT == 1 && NCH <= 2 && D <= 4 && (QOP != 5 || OWN);
   v4i ha[HOIST ? NCH : 1], ha8 = {};
   float hs[HOIST ? NCH : 1], hs8 = 0.f;
   if constexpr (HOIST) {
@@ -624,7 +645,7 @@ static int launch1d(const GemmParams &p, hipStream_t s) {
   // features into LDS by LDS-DMA: bit-identical and slower -- profiles/r06/ab_gemvq_lds_prefetch.txt, commit ea86eed -- and removed.)
   GemmParams q = p;
   const int H_ = p.K4h * 2 + kKeeper;
-  q.q_roles = (QOP <= 3 && MT == 1 && p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64) ? ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) : 0;
+  q.q_roles = ((QOP <= 3 || QOP == 5) && MT == 1 && p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64) ? ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) : 0;
   if (QOP == 4) q.q_roles = ATOM_TUNE("ATOM_GEMVQ_EARLY4", 1) ? 2 : 0;   // bit 1: SiLU x up requests its weight ring in front of the codes
   const size_t lds = lds_bytes(QOP, p.K4h, p.G);
   static std::atomic<uint64_t> attr_done{0};
@@ -647,7 +668,7 @@ static int launch1(const GemmParams &p, hipStream_t s) {
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
   const int per_wg = (p.N + grid - 1) / grid, steps = (per_wg + NWV - 1) / NWV * PARTS;
-  if constexpr (MT == 1 && NCH <= 2 && QOP <= 3) {
+  if constexpr (MT == 1 && NCH <= 2 && (QOP <= 3 || QOP == 5)) {
     // roles (launch1d's predicate) and a share of at most two steps per streamer wave: they own every feature (OWN)
     const int H_ = p.K4h * 2 + kKeeper, sall = (per_wg + 7) / 8;
     if (p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64 && ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) && ATOM_TUNE("ATOM_GEMVQ_OWN", 1) && sall <= 2)

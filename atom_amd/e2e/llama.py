@@ -27,10 +27,12 @@ class DecodeFusion:
       kv_append  k / v quantised into the paged cache from the FP32 sums (False: the reference's op sequence _o4 GEMM -> append)
       kv_in_decode  ... by the attention launch itself (atom_batch_decode_append_i4, round 6; False: a launch of its own in front)
       merge_in_o_proj  one or two tokens whose KV range is split over several waves: the split merge runs in front of o_proj's quantiser
-                 inside o_proj's launch (atom_gemm_w4a4_multi_merge_q, round 6) instead of the decode op's own merge launch.  Built,
-                 bit-identical, and SLOWER -- every one of o_proj's 256 workgroups re-reads the partial states of all heads from the other
-                 XCDs' memory side: the layer at batch 1 53.4 -> 57.2 us cold with 16 splits, 55.2 -> 56.6 with 8
-                 (profiles/r06/ab_merge_in_o_proj.txt) -- hence off by default.
+                 inside o_proj's launch (atom_gemm_w4a4_multi_merge_q, round 6) instead of the decode op's own merge launch:
+                 bit-identical, a launch fewer.  Every one of o_proj's 256 workgroups re-reads the partial states of all heads (133 KB at 8
+                 states per head: 2 k cycles of a CU's 64 B / clock), so the first form LOST (53.4 -> 57.2 us cold per layer with 16
+                 states, 55.2 -> 56.6 with 8: profiles/r06/ab_merge_in_o_proj.txt); with the two-level merge in the attention launch
+                 (8 states at context 1024), quantiser / streamer roles for this op and one (m, d) request per lane it is ahead --
+                 46.3-46.8 -> 45.6-46.0 us at batch 1, 59.7 -> 59.5 at batch 2 (ab_merge_in_o_proj4.txt) -- and on by default.
       q_decode   one or two tokens: quantisers inside the GEMM that consumes them (atom_gemm_w4a4_multi_q)
       q_mask     ... which of the four (LlamaDecoderLayer._decode_fused_q): 1 input_layernorm -> q / k / v, 2 reorder -> o_proj,
                  4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 15 since round 6: the quantiser runs once per
@@ -43,7 +45,7 @@ class DecodeFusion:
     decode: bool = True
     kv_append: bool = True
     kv_in_decode: bool = True
-    merge_in_o_proj: bool = False
+    merge_in_o_proj: bool = True
     q_decode: bool = True
     q_mask: int = 15
     q_mask2: int = 2

@@ -361,6 +361,7 @@ def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
     x = (torch.randn(bsz, cfg.hidden_size) * 0.7).half().cuda()
     outs, caches = [], []
     nblk = bsz * (ctx // 16 + 2)
+    prev = E.FUSION.merge_in_o_proj
     for fused in (False, True):
         E.FUSION.merge_in_o_proj = fused
         try:
@@ -379,7 +380,7 @@ def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
             outs.append(layer(x, BatchLenInfo([], bsz, dev), None, kv))
             caches.append((pool.buf.clone(), pool.param.clone()))
         finally:
-            E.FUSION.merge_in_o_proj = False
+            E.FUSION.merge_in_o_proj = prev
     assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1].view(torch.int16), caches[1][1].view(torch.int16))
     assert torch.equal(outs[0], outs[1])
     # the op itself, on the partial states of a decode over the cache just written
@@ -390,6 +391,38 @@ def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
     add = (torch.randn(bsz, cfg.hidden_size, device=dev) * 2).half()
     (want,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o.view(bsz, -1), at.o_proj.single(), reorder_index=at.reorder_index, add=add)
     (got,) = ops.dense_layer_gemm_i4_merge_q(part, ops.decode_splits(bsz, kv), at.o_proj.single(), reorder_index=at.reorder_index, add=add)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("bsz,heads,ctx", [(1, 32, 1030), (1, 32, 2500), (1, 16, 1030), (1, 40, 1030), (1, 8, 1030)])
+def test_merge_q_op_at_llama_widths(bsz, heads, ctx):
+    """The op alone at Llama-7B / 13B widths (hidden 4096: every thread of the eight quantiser waves holds a chunk of the row; 5120: the
+    row needs more than eight waves, no roles), 2-16 partial states per head (two tokens never reach the op: they run the dot-product kernel
+    only for K > 4096, and two rows of that width exceed its one chunk per thread): merge_q on the partial states of a decode
+    against the decode op's own merge launch -> multi_q("reorder"), bit for bit."""
+    from atom_amd import ops
+    from atom_amd.e2e.llama import LinearInt4
+    from atom_amd.utils import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
+    dev = torch.device("cuda")
+    hs = heads * 128
+    g = torch.Generator(device="cuda").manual_seed(heads + ctx)
+    lin = LinearInt4(hs, 1024, out_dtype="fp16", bias=False).cuda()
+    lin.load_fp16_weight((torch.randn(1024, hs, device=dev, generator=g) * 0.05).half())
+    idx = torch.randperm(hs, device=dev, generator=g).to(torch.int16)
+    nblk = bsz * (ctx // 16 + 2)
+    pool = KvPoolInt4(num_layers=1, num_heads=heads, head_dim=128, capacity=nblk, block_len=16, device=dev)
+    pool.buf.copy_(torch.randint(0, 255, pool.buf.shape, device=dev, dtype=torch.uint8, generator=g))
+    pool.param.copy_((torch.rand(pool.param.shape, device=dev, generator=g) * 0.05 + 0.01).half())
+    pool._free = set(range(nblk))
+    kv = BatchedKvCacheInt4([KvCacheInt4(pool, ctx) for _ in range(bsz)])
+    splits = ops.decode_splits(bsz, kv)
+    if splits < 2 or not ops.merge_q_gemm_fits(bsz, 1024, 1, hs, splits):
+        pytest.skip(f"{splits} partial states / shape outside the merge op")
+    q = torch.randn((bsz, heads, 128), device=dev, generator=g).half()
+    part = ops.batch_decode_i4(q, kv, 0, merge=False)
+    o = ops.batch_decode_i4(q, kv, 0)
+    (want,), _ = ops.dense_layer_gemm_i4_multi_q("reorder", o.view(bsz, hs), lin.single(), reorder_index=idx)
+    (got,) = ops.dense_layer_gemm_i4_merge_q(part, splits, lin.single(), reorder_index=idx)
     assert torch.equal(got, want)
 
 

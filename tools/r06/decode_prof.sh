@@ -43,5 +43,10 @@ for k in order:
     v=dur[k]
     print("%7.2f us avg  %6.2f min  x%d per layer  %s"%(sum(v)/len(v),min(v),len(v)//nl,k))
 print("sum of kernel time per layer %.1f us; gaps: avg %.2f us, per layer %.1f us"%(sum(sum(v) for v in dur.values())/nl,sum(gaps)/len(gaps),sum(gaps)/nl))
+# the gap IN FRONT of each launch of a layer (position by position over the layers)
+pos=collections.defaultdict(list)
+for i,r in enumerate(seg):
+    if i: pos[i%per].append((int(r["Start_Timestamp"])-int(seg[i-1]["End_Timestamp"]))/1e3)
+print("gap in front of launch: "+"  ".join("%d: %.2f"%(k,sum(v)/len(v)) for k,v in sorted(pos.items())))
 PY
 cat $O/decode_prof_$TAG.txt

@@ -36,13 +36,19 @@ def run(op, N, nseg, K, copies):
     idx = torch.randperm(K, device=dev).to(torch.int16)
     res = torch.randn((1, K), device=dev).half()
     kw = {"reorder": dict(reorder_index=idx), "rmsnorm": dict(x2=w, reorder_index=idx, eps=1e-5),
-          "add_rmsnorm": dict(x2=w, residual=res, reorder_index=idx, eps=1e-5), "silu_mul": dict(x2=x2)}[op]
+          "add_rmsnorm": dict(x2=w, residual=res, reorder_index=idx, eps=1e-5), "silu_mul": dict(x2=x2), "merge": None}[op]
     buf = torch.zeros(2 * 16 * 16, dtype=torch.int32, device=dev)
+    if op == "merge":                                            # the KV-split merge in front of the reorder quantiser: 8 partial states per head
+        part = torch.randn((1, K // 128, 8, 130), device=dev)
+        part[..., 129] = part[..., 129].abs() + 0.5
+        call = lambda st: ops.dense_layer_gemm_i4_merge_q(part, 8, st, reorder_index=idx)
+    else:
+        call = lambda st: ops.dense_layer_gemm_i4_multi_q(op, x, st, **kw)
     for i in range(3 * copies):
-        ops.dense_layer_gemm_i4_multi_q(op, x, sets[i % copies], **kw)
+        call(sets[i % copies])
     torch.cuda.synchronize()
     os.environ["ATOM_TRACE_PTR"] = hex(buf.data_ptr())
-    ops.dense_layer_gemm_i4_multi_q(op, x, sets[0], **kw)        # its weights were evicted by the other copies: a cold launch
+    call(sets[0])                                                # its weights were evicted by the other copies: a cold launch
     torch.cuda.synchronize()
     del os.environ["ATOM_TRACE_PTR"]
     t = buf.cpu().numpy().astype("uint32").reshape(2, 16, 16)
@@ -61,3 +67,5 @@ run("rmsnorm", 4096, 3, 4096, 12)
 run("reorder", 4096, 1, 4096, 36)
 run("add_rmsnorm", 11008, 2, 4096, 8)
 run("silu_mul", 4096, 1, 11008, 14)
+if os.environ.get("TRACE_MERGE"):
+    run("merge", 4096, 1, 4096, 36)
