@@ -631,9 +631,10 @@ def main():
                                        "weight_stream_us_at_8TBps": 12.6,
                                        "note": "hot = one layer replayed (its 101 MB of weights stay in the Infinity Cache); cold = 8 distinct "
                                                "layers per replay, every launch streams its weights from HBM; cold_frac_hbm = 12.6 us (the "
-                                               "layer's weight bytes at 8 TB/s) / cold_us.  Batch 1: six launches since round 6 (the four "
+                                               "layer's weight bytes at 8 TB/s) / cold_us.  Batch 1: five launches since round 6 (the four "
                                                "activation quantisers inside their projections' launches, csrc/gemvq_w4a4.hip; KV quant + "
-                                               "append inside the attention launch) -- round 5: ten, 55.3 / 59.7 us"}
+                                               "append inside the attention launch; the KV-split merge inside o_proj's) -- round 5: ten, "
+                                               "55.3 / 59.7 us"}
             except Exception as e:                               # pragma: no cover
                 out["decode_layer"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:
