@@ -33,3 +33,21 @@ for op, N, nseg, K in (("rmsnorm", 4096, 3, 4096), ("add_rmsnorm", 11008, 2, 409
     got, _ = ops.dense_layer_gemm_i4_multi_q(op, x, fused, **kw)
     bad += int(not all(torch.equal(a, b) for a, b in zip(got, want)))
     print(op, N * nseg, K, "mismatches", bad)
+
+# the KV-split merge in front of the reorder quantiser (q_op 5: roles + the (m, d) exchange through wave-local LDS), 8 and 16 states per head
+for splits in (8, 16, 3):
+    fused = mk(4096, 4096, 1)
+    g = torch.Generator(device="cuda").manual_seed(splits)
+    part = torch.randn((1, 32, splits, 130), device=dev, generator=g)
+    part[..., 128] *= 4
+    part[..., 129] = part[..., 129].abs() + 0.25
+    idx = torch.randperm(4096, device=dev).to(torch.int16)
+    (want,) = ops.dense_layer_gemm_i4_merge_q(part, splits, fused, reorder_index=idx)
+    want = want.clone()
+    bad = 0
+    for it in range(3000):
+        (got,) = ops.dense_layer_gemm_i4_merge_q(part, splits, fused, reorder_index=idx)
+        if it % 50 == 0 or it > 2950:
+            bad += int(not torch.equal(got, want))
+    torch.cuda.synchronize()
+    print("merge", splits, "states: mismatches", bad)
