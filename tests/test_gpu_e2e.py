@@ -394,20 +394,22 @@ def test_split_merge_inside_o_proj_equals_the_merge_launch(bsz, ctx):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("bsz,heads,ctx", [(1, 32, 1030), (1, 32, 2500), (1, 16, 1030), (1, 40, 1030), (1, 8, 1030)])
-def test_merge_q_op_at_llama_widths(bsz, heads, ctx):
+@pytest.mark.parametrize("bsz,heads,ctx,n_out", [(1, 32, 1030, 1024), (1, 32, 2500, 1024), (1, 16, 1030, 1024), (1, 40, 1030, 1024), (1, 8, 1030, 1024),
+                                                   (1, 32, 1030, 8192), (1, 32, 520, 4096)])
+def test_merge_q_op_at_llama_widths(bsz, heads, ctx, n_out):
     """The op alone at Llama-7B / 13B widths (hidden 4096: every thread of the eight quantiser waves holds a chunk of the row; 5120: the
     row needs more than eight waves, no roles), 2-16 partial states per head (two tokens never reach the op: they run the dot-product kernel
     only for K > 4096, and two rows of that width exceed its one chunk per thread): merge_q on the partial states of a decode
-    against the decode op's own merge launch -> multi_q("reorder"), bit for bit."""
+    against the decode op's own merge launch -> multi_q("reorder"), bit for bit.  8192 outputs: more than two feature steps per streamer
+    wave, so the quantiser waves stream features too (roles without the owning streamers); 4096: the decode layer's own shape."""
     from atom_amd import ops
     from atom_amd.e2e.llama import LinearInt4
     from atom_amd.utils import BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
     dev = torch.device("cuda")
     hs = heads * 128
     g = torch.Generator(device="cuda").manual_seed(heads + ctx)
-    lin = LinearInt4(hs, 1024, out_dtype="fp16", bias=False).cuda()
-    lin.load_fp16_weight((torch.randn(1024, hs, device=dev, generator=g) * 0.05).half())
+    lin = LinearInt4(hs, n_out, out_dtype="fp16", bias=False).cuda()
+    lin.load_fp16_weight((torch.randn(n_out, hs, device=dev, generator=g) * 0.05).half())
     idx = torch.randperm(hs, device=dev, generator=g).to(torch.int16)
     nblk = bsz * (ctx // 16 + 2)
     pool = KvPoolInt4(num_layers=1, num_heads=heads, head_dim=128, capacity=nblk, block_len=16, device=dev)
@@ -416,7 +418,7 @@ def test_merge_q_op_at_llama_widths(bsz, heads, ctx):
     pool._free = set(range(nblk))
     kv = BatchedKvCacheInt4([KvCacheInt4(pool, ctx) for _ in range(bsz)])
     splits = ops.decode_splits(bsz, kv)
-    if splits < 2 or not ops.merge_q_gemm_fits(bsz, 1024, 1, hs, splits):
+    if splits < 2 or not ops.merge_q_gemm_fits(bsz, n_out, 1, hs, splits):
         pytest.skip(f"{splits} partial states / shape outside the merge op")
     q = torch.randn((bsz, heads, 128), device=dev, generator=g).half()
     part = ops.batch_decode_i4(q, kv, 0, merge=False)
