@@ -253,11 +253,12 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
 
   // ---- the weights of this wave's first D steps (NCH <= 2: its first D features)
   constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1), PCH = NCH / PARTS;
-  // D = ring slots (template): the host picks the number of steps a wave of this launch has when that is <= 6 (launch1), so that the
-  // ring holds a wave's WHOLE share, every slot is requested unconditionally, and the first trip below is straight-line code --
-  // hipcc then waits for exactly the step it is about to use (s_waitcnt vmcnt(n) with n > 0).  With requests or refills under
-  // run-time conditions it falls back to vmcnt(0) at every step: a wave then waited for its whole ring before its first feature and ran
-  // its five or six steps with nothing in flight (~4 k idle cycles at the end of gate / up, profiles/r06/gemvq_trace.txt).
+  // D = ring slots (template; the host's choice, launch1: a wave's steps up to two, HALF of them -- two or three slots -- beyond).  Every
+  // slot is requested unconditionally and the first trip below is straight-line code, so that hipcc counts its waits (with requests
+  // under run-time conditions it falls back to vmcnt(0) at every step: a wave then waited for its whole ring before its first feature and
+  // ran its steps with nothing in flight, ~4 k idle cycles at the end of gate / up, profiles/r06/gemvq_trace.txt).  Where the two roles'
+  // paths join in front of the feature loop the wait IS vmcnt(0) -- the ring was requested in different places --: one more reason for
+  // a ring that is not the whole share.
   static_assert(PCH * PARTS == NCH && D % PARTS == 0, "chunks per lane: 1, 2, 4, 6 or 8");
   PartW<PCH> ring[D];
   v4i ring8[D / PARTS];                                           // the keeper chunks / scales of the features in the ring
@@ -659,8 +660,8 @@ static int launch1d(const GemmParams &p, hipStream_t s) {
   return check_launch();
 }
 
-// ring depth: the steps per wave of this launch (its features x parts) when the ring can hold them all -- at most 6 slots at one token
-// and <= 4 chunks per lane, 4 otherwise (registers)
+// ring depth by the steps per wave of this launch (its features x parts): see the rule below; 4 slots for rows of more than 4 chunks per
+// lane and at two tokens (registers)
 template <int QOP, int NCH, int MT>
 static int launch1(const GemmParams &p, hipStream_t s) {
   constexpr int PARTS = NCH > 6 ? 4 : (NCH > 2 ? 2 : 1);
@@ -672,18 +673,29 @@ static int launch1(const GemmParams &p, hipStream_t s) {
     // roles (launch1d's predicate) and a share of at most two steps per streamer wave: they own every feature (OWN)
     const int H_ = p.K4h * 2 + kKeeper, sall = (per_wg + 7) / 8;
     if (p.M == 1 && H_ / 8 <= 8 * 64 && H_ / CPT <= TPT1 * 8 * 64 && ATOM_TUNE("ATOM_GEMVQ_ROLES", 1) && ATOM_TUNE("ATOM_GEMVQ_OWN", 1) && sall <= 2)
-      return sall <= 1 ? launch1d<QOP, NCH, MT, 1, true>(p, s) : launch1d<QOP, NCH, MT, 2, true>(p, s);
+      return (sall <= 1 || ATOM_TUNE("ATOM_GEMVQ_OWN_D", 2) == 1) ? launch1d<QOP, NCH, MT, 1, true>(p, s) : launch1d<QOP, NCH, MT, 2, true>(p, s);
   }
   if constexpr (MT == 1 && NCH <= 4) {
     if constexpr (PARTS == 1) {
-      if (steps <= 1) return launch1d<QOP, NCH, MT, 1>(p, s);
-      if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
-      if (steps <= 3) return launch1d<QOP, NCH, MT, 3>(p, s);
+      // HALF a wave's share in the ring from three steps on (q / k / v: 3 steps, 2 slots; gate / up: 6 steps, 3 slots).  The first form
+      // of this rule put the WHOLE share in flight (ring = steps, up to six slots): that was right while conditional refills made hipcc
+      // wait for the whole ring at every step; with exact waits it is wrong -- a wave cannot compute while it sits in request issue, and
+      // a CU hands out ~10 bytes per clock: the streamers of gate / up were still ISSUING their six slots at 16.7 k cycles, 8 k after
+      // the operand was published, and ran their six steps behind that (profiles/r06/gemvq_trace_final.txt).  Same box, us per layer
+      // cold: six slots 45.7, three 44.1, two 43.8-44.0, one 45.2; per kernel gate / up 12.9 / 11.3 / 11.7 (6 / 3 / 2 slots),
+      // q / k / v 8.56 / 8.01 (3 / 2): profiles/r06/ab_gemvq_ring_depth2.txt.  (ATOM_GEMVQ_DMAX = n in tuning builds: min(steps, n).)
+      const int dmax = ATOM_TUNE("ATOM_GEMVQ_DMAX", 0);
+      const int d = dmax > 0 ? (steps < dmax ? steps : dmax) : (steps <= 2 ? steps : (steps <= 4 ? 2 : 3));
+      if (d <= 1) return launch1d<QOP, NCH, MT, 1>(p, s);
+      if (d == 2) return launch1d<QOP, NCH, MT, 2>(p, s);
+      if (d == 3) return launch1d<QOP, NCH, MT, 3>(p, s);
+      if (d <= 5 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);   // (the merge op has no registers for six slots)
+      return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
     } else {
       if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
+      if (steps <= 4 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);
+      return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
     }
-    if (steps <= 4 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);   // (the merge op has no registers for six slots)
-    return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
   } else {
     return launch1d<QOP, NCH, MT, 4>(p, s);
   }
