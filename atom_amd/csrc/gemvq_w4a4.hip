@@ -215,8 +215,11 @@ __global__ __launch_bounds__(NTH) void gemvq_w4a4_kernel(GemmParams p) {
     for (int sp = 0; sp < PS; ++sp) {
       const int sc = min(sp, p.q_splits - 1);
       if (sp < PH) {
-        po[sp][0] = *reinterpret_cast<const v4f_u *>(wp + sc * 130);
-        po[sp][1] = *reinterpret_cast<const v4f_u *>(wp + sc * 130 + 64);
+        po[sp][0] = po[sp][1] = v4f_u{0.f, 0.f, 0.f, 0.f};
+        if (MT > 1 || sp < p.q_splits) {                    // (workgroup-uniform: a layer at context 1024 has 4 states -- 8 requests, not 16)
+          po[sp][0] = *reinterpret_cast<const v4f_u *>(wp + sc * 130);
+          po[sp][1] = *reinterpret_cast<const v4f_u *>(wp + sc * 130 + 64);
+        }
       }
     }
     // (a wave's vector-memory instruction costs ~16 cycles of the CU's request path whatever its width: with every lane asking for all

@@ -31,8 +31,9 @@ class DecodeFusion:
                  bit-identical, a launch fewer.  Every one of o_proj's 256 workgroups re-reads the partial states of all heads (133 KB at 8
                  states per head: 2 k cycles of a CU's 64 B / clock), so the first form LOST (53.4 -> 57.2 us cold per layer with 16
                  states, 55.2 -> 56.6 with 8: profiles/r06/ab_merge_in_o_proj.txt); with the two-level merge in the attention launch
-                 (8 states at context 1024), quantiser / streamer roles for this op and one (m, d) request per lane it is ahead --
-                 46.3-46.8 -> 45.6-46.0 us at batch 1, 59.7 -> 59.5 at batch 2 (ab_merge_in_o_proj4.txt) -- and on by default.
+                 (4 states at context 1024: 66 KB), quantiser / streamer roles for this op and one (m, d) request per lane it is ahead --
+                 46.3-46.8 -> 45.6-46.0 us at batch 1 (ab_merge_in_o_proj4.txt; two tokens of hidden <= 4096 run the decode-batch kernel and never
+                 reach the op) -- and on by default.
       q_decode   one or two tokens: quantisers inside the GEMM that consumes them (atom_gemm_w4a4_multi_q)
       q_mask     ... which of the four (LlamaDecoderLayer._decode_fused_q): 1 input_layernorm -> q / k / v, 2 reorder -> o_proj,
                  4 add + post_attention_layernorm -> gate / up, 8 SiLU x up -> down_proj.  Default 15 since round 6: the quantiser runs once per

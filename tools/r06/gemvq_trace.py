@@ -38,10 +38,11 @@ def run(op, N, nseg, K, copies):
     kw = {"reorder": dict(reorder_index=idx), "rmsnorm": dict(x2=w, reorder_index=idx, eps=1e-5),
           "add_rmsnorm": dict(x2=w, residual=res, reorder_index=idx, eps=1e-5), "silu_mul": dict(x2=x2), "merge": None}[op]
     buf = torch.zeros(2 * 16 * 16, dtype=torch.int32, device=dev)
-    if op == "merge":                                            # the KV-split merge in front of the reorder quantiser: 8 partial states per head
-        part = torch.randn((1, K // 128, 8, 130), device=dev)
+    if op == "merge":                                            # the KV-split merge in front of the reorder quantiser: TRACE_MERGE partial states per head (4 = a layer at context 1024)
+        ns = int(os.environ.get("TRACE_MERGE", "4"))
+        part = torch.randn((1, K // 128, ns, 130), device=dev)
         part[..., 129] = part[..., 129].abs() + 0.5
-        call = lambda st: ops.dense_layer_gemm_i4_merge_q(part, 8, st, reorder_index=idx)
+        call = lambda st: ops.dense_layer_gemm_i4_merge_q(part, ns, st, reorder_index=idx)
     else:
         call = lambda st: ops.dense_layer_gemm_i4_multi_q(op, x, st, **kw)
     for i in range(3 * copies):

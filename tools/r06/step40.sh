@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, step 40: the KV-split merge inside o_proj's launch, re-measured now that the attention leaves 8 partial states per head at batch 1
+# Round 6, step 40: the KV-split merge inside o_proj's launch, re-measured now that the attention leaves 4 partial states per head at batch 1, context 1024
 # (two-level merge) instead of 16-32.
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/r06; mkdir -p $O

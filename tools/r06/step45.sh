@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, step 45: with the merge inside o_proj's launch, 8 split waves per workgroup (4 partial states per head at context 1024) against 4 (8 states)
+# Round 6, step 45: with the merge inside o_proj's launch, 8 split waves per workgroup (2 partial states per head at context 1024) against 4 (4 states)
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/r06; mkdir -p $O
 run() { echo "== $*"; env "$@" timeout 300 python tools/cold_bench.py layer 1,2 2>&1 | grep "^batch"; }
