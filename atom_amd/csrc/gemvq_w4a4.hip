@@ -695,8 +695,12 @@ static int launch1(const GemmParams &p, hipStream_t s) {
       if (d <= 5 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);   // (the merge op has no registers for six slots)
       return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
     } else {
-      if (steps <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
-      if (steps <= 4 || QOP == 5) return launch1d<QOP, NCH, MT, 4>(p, s);
+      // rows of 3-4 chunks per lane (hidden 5120: Llama-13B): a feature = two steps, and ONE feature in the ring -- the same finding as
+      // above, every wave quantises and streams here (no roles: the row needs more than eight waves' threads): a 13B layer at batch 1
+      // 73.6 (six steps in the ring) / 73.5 (four) / 72.0 us (two), profiles/r06/ab_gemvq_ring_depth_13b.txt.  (ATOM_GEMVQ_DMAX2: tuning)
+      const int dmax = ATOM_TUNE("ATOM_GEMVQ_DMAX2", 2);
+      if (steps <= 2 || dmax <= 2) return launch1d<QOP, NCH, MT, 2>(p, s);
+      if (steps <= 4 || QOP == 5 || dmax <= 4) return launch1d<QOP, NCH, MT, 4>(p, s);
       return launch1d<QOP, NCH, MT, QOP == 5 ? 4 : 6>(p, s);
     }
   } else {

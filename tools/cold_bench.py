@@ -133,6 +133,9 @@ def layer_main(ctx=1024, batches=(1, 16, 64), hidden=4096, heads=32, inter=11008
     from atom_amd.utils import BatchLenInfo, BatchedKvCacheInt4, KvCacheInt4, KvPoolInt4
     cfg = types.SimpleNamespace(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter, rms_norm_eps=1e-5, rope_theta=1e4)
     g = torch.Generator().manual_seed(1)
+    if "ATOM_LAYER_DIMS" in os.environ:                       # tools only: another model's layer, "hidden,heads,inter" (Llama-13B: 5120,40,13824)
+        hidden, heads, inter = (int(v) for v in os.environ["ATOM_LAYER_DIMS"].split(","))
+        cfg = types.SimpleNamespace(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter, rms_norm_eps=1e-5, rope_theta=1e4)
     layers = []
     for li in range(nlayers):
         layer = LlamaDecoderLayer(cfg, layer_idx=0).cuda()
